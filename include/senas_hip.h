@@ -1,0 +1,131 @@
+/*
+ * senas_hip.h -- C ABI of libsenas_hip.so, the MI355X (gfx950) device library behind the SENAS
+ * hot path (supernet MixedOp DAG + derived-genotype encoder/decoder).
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers
+ *     borrowed from the caller (the caller owns them and keeps them alive until the stream has
+ *     passed the launch).  Nothing here allocates, frees or synchronises.
+ *   - activations are fp32, NHWC ("channels_last"): element (n,y,x,c) at ((n*H + y)*W + x)*C + c.
+ *   - weights keep the reference's (torch) parameter layout so that reference checkpoints load
+ *     unchanged: Conv2d [c_out][c_in/groups][kh][kw], ConvTranspose2d [c_in][c_out/groups][kh][kw].
+ *   - every entry point launches on `stream` (a hipStream_t passed as void*) and returns
+ *     SENAS_OK or a negative error code; launch errors are reported, never swallowed.
+ *
+ * The reference has no FFI on this path: it is pure Python on torch.nn, so
+ * each entry point cites the reference call site whose arithmetic it replaces
+ * (paths relative to the reference repository root).
+ */
+#ifndef SENAS_HIP_H
+#define SENAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SENAS_OK            0
+#define SENAS_EINVAL       -1   /* bad argument (null pointer, shape mismatch, unsupported size) */
+#define SENAS_ELAUNCH      -2   /* hipLaunch / runtime error; see senas_last_error()            */
+#define SENAS_EUNSUPPORTED -3
+
+#define SENAS_MAX_TERMS 32
+
+/* Geometry of one convolution, always stated for the FORWARD op y = op(x):
+ *   x: [n][hi][wi][ci]  ->  y: [n][ho][wo][co]
+ * transposed == 0 : nn.Conv2d           (utils/operations.py:128-129)
+ * transposed == 1 : nn.ConvTranspose2d  (utils/operations.py:125-126), output_padding folded in ho/wo
+ * groups is 1 (dense) or ci == co (depthwise, utils/operations.py:110).                        */
+typedef struct senas_conv_geom {
+    int32_t n, hi, wi, ci, ho, wo, co;
+    int32_t kh, kw, stride, pad, dil;
+    int32_t transposed;
+    int32_t groups;
+} senas_conv_geom;
+
+/* ---- convolution (dense and depthwise) ------------------------------------------------------
+ * Replaces the nn.Conv2d / nn.ConvTranspose2d calls made by ConvBn, ConvBnSe, DepSepConv,
+ * AdapterBlock.conv, ShrinkBlock, RectifyBlock, ReLUConv, build_rectify and BasicBlock
+ * (utils/operations.py:81-130,141-152,167-183,206-268).
+ *
+ * in_relu != 0 applies ReLU to x on load (the reference's separate nn.ReLU in front of the conv,
+ * e.g. operations.py:84,142,210); zero padding is applied after that ReLU, as in the reference.
+ * stats (optional, may be NULL): double[n][co][2], the kernel ADDS per-image per-channel sum and
+ * sum of squares of y into it (producer-side batch-norm statistics; caller zeroes it).          */
+/* ws: device scratch of at least senas_conv2d_ws_bytes(g) bytes (repacked weights / partial sums),
+ * private to the call until the stream has passed it.                                          */
+int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);
+int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y,
+                     int in_relu, double* stats, void* ws, void* stream);
+/* dx = d loss / d x.  If in_relu != 0, x must be given and dx is masked by (x > 0).            */
+int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx,
+                          int in_relu, const float* x, void* ws, void* stream);
+/* dw (same layout as w) is OVERWRITTEN.                                                        */
+int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
+                            float* dw, void* ws, void* stream);
+
+/* ---- pooling / resampling --------------------------------------------------------------------
+ * nn.AvgPool2d(3, stride, 1, count_include_pad=False)  (operations.py:62,150)
+ * nn.MaxPool2d(3, stride, 1)                            (operations.py:64; senas_search.py:31)
+ * nn.Upsample(scale_factor=2, 'bilinear', align_corners=False) (operations.py:13,145)
+ * x: [n][h][w][c]; stride in {1,2}.  in_relu as above.  stats as above (may be NULL).           */
+int senas_avgpool3_fwd(int n, int h, int w, int c, int stride, const float* x, int in_relu, float* y,
+                       double* stats, void* stream);
+int senas_avgpool3_bwd(int n, int h, int w, int c, int stride, const float* dy, int in_relu,
+                       const float* x, float* dx, void* stream);
+/* argmax: uint8[n][ho][wo][c], window-local index (ky*3+kx) of the first maximum.                */
+int senas_maxpool3_fwd(int n, int h, int w, int c, int stride, const float* x, int in_relu, float* y,
+                       uint8_t* argmax, double* stats, void* stream);
+int senas_maxpool3_bwd(int n, int h, int w, int c, int stride, const float* dy, const uint8_t* argmax,
+                       int in_relu, const float* x, float* dx, void* stream);
+int senas_bilinear2x_fwd(int n, int h, int w, int c, const float* x, float* y, double* stats, void* stream);
+int senas_bilinear2x_bwd(int n, int h, int w, int c, const float* dy, float* dx, void* stream);
+
+/* ---- elementwise ReLU (Cell.preprocess1, search/cell.py:66,94; senas_model.py:15,52) ---------- */
+int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream);
+int senas_relu_bwd(int64_t numel, const float* dy, const float* y, float* dx, void* stream);
+
+/* ---- batch-norm statistics --------------------------------------------------------------------
+ * Per-image per-channel sum / sum-of-squares of x [n][hw][c] ADDED into stats double[n][c][2].   */
+int senas_chan_stats(int n, int64_t hw, int c, const float* x, double* stats, void* stream);
+
+/* nn.BatchNorm2d training/eval semantics (operations.py:133-134; torch defaults eps=1e-5,
+ * momentum=0.1, biased variance for normalisation, unbiased for running_var).
+ * stats: double[n][c][2] as produced above (ignored when training == 0).
+ * Outputs (float[c] each): mean, invstd, scale = gamma*invstd, shift = beta - mean*scale.
+ * When training != 0 the running buffers are updated in place and *num_batches_tracked += 1.   */
+int senas_bn_finalize(int n, int64_t hw, int c, const double* stats, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float momentum, float eps, int training,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* ---- fused "normalise, gate, mix, add, activate" ------------------------------------------------
+ * y[n,p,c] = act( sum_t coef[t][n][c] * z_t[n,p,c] + bias[n][c] (+ residual[n,p,c]) )
+ * This single pass replaces, per cell node, the BatchNorm2d of every candidate op, the SE channel
+ * scale (operations.py:203), the alpha-weighted MixedOp sum (search/cell.py:34-36), the
+ * beta-weighted edge sum (search/cell.py:104-105), the node add of the derived cell
+ * (senas_model.py:62), the residual add of BasicBlock (operations.py:266) and the node ReLU
+ * (search/cell.py:107).  coef: float[nterms][n][c]; bias: float[n][c] (device);
+ * z / dz: HOST arrays of nterms device pointers (copied into the launch arguments).             */
+int senas_combine_fwd(int n, int64_t hw, int c, int nterms, const float* const* z, const float* coef,
+                      const float* bias, const float* residual, int relu, float* y, void* stream);
+/* Backward reductions: with ds = dy * (relu ? y > 0 : 1),
+ *   p1[n][c]      += sum_p ds          (double)
+ *   p2[t][n][c]   += sum_p ds * z_t    (double)       -- caller zeroes p1/p2.                    */
+int senas_combine_bwd_reduce(int n, int64_t hw, int c, int nterms, const float* const* z, const float* dy,
+                             const float* y, int relu, double* p1, double* p2, void* stream);
+/* Backward apply: dz_t = a[t][n][c] * ds + b[t][n][c] * z_t + k[t][n][c]  (dz_t may be NULL: skipped)
+ * ds_out (optional): receives ds itself (gradient of the residual input).                       */
+int senas_combine_bwd_apply(int n, int64_t hw, int c, int nterms, const float* const* z, const float* dy,
+                            const float* y, int relu, const float* a, const float* b, const float* k,
+                            float* const* dz, float* ds_out, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+const char* senas_last_error(void);
+int senas_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SENAS_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libsenas_hip.so (the C ABI declared in include/senas_hip.h).
+
+There is no fallback: if the shared library is missing or an entry point reports an error this
+module raises.  Nothing here imports ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
+
+OK = 0
+MAX_TERMS = 32
+
+
+class ConvGeom(C.Structure):
+    """senas_conv_geom (include/senas_hip.h)."""
+    _fields_ = [(k, C.c_int32) for k in ('n', 'hi', 'wi', 'ci', 'ho', 'wo', 'co', 'kh', 'kw', 'stride', 'pad', 'dil',
+                                         'transposed', 'groups')]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_G = C.POINTER(ConvGeom)
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/senas_hip.h one to one
+SIGNATURES = {
+    'senas_conv2d_ws_bytes': (C.c_int64, [_G]),
+    'senas_conv2d_fwd': (_I, [_G, _P, _P, _P, _I, _P, _P, _P]),
+    'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P]),
+    'senas_conv2d_bwd_weight': (_I, [_G, _P, _I, _P, _P, _P, _P]),
+    'senas_avgpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    'senas_avgpool3_bwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    'senas_maxpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    'senas_maxpool3_bwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'senas_bilinear2x_fwd': (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    'senas_bilinear2x_bwd': (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    'senas_relu_fwd': (_I, [_L, _P, _P, _P]),
+    'senas_relu_bwd': (_I, [_L, _P, _P, _P, _P]),
+    'senas_chan_stats': (_I, [_I, _L, _I, _P, _P, _P]),
+    'senas_bn_finalize': (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
+    'senas_combine_fwd': (_I, [_I, _L, _I, _I, _PP, _P, _P, _P, _I, _P, _P]),
+    'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
+    'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),
+    'senas_last_error': (C.c_char_p, []),
+    'senas_abi_version': (_I, []),
+}
+
+_lib = None
+
+
+class SenasHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SenasHipError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                                'or `make -C senas_amd/csrc`; there is no CPU fallback' % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the .so does not export the symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != OK:
+        raise SenasHipError('%s failed (%d): %s' % (what, code, lib().senas_last_error().decode()))
+
+
+def ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return arr

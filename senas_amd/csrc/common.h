@@ -1,0 +1,80 @@
+// Shared helpers for the gfx950 kernels of libsenas_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/senas_hip.h"
+
+namespace senas {
+
+void set_error(const char* what, hipError_t e);
+void set_error_msg(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Every launcher ends with this: report (not swallow) launch failures.
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(what, e); return SENAS_ELAUNCH; }
+    return SENAS_OK;
+}
+
+#define SENAS_REQUIRE(cond, msg)                                     \
+    do { if (!(cond)) { ::senas::set_error_msg(msg); return SENAS_EINVAL; } } while (0)
+
+constexpr int kWave = 64;   // gfx950 wavefront
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+// Geometry of one "gather" pass: out[n,oy,ox,:] reads in[n, f(oy,ky), f(ox,kx), :].
+//   plain      : iy = oy*stride - pad + ky*dil                       (conv fwd, convT dgrad)
+//   transposed : iy = (oy + pad - ky*dil)/stride when divisible      (convT fwd, conv dgrad)
+struct GatherGeom {
+    int n, hin, win, cin, hout, wout, cout;
+    int kh, kw, stride, pad, dil;
+};
+
+template <bool TG>
+__device__ __forceinline__ bool tap_src(const GatherGeom& g, int o, int k, int lim, int& i) {
+    if (!TG) {
+        i = o * g.stride - g.pad + k * g.dil;
+    } else {
+        int t = o + g.pad - k * g.dil;
+        if (t < 0) return false;
+        if (g.stride == 2) { if (t & 1) return false; i = t >> 1; }
+        else i = t;
+    }
+    return i >= 0 && i < lim;
+}
+
+// V consecutive floats (V == 4: one 16-byte access; the caller guarantees 16-byte alignment)
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = p[j];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) p[j] = v[j];
+    }
+}
+
+}  // namespace senas

@@ -1,0 +1,380 @@
+// Convolution kernels (dense + depthwise), NHWC fp32, gfx950.
+//
+// "direct" family: one lane = one output pixel, the weight tile of the block is wave-uniform so it
+// is fetched through the scalar cache (s_load) and every FMA has an SGPR operand; activations are
+// read as 16-byte vectors along the channel axis.  Handles every shape on the path (any channel
+// count, stride 1/2, dilation, transposed) and is the fallback for the MFMA kernels in conv_mfma.hip.
+#include "common.h"
+
+namespace senas {
+
+// ---------------------------------------------------------------------------------------------
+// weight repack: torch layout src[d0][d1][taps] -> dst[tap][A][B]
+//   swap == 0: A = d0, B = d1        swap == 1: A = d1, B = d0
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int taps,
+                                    int swap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = d0 * d1 * taps;
+    if (i >= total) return;
+    // iterate in dst order for coalesced stores
+    int A = swap ? d1 : d0, B = swap ? d0 : d1;
+    int b = i % B, a = (i / B) % A, t = i / (A * B);
+    int s0 = swap ? b : a, s1 = swap ? a : b;
+    dst[i] = src[(s0 * d1 + s1) * taps + t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense direct conv.  wp: [tap][cin][cout].  grid = (pixel tiles, n, cout tiles)
+template <int COT, bool TG, bool VEC4>
+__global__ __launch_bounds__(256) void conv_direct_kernel(GatherGeom g, const float* __restrict__ in,
+                                                          const float* __restrict__ wp, float* __restrict__ out,
+                                                          int in_relu, const float* __restrict__ mask,
+                                                          double* __restrict__ stats) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    const int cob = blockIdx.z * COT;
+    const bool live = pix < g.hout * g.wout;
+    const int oy = live ? pix / g.wout : 0, ox = live ? pix % g.wout : 0;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = 0.f;
+
+    for (int ky = 0; ky < g.kh; ++ky) {
+        int iy;
+        const bool oky = tap_src<TG>(g, oy, ky, g.hin, iy);
+        for (int kx = 0; kx < g.kw; ++kx) {
+            int ix;
+            const bool ok = live && oky && tap_src<TG>(g, ox, kx, g.win, ix);
+            const float* wt = wp + (size_t)(ky * g.kw + kx) * g.cin * g.cout + cob;
+            if (ok) {
+                const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin;
+                if (VEC4) {
+                    for (int ci = 0; ci < g.cin; ci += 4) {
+                        float4 v = *reinterpret_cast<const float4*>(ip + ci);
+                        if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        const float* w0 = wt + (size_t)ci * g.cout;
+#pragma unroll
+                        for (int j = 0; j < COT; ++j) {
+                            if (cob + j < g.cout) {
+                                acc[j] = fmaf(v.x, w0[j], acc[j]);
+                                acc[j] = fmaf(v.y, w0[g.cout + j], acc[j]);
+                                acc[j] = fmaf(v.z, w0[2 * g.cout + j], acc[j]);
+                                acc[j] = fmaf(v.w, w0[3 * g.cout + j], acc[j]);
+                            }
+                        }
+                    }
+                } else {
+                    for (int ci = 0; ci < g.cin; ++ci) {
+                        float v = ip[ci];
+                        if (in_relu) v = fmaxf(v, 0.f);
+                        const float* w0 = wt + (size_t)ci * g.cout;
+#pragma unroll
+                        for (int j = 0; j < COT; ++j)
+                            if (cob + j < g.cout) acc[j] = fmaf(v, w0[j], acc[j]);
+                    }
+                }
+            }
+        }
+    }
+    const size_t obase = ((size_t)n * g.hout * g.wout + pix) * g.cout + cob;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            if (cob + j < g.cout) {
+                float v = acc[j];
+                if (mask != nullptr && !(mask[obase + j] > 0.f)) v = 0.f;
+                acc[j] = v;
+                out[obase + j] = v;
+            }
+        }
+    }
+    if (stats != nullptr) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            if (cob + j < g.cout) {
+                double v = live ? (double)acc[j] : 0.0;
+                double s = wave_sum(v), q = wave_sum(v * v);
+                if (lane == 0) {
+                    double* st = stats + ((size_t)n * g.cout + cob + j) * 2;
+                    atomicAdd(st, s);
+                    atomicAdd(st + 1, q);
+                }
+            }
+        }
+    }
+}
+
+template <bool TG>
+static int launch_direct(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
+                         const float* mask, double* stats, hipStream_t st) {
+    const int tiles = (g.hout * g.wout + 255) / 256;
+    const bool v4 = (g.cin % 4) == 0;
+#define SENAS_GO(COT)                                                                                       \
+    do {                                                                                                    \
+        dim3 grid(tiles, g.n, (g.cout + COT - 1) / COT);                                                    \
+        if (v4) hipLaunchKernelGGL((conv_direct_kernel<COT, TG, true>), grid, dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats); \
+        else hipLaunchKernelGGL((conv_direct_kernel<COT, TG, false>), grid, dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats);   \
+    } while (0)
+    if (g.cout >= 16) SENAS_GO(16);
+    else if (g.cout > 4) SENAS_GO(8);
+    else SENAS_GO(4);
+#undef SENAS_GO
+    return launch_status("conv_direct");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense weight gradient.  dW[b][a][tap] = sum_{n,p} I[n, p*s - pad + k*d][a] * G[n,p][b]
+// G lives on the coarse grid (hg x wg, channels B), I on the fine grid (hi x wi, channels A).
+// grid = (pixel chunks, taps, a-tiles * b-tiles); block 256 = 32 b-lanes x 8 a-groups of 4.
+struct WgradGeom {
+    int n, hg, wg, B, hi, wi, A, kh, kw, stride, pad, dil, chunk;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGeom g, const float* __restrict__ I,
+                                                         const float* __restrict__ G, float* __restrict__ dw,
+                                                         int i_relu, int g_relu) {
+    const int tap = blockIdx.y, ky = tap / g.kw, kx = tap % g.kw;
+    const int btiles = (g.B + 31) / 32;
+    const int b = (blockIdx.z % btiles) * 32 + (threadIdx.x & 31);
+    const int a0 = (blockIdx.z / btiles) * 32 + (threadIdx.x >> 5) * 4;
+    const int per_img = g.hg * g.wg;
+    const long total = (long)g.n * per_img;
+    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    if (p1 > total) p1 = total;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bok = b < g.B;
+    for (long p = p0; p < p1; ++p) {
+        const int n = (int)(p / per_img), r = (int)(p % per_img);
+        const int gy = r / g.wg, gx = r % g.wg;
+        const int iy = gy * g.stride - g.pad + ky * g.dil, ix = gx * g.stride - g.pad + kx * g.dil;
+        if (iy < 0 || iy >= g.hi || ix < 0 || ix >= g.wi) continue;   // block-uniform
+        float gv = bok ? G[(size_t)p * g.B + b] : 0.f;
+        if (g_relu) gv = fmaxf(gv, 0.f);
+        const float* ip = I + ((size_t)(n * g.hi + iy) * g.wi + ix) * g.A;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (a0 + j < g.A) {
+                float iv = ip[a0 + j];
+                if (i_relu) iv = fmaxf(iv, 0.f);
+                acc[j] = fmaf(iv, gv, acc[j]);
+            }
+        }
+    }
+    if (bok) {
+        const int taps = g.kh * g.kw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (a0 + j < g.A) atomicAdd(&dw[((size_t)b * g.A + a0 + j) * taps + tap], acc[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise.  w: torch layout [c][1][kh][kw] (same indexing for Conv2d and ConvTranspose2d).
+// one thread = 4 channels of one output pixel (c % 4 == 0) or 1 channel.
+template <bool TG, int V>
+__global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
+                                                     const float* __restrict__ w, float* __restrict__ out,
+                                                     int in_relu, const float* __restrict__ mask,
+                                                     double* __restrict__ stats, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = g.cout / V;
+    const int c = (int)(idx % cv) * V;
+    long pix = idx / cv;
+    const int ox = (int)(pix % g.wout);
+    pix /= g.wout;
+    const int oy = (int)(pix % g.hout), n = (int)(pix / g.hout);
+    const int taps = g.kh * g.kw;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < g.kh; ++ky) {
+        int iy;
+        if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
+        for (int kx = 0; kx < g.kw; ++kx) {
+            int ix;
+            if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
+            const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
+            float v[V];
+            ldv<V>(ip, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float x = in_relu ? fmaxf(v[j], 0.f) : v[j];
+                acc[j] = fmaf(x, w[(c + j) * taps + ky * g.kw + kx], acc[j]);
+            }
+        }
+    }
+    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + c;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        float r = acc[j];
+        if (mask != nullptr && !(mask[o + j] > 0.f)) r = 0.f;
+        out[o + j] = r;
+        if (stats != nullptr) {
+            double* st = stats + ((size_t)n * g.cout + c + j) * 2;
+            atomicAdd(st, (double)r);
+            atomicAdd(st + 1, (double)r * r);
+        }
+    }
+}
+
+// depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
+// grid = (pixel chunks, taps); block = rows x C lanes, C <= 256.
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const float* __restrict__ I,
+                                                           const float* __restrict__ G, float* __restrict__ dw,
+                                                           int i_relu, int g_relu) {
+    __shared__ float red[256];
+    const int C = g.A;
+    const int rows = 256 / C;
+    const int c = threadIdx.x % C, row = threadIdx.x / C;
+    const int tap = blockIdx.y, ky = tap / g.kw, kx = tap % g.kw;
+    const int per_img = g.hg * g.wg;
+    const long total = (long)g.n * per_img;
+    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    if (p1 > total) p1 = total;
+    float acc = 0.f;
+    if (row < rows) {
+        for (long p = p0 + row; p < p1; p += rows) {
+            const int n = (int)(p / per_img), r = (int)(p % per_img);
+            const int gy = r / g.wg, gx = r % g.wg;
+            const int iy = gy * g.stride - g.pad + ky * g.dil, ix = gx * g.stride - g.pad + kx * g.dil;
+            if (iy < 0 || iy >= g.hi || ix < 0 || ix >= g.wi) continue;
+            float gv = G[(size_t)p * C + c];
+            float iv = I[((size_t)(n * g.hi + iy) * g.wi + ix) * C + c];
+            if (g_relu) gv = fmaxf(gv, 0.f);
+            if (i_relu) iv = fmaxf(iv, 0.f);
+            acc = fmaf(iv, gv, acc);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (row == 0) {
+        for (int r = 1; r < rows; ++r) acc += red[r * C + c];
+        atomicAdd(&dw[c * g.kh * g.kw + tap], acc);
+    }
+}
+
+static bool geom_ok(const senas_conv_geom* g) {
+    if (!g || g->n <= 0 || g->ci <= 0 || g->co <= 0 || g->kh <= 0 || g->kw <= 0) return false;
+    if (g->stride != 1 && g->stride != 2) return false;
+    if (g->groups != 1 && !(g->groups == g->ci && g->ci == g->co)) return false;
+    int ho, wo;
+    if (!g->transposed) {
+        ho = (g->hi + 2 * g->pad - g->dil * (g->kh - 1) - 1) / g->stride + 1;
+        wo = (g->wi + 2 * g->pad - g->dil * (g->kw - 1) - 1) / g->stride + 1;
+        return ho == g->ho && wo == g->wo;
+    }
+    // transposed: ho = (hi-1)*s - 2p + d(k-1) + output_padding + 1, output_padding in [0, s)
+    int base = (g->hi - 1) * g->stride - 2 * g->pad + g->dil * (g->kh - 1) + 1;
+    int basw = (g->wi - 1) * g->stride - 2 * g->pad + g->dil * (g->kw - 1) + 1;
+    return g->ho >= base && g->ho < base + g->stride && g->wo >= basw && g->wo < basw + g->stride;
+}
+
+}  // namespace senas
+
+using namespace senas;
+
+extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
+    if (!g) return 0;
+    if (g->groups != 1) return 16;
+    return (int64_t)g->kh * g->kw * g->ci * g->co * sizeof(float) + 256;
+}
+
+// forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
+extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
+                                double* stats, void* ws, void* stream) {
+    SENAS_REQUIRE(geom_ok(g), "conv2d_fwd: inconsistent geometry");
+    SENAS_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (g->groups != 1) {
+        const int V = (g->co % 4 == 0) ? 4 : 1;
+        long total = (long)g->n * g->ho * g->wo * (g->co / V);
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (g->transposed) {
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+        } else {
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+        }
+        return launch_status("dwconv_fwd");
+    }
+    SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
+    float* wp = reinterpret_cast<float*>(ws);
+    const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    // Conv2d w[co][ci][tap] -> wp[tap][ci][co] (swap); ConvTranspose2d w[ci][co][tap] -> wp[tap][ci][co]
+    if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 1);
+    else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 0);
+    if (!g->transposed) return launch_direct<false>(gg, x, wp, y, in_relu, nullptr, stats, st);
+    return launch_direct<true>(gg, x, wp, y, in_relu, nullptr, stats, st);
+}
+
+// data gradient: Conv2d -> transposed gather over dy; ConvTranspose2d -> plain gather over dy
+extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx, int in_relu,
+                                     const float* x, void* ws, void* stream) {
+    SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_data: inconsistent geometry");
+    SENAS_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
+    SENAS_REQUIRE(!in_relu || x, "conv2d_bwd_data: in_relu needs x");
+    hipStream_t st = as_stream(stream);
+    const float* mask = in_relu ? x : nullptr;
+    GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (g->groups != 1) {
+        const int V = (g->ci % 4 == 0) ? 4 : 1;
+        long total = (long)g->n * g->hi * g->wi * (g->ci / V);
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (!g->transposed) {
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+        } else {
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+        }
+        return launch_status("dwconv_bwd_data");
+    }
+    SENAS_REQUIRE(ws, "conv2d_bwd_data: null workspace");
+    float* wp = reinterpret_cast<float*>(ws);
+    const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    // wp[tap][a = co][b = ci]
+    if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 0);
+    else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 1);
+    if (!g->transposed) return launch_direct<true>(gg, dy, wp, dx, 0, mask, nullptr, st);
+    return launch_direct<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
+}
+
+extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw,
+                                       void* ws, void* stream) {
+    (void)ws;
+    SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_weight: inconsistent geometry");
+    SENAS_REQUIRE(x && dy && dw, "conv2d_bwd_weight: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int taps = g->kh * g->kw;
+    WgradGeom wg;
+    const float *I, *G;
+    int i_relu, g_relu;
+    if (!g->transposed) {   // I = x (fine grid), G = dy (coarse grid)
+        wg = WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        I = x; G = dy; i_relu = in_relu; g_relu = 0;
+    } else {                // I = dy (fine grid), G = x (coarse grid)
+        wg = WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        I = dy; G = x; i_relu = 0; g_relu = in_relu;
+    }
+    const long total = (long)wg.n * wg.hg * wg.wg;
+    if (g->groups != 1) {
+        SENAS_REQUIRE(g->ci <= 256, "depthwise wgrad: more than 256 channels");
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * taps * sizeof(float), st);
+        if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }
+        wg.chunk = 4096;
+        dim3 grid((unsigned)((total + wg.chunk - 1) / wg.chunk), taps);
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
+        return launch_status("dwconv_wgrad");
+    }
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * g->co * taps * sizeof(float), st);
+    if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }
+    wg.chunk = 1024;
+    const int tiles = ((wg.A + 31) / 32) * ((wg.B + 31) / 32);
+    dim3 grid((unsigned)((total + wg.chunk - 1) / wg.chunk), taps, tiles);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
+    return launch_status("conv_wgrad");
+}

@@ -1,0 +1,54 @@
+"""The UNet++-style macro grid shared by the supernet and the derived network.
+
+Level 0 is the down path (stem1 + depth-1 down cells); level i >= 1 holds the up cells
+``(i, j)``, j = 0 .. depth-i-1.  Up cell (i, j) takes as in0 the concatenation of the outputs that
+currently sit at positions j .. i+j-1 of the running output list (all at resolution level j) and
+as in1 the output at position i+j, and overwrites position i+j.
+Reference: search/senas_search.py:16-112 and models/senas_model.py:78-179 build and walk the same
+grid; here the bookkeeping lives in one place.
+"""
+import torch.nn as nn
+
+from .operations import ConvBn, Stem1
+
+
+def gamma_index(i, j):
+    """Index into the flat gamma table of the skip feeding row i+j from column j."""
+    return sum(range(i + j)) + j
+
+
+class MacroGrid(nn.Module):
+    """Owns ``stem0``, ``stem1``, ``blocks`` and ``head_block`` with the reference's names.
+
+    make_cell(cell_type, c_in0, c_in1, c_out, i, j) -> nn.Module or None (None = pruned up cell)
+    make_head(c_in0, c_in1, nclass) -> nn.Module
+    """
+
+    def __init__(self, in_channels, c, nclass, depth, double_down_channel, make_cell, make_head):
+        super().__init__()
+        assert depth >= 2, 'depth must >= 2'
+        self._depth = depth
+        self._double_down_channel = double_down_channel
+        double = 2 if double_down_channel else 1
+        self.blocks = nn.ModuleList()
+        self.stem0 = ConvBn(in_channels, c, kernel_size=7)
+        self.stem1 = Stem1(c, c)
+        widths = [[c]]                       # widths[level][j] = channels produced at grid slot (level, j)
+        row = nn.ModuleList([self.stem1])
+        c_in0, c_in1, c_cur = c, c, c
+        for _ in range(1, depth):
+            c_cur = int(double * c_cur)
+            row.append(make_cell('down', c_in0, c_in1, c_cur, 0, len(row)))
+            widths[0].append(c_cur)
+            c_in0, c_in1 = c_in1, c_cur
+        self.blocks.append(row)
+        for i in range(1, depth):
+            row, wrow = nn.ModuleList(), []
+            for j in range(depth - i):
+                c_skip = sum(widths[k][j] for k in range(i))
+                cell = make_cell('up', c_skip, widths[i - 1][j + 1], widths[0][j], i, j)
+                row.append(cell)
+                wrow.append(widths[0][j] if cell is not None else 0)
+            self.blocks.append(row)
+            widths.append(wrow)
+        self.head_block = nn.ModuleList([make_head(c, widths[-1][0], nclass)])

@@ -1,0 +1,99 @@
+"""Derived ("expanded") network of the SENAS train phase: ``BuildCell`` wires the ops a
+``Genotype`` names, ``SenasModel`` stacks them on the macro grid, pruning the up cells whose gamma
+entry is 0.  Same public surface as the reference's ``models/senas_model.py`` (BuildCell :4-64,
+Head :67-75, SenasModel :78-179).
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .grid import MacroGrid, gamma_index
+from .operations import OPS, OpType, RectifyBlock, ReLUConv, ShrinkBlock, build_activation, build_rectify
+
+
+class BuildCell(nn.Module):
+    def __init__(self, genotype, double_down, c_in0, c_in1, c_out, cell_type, dropout_prob=0):
+        super().__init__()
+        if cell_type == 'down':
+            self.preprocess0 = build_rectify(c_in0, c_in1, cell_type)
+            c_part = c_out // double_down
+            gene, concat = genotype.down, genotype.down_concat
+        else:
+            self.preprocess0 = ShrinkBlock(c_in0, c_in1)
+            c_part = c_out
+            gene, concat = genotype.up, genotype.up_concat
+        self.preprocess1 = build_activation(False)
+        self.node_activation = build_activation()
+        self.post_process = RectifyBlock(c_part * len(concat), c_out, cell_type=cell_type)
+        self.dropout_prob = dropout_prob
+        self._concat = concat
+        self._multiplier = len(concat)
+        self._input_num = 2
+        self._num_meta_node = len(gene) // 2
+        self._indices = tuple(idx for _, idx in gene)
+
+        def edge_type(idx):
+            if idx >= self._input_num:
+                return OpType.NORM
+            if cell_type == 'down':
+                return OpType.DOWN
+            return OpType.UP if idx > 0 else OpType.NORM
+
+        self._ops = nn.ModuleList(
+            OPS[name](c_in1 if idx < self._input_num else c_part, c_part, edge_type(idx), dropout_prob)
+            for name, idx in gene)
+
+    def forward(self, in0, in1):
+        states = [self.preprocess0(in0), self.preprocess1(in1)]
+        for i in range(self._num_meta_node):
+            pair = [self._ops[e].raw(states[self._indices[e]]) for e in (2 * i, 2 * i + 1)]
+            states.append(F.bn_combine(pair, relu=True))           # ReLU(op_a(.) + op_b(.)) in one pass
+        return self.post_process(torch.cat([states[i] for i in self._concat], dim=1))
+
+
+class Head(nn.Module):
+    def __init__(self, genotype, double_down, c_in0, c_in1, nclass):
+        super().__init__()
+        self.up_cell = BuildCell(genotype, double_down, c_in0, c_in1, c_in1, cell_type='up')
+        self.segmentation_head = ReLUConv(c_in1, nclass, kernel_size=3)
+
+    def forward(self, s0, ot):
+        return self.segmentation_head(self.up_cell(s0, ot))
+
+
+class SenasModel(MacroGrid):
+    def __init__(self, nclass, in_channels, c=32, depth=5, dropout_prob=0, supervision=False, genotype=None,
+                 double_down_channel=False):
+        double = 2 if double_down_channel else 1
+        gamma = genotype.gamma
+
+        def make_cell(kind, c0, c1, co, i, j):
+            if kind == 'up' and i + j < depth - 1 and gamma[gamma_index(i, j)] == 0:
+                return None                                        # pruned skip cell
+            return BuildCell(genotype, double, c0, c1, co, cell_type=kind, dropout_prob=dropout_prob)
+
+        super().__init__(in_channels, c, nclass, depth, double_down_channel, make_cell=make_cell,
+                         make_head=lambda c0, c1, ncls: Head(genotype, double, c0, c1, ncls))
+        self._supervision = supervision
+        self._meta_node_num = len(genotype.down_concat)
+        self.gamma = gamma
+
+    def forward(self, x):
+        s0 = self.stem0(x)
+        outs = [self.stem1(s0)]
+        for j in range(1, self._depth):
+            outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1]))
+        for j in reversed(range(self._depth - 1)):
+            for i in range(1, self._depth - j):
+                cell = self.blocks[i][j]
+                if cell is None:
+                    outs[i + j] = None
+                    continue
+                skips = [outs[t] for t in range(j, i + j) if outs[t] is not None]
+                outs[i + j] = cell(skips[0] if len(skips) == 1 else torch.cat(skips, dim=1), outs[i + j])
+        head = self.head_block[-1]
+        tails = outs if self._supervision else outs[-1:]
+        if any(o is None for o in tails):
+            raise TypeError('deep supervision needs every grid column alive; this genotype prunes some '
+                            '(the reference fails the same way, models/senas_model.py:177)')
+        return [head(s0, o) for o in tails]

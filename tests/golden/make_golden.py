@@ -1,0 +1,480 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference); the resulting ``*.npz`` files are
+data (inputs, weights, expected outputs / gradients) and are committed.  The reference's source
+never leaves /root/reference.
+
+Import recipe: the reference's ``utils`` package imports a few libraries
+that are absent here and that the hot path never calls (graphviz, cv2, torchvision.utils.make_grid,
+ptflops, torchstat); inert placeholder modules are registered for those names only.
+``models/senas_model.py`` is loaded by file path because ``models/__init__.py`` imports the
+un-vendored torchvision encoders.
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+BIG = 4096          # parameters above this size get a gradient digest instead of the full tensor
+HEAD = 1024
+
+
+def _import_reference():
+    for name, attrs in {'graphviz': ['Digraph'], 'cv2': [], 'torchvision': [], 'torchvision.utils': ['make_grid'],
+                        'ptflops': ['get_model_complexity_info'], 'torchstat': ['stat']}.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, None)
+            sys.modules[name] = m
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    sys.path.insert(0, REF)
+    import search.senas_search as S
+    import search.cell as C
+    import utils.operations as O
+    import utils.genotype as G
+    from utils.loss.loss import SegmentationLosses
+    from utils.metrics import SegmentationMetric
+    spec = importlib.util.spec_from_file_location('ref_senas_model', os.path.join(REF, 'models/senas_model.py'))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    spec = importlib.util.spec_from_file_location('ref_geno_searched', os.path.join(REF, 'models/geno_searched.py'))
+    GS = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(GS)
+    return S, C, O, G, M, GS, SegmentationLosses, SegmentationMetric
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _rand_init(module, gen):
+    """Deterministic, non-trivial values for every parameter and BN buffer (weights_init would
+    leave BN at weight 1 / bias 0, which hides affine bugs)."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() >= 2:
+                fan = max(1, p[0].numel())
+                p.copy_(torch.randn(p.shape, generator=gen) * (1.5 / fan ** 0.5))
+            elif 'alphas' in name or 'betas' in name or 'gamma' in name:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.5)
+            elif name.endswith('weight'):
+                p.copy_(1.0 + 0.3 * torch.randn(p.shape, generator=gen))
+            else:
+                p.copy_(0.2 * torch.randn(p.shape, generator=gen))
+        for name, b in module.named_buffers():
+            if name.endswith('running_mean'):
+                b.copy_(0.1 * torch.randn(b.shape, generator=gen))
+            elif name.endswith('running_var'):
+                b.copy_(1.0 + 0.2 * torch.rand(b.shape, generator=gen))
+
+
+def _state(module, prefix='sd0/'):
+    return {prefix + k: _np(v) for k, v in module.state_dict().items()}
+
+
+def _grads(module, prefix='grad/'):
+    out = {}
+    for k, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        g = _np(p.grad)
+        if g.size <= BIG:
+            out[prefix + k] = g
+        else:
+            out[prefix + k + '#head'] = g.reshape(-1)[:HEAD]
+            out[prefix + k + '#sum'] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+    return out
+
+
+def _pack(named, prefix):
+    """Flat-pack many tensors into one float32 vector + a JSON index (name, shape, offset); integer
+    buffers (num_batches_tracked) are left out -- they start at 0."""
+    names, chunks, off = [], [], 0
+    for k, v in named:
+        v = _np(v)
+        if v.dtype.kind != 'f':
+            continue
+        names.append([k, list(v.shape), off])
+        chunks.append(v.astype(np.float32).reshape(-1))
+        off += v.size
+    return {prefix + 'flat': np.concatenate(chunks), prefix + 'index': np.array(json.dumps(names))}
+
+
+def _digest(named, prefix):
+    """Per-tensor (sum, l2 norm) in float64, as one [n, 2] array + the list of names."""
+    names, rows = [], []
+    for k, v in named:
+        v = _np(v).astype(np.float64)
+        names.append(k)
+        rows.append([v.sum(), np.sqrt((v ** 2).sum())])
+    return {prefix + 'digest': np.array(rows), prefix + 'names': np.array(json.dumps(names))}
+
+
+def _net_record(net, tag, out, full_grad=lambda k: not k.startswith('net.') and '.' not in k):
+    """Gradients: full for the arch parameters, digest for everything; BN running stats: digest."""
+    params = [(k, p) for k, p in net.named_parameters() if p.grad is not None]
+    out.update(_digest([(k, p.grad) for k, p in params], tag + '/grad/'))
+    for k, p in params:
+        if full_grad(k):
+            out[tag + '/gradfull/' + k] = _np(p.grad)
+    # a few full weight grads as spot checks
+    big = [(k, p) for k, p in params if not full_grad(k)]
+    for k, p in big[:: max(1, len(big) // 12)]:
+        out[tag + '/gradfull/' + k] = _np(p.grad)
+    out.update(_digest([(k, v) for k, v in net.state_dict().items()
+                        if k.endswith('running_mean') or k.endswith('running_var')], tag + '/bn1/'))
+
+
+def _bn_after(module, prefix='sd1/'):
+    return {prefix + k: _np(v) for k, v in module.state_dict().items()
+            if k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked')}
+
+
+def gen_prims(O):
+    gen = torch.Generator().manual_seed(11)
+    out, index = {}, []
+    kinds = {'up': O.OpType.UP, 'down': O.OpType.DOWN, 'norm': O.OpType.NORM}
+    cases = []
+    for kind, ot in kinds.items():
+        for name in ot.value['ops']:
+            cases.append((name, kind, 32, 8))
+            cases.append((name, kind, 32, 32))
+    for name in O.NormOps:
+        cases.append((name, 'norm', 8, 8))
+    for name, kind in (('conv_3', 'norm'), ('conv_3', 'down'), ('conv_3', 'up'), ('max_pool', 'down'),
+                       ('max_pool', 'norm'), ('avg_pool', 'norm')):
+        cases.append((name, kind, 32, 8))
+    for name, kind, ci, co in cases:
+        tag = '%s.%s.%d.%d' % (kind, name, ci, co)
+        mod = O.OPS[name](ci, co, kinds[kind], 0)
+        _rand_init(mod, gen)
+        mod.train()
+        hw = 6 if kind == 'up' else 12
+        x = torch.randn(2, ci, hw, hw, generator=gen, requires_grad=True)
+        out.update(_state(mod, tag + '/sd0/'))
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out[tag + '/x'] = _np(x)
+        out[tag + '/gy'] = _np(gy)
+        out[tag + '/y'] = _np(y)
+        out[tag + '/dx'] = _np(x.grad)
+        out.update(_grads(mod, tag + '/grad/'))
+        out.update(_bn_after(mod, tag + '/sd1/'))
+        if co == 8:
+            mod.eval()
+            with torch.no_grad():
+                out[tag + '/y_eval'] = _np(mod(x))
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'prims.npz'), **out)
+    print('prims: %d cases' % len(index))
+
+
+def gen_blocks(O):
+    """The non-candidate blocks: build_rectify (both branches), ShrinkBlock, RectifyBlock, ReLUConv,
+    stem (ConvBn k=7, ReLU+MaxPool+BasicBlock)."""
+    import torch.nn as nn
+    gen = torch.Generator().manual_seed(12)
+    out, index = {}, []
+    blocks = {
+        'rectify_pool': (O.build_rectify(32, 32, 'down'), (2, 32, 14, 14)),
+        'rectify_conv': (O.build_rectify(16, 32, 'down'), (2, 16, 16, 16)),
+        'shrink64': (O.ShrinkBlock(64, 32), (2, 64, 12, 12)),
+        'shrink32': (O.ShrinkBlock(32, 32), (2, 32, 12, 12)),
+        'rectify24': (O.RectifyBlock(24, 32), (2, 24, 12, 12)),
+        'rectify128': (O.RectifyBlock(128, 32), (2, 128, 8, 8)),
+        'reluconv': (O.ReLUConv(32, 2, kernel_size=3), (2, 32, 12, 12)),
+        'reluconv4': (O.ReLUConv(32, 4, kernel_size=3), (2, 32, 12, 12)),
+        'stem0': (O.ConvBn(1, 32, kernel_size=7), (2, 1, 20, 20)),
+        'stem0_rgb': (O.ConvBn(3, 32, kernel_size=7), (2, 3, 20, 20)),
+        'stem1': (nn.Sequential(O.build_activation(False), nn.MaxPool2d(3, stride=2, padding=1),
+                                O.BasicBlock(32, 32, stride=1, dilation=1, previous_dilation=1,
+                                             norm_layer=nn.BatchNorm2d)), (2, 32, 24, 24)),
+    }
+    for tag, (mod, shape) in blocks.items():
+        _rand_init(mod, gen)
+        mod.train()
+        x = torch.randn(*shape, generator=gen, requires_grad=True)
+        out.update(_state(mod, tag + '/sd0/'))
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out[tag + '/x'], out[tag + '/gy'], out[tag + '/y'], out[tag + '/dx'] = _np(x), _np(gy), _np(y), _np(x.grad)
+        out.update(_grads(mod, tag + '/grad/'))
+        out.update(_bn_after(mod, tag + '/sd1/'))
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'blocks.npz'), **out)
+    print('blocks: %d cases' % len(index))
+
+
+def gen_mixed(C, O):
+    gen = torch.Generator().manual_seed(13)
+    out, index = {}, []
+    for kind, ot, ci in (('up', O.OpType.UP, 32), ('down', O.OpType.DOWN, 32), ('norm', O.OpType.NORM, 32),
+                         ('norm', O.OpType.NORM, 8)):
+        tag = 'mixed.%s.%d' % (kind, ci)
+        mod = C.MixedOp(ci, 8, ot)
+        _rand_init(mod, gen)
+        mod.train()
+        hw = 8 if kind == 'up' else 16
+        x = torch.randn(2, ci, hw, hw, generator=gen, requires_grad=True)
+        araw = torch.randn(6, generator=gen, requires_grad=True)
+        alpha = torch.softmax(araw, -1)
+        out.update(_state(mod, tag + '/sd0/'))
+        y = mod(x, alpha, alpha)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out[tag + '/x'], out[tag + '/gy'], out[tag + '/y'], out[tag + '/dx'] = _np(x), _np(gy), _np(y), _np(x.grad)
+        out[tag + '/alpha_raw'], out[tag + '/dalpha_raw'] = _np(araw), _np(araw.grad)
+        out.update(_grads(mod, tag + '/grad/'))
+        out.update(_bn_after(mod, tag + '/sd1/'))
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'mixed.npz'), **out)
+    print('mixed: %d cases' % len(index))
+
+
+def gen_cells(C, M, GS):
+    gen = torch.Generator().manual_seed(14)
+    out, index = {}, []
+    # search cells at the real width (c=32 -> c_part=8)
+    for tag, ctype, cin0, shp0, shp1 in (('cell.down', 'down', 32, (2, 32, 16, 16), (2, 32, 8, 8)),
+                                         ('cell.up', 'up', 64, (2, 64, 16, 16), (2, 32, 8, 8))):
+        mod = C.Cell(3, 1, cin0, 32, 32, ctype)
+        _rand_init(mod, gen)
+        mod.train()
+        in0 = torch.randn(*shp0, generator=gen, requires_grad=True)
+        in1 = torch.randn(*shp1, generator=gen, requires_grad=True)
+        raw = [torch.randn(9, 6, generator=gen, requires_grad=True) for _ in range(2)]
+        braw = torch.randn(9, generator=gen, requires_grad=True)
+        wn, wc = (torch.softmax(r, -1) for r in raw)
+        beta = torch.softmax(braw, -1)
+        out.update(_state(mod, tag + '/sd0/'))
+        y = mod(in0, in1, wn, wc, beta)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        for k, v in (('in0', in0), ('in1', in1), ('gy', gy), ('y', y), ('din0', in0.grad), ('din1', in1.grad),
+                     ('wn_raw', raw[0]), ('wc_raw', raw[1]), ('beta_raw', braw), ('dwn_raw', raw[0].grad),
+                     ('dwc_raw', raw[1].grad), ('dbeta_raw', braw.grad)):
+            out[tag + '/' + k] = _np(v)
+        out.update(_grads(mod, tag + '/grad/'))
+        out.update(_bn_after(mod, tag + '/sd1/'))
+        index.append(tag)
+    # derived cells with the README genotype at c=16 (same wiring as c=32, 4x fewer weights)
+    geno = GS.senas_node_4
+    for tag, ctype, cin0, shp0, shp1 in (('build.down', 'down', 16, (2, 16, 16, 16), (2, 16, 8, 8)),
+                                         ('build.up', 'up', 32, (2, 32, 16, 16), (2, 16, 8, 8))):
+        mod = M.BuildCell(geno, 1, cin0, 16, 16, ctype)
+        _rand_init(mod, gen)
+        mod.train()
+        in0 = torch.randn(*shp0, generator=gen, requires_grad=True)
+        in1 = torch.randn(*shp1, generator=gen, requires_grad=True)
+        out.update(_state(mod, tag + '/sd0/'))
+        y = mod(in0, in1)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        for k, v in (('in0', in0), ('in1', in1), ('gy', gy), ('y', y), ('din0', in0.grad), ('din1', in1.grad)):
+            out[tag + '/' + k] = _np(v)
+        out.update(_grads(mod, tag + '/grad/'))
+        out.update(_bn_after(mod, tag + '/sd1/'))
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'cells.npz'), **out)
+    print('cells: %d cases' % len(index))
+
+
+def _geno_json(g):
+    return json.dumps({'down': [list(t) for t in g.down], 'down_concat': list(g.down_concat),
+                       'up': [list(t) for t in g.up], 'up_concat': list(g.up_concat), 'gamma': list(g.gamma)})
+
+
+def gen_nets(S, M, GS, Loss):
+    gen = torch.Generator().manual_seed(15)
+    out, index = {}, []
+    crit = Loss('dice_ce')
+    # supernet, real topology (depth 5, 3 nodes), narrow (c=8 -> c_part=2)
+    for tag, kw, shape, ncls in (('nas.c8', dict(input_c=1, c=8, num_classes=2, depth=5, meta_node_num=3),
+                                  (2, 1, 128, 128), 2),
+                                 ('nas.c8.sup', dict(input_c=3, c=8, num_classes=3, depth=4, meta_node_num=3,
+                                                     supervision=True), (2, 3, 64, 64), 3)):
+        torch.manual_seed(5)
+        net = S.NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+        out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
+        out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+        logits = net(x)
+        loss = crit(logits, tgt)
+        loss.backward()
+        out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
+        for i, l in enumerate(logits):
+            out[tag + '/logits%d' % i] = _np(l)
+        out[tag + '/loss'] = _np(loss)
+        out[tag + '/kw'] = np.array(json.dumps({k: v for k, v in kw.items()}))
+        _net_record(net, tag, out)
+        index.append(tag)
+    # derived nets
+    for tag, geno, kw, shape in (('derived.node4.c8', GS.senas_node_4, dict(nclass=2, in_channels=1, c=8, depth=5),
+                                  (2, 1, 128, 128)),
+                                 ('derived.node4.c8.rgb4', GS.senas_node_4, dict(nclass=4, in_channels=3, c=8, depth=5),
+                                  (2, 3, 128, 128)),
+                                 ('derived.node3.c8', GS.senas_node_3, dict(nclass=2, in_channels=1, c=8, depth=5),
+                                  (2, 1, 128, 128)),
+                                 ('derived.node2.c8.sup', GS.senas_node_2._replace(gamma=[1] * 6), dict(nclass=2, in_channels=1, c=8, depth=5,
+                                                                               supervision=True), (2, 1, 128, 128))):
+        net = M.SenasModel(genotype=geno, **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, kw['nclass'], (shape[0],) + shape[2:], generator=gen)
+        out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
+        logits = net(x)
+        loss = crit(logits, tgt)
+        loss.backward()
+        out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
+        for i, l in enumerate(logits):
+            out[tag + '/logits%d' % i] = _np(l)
+        out[tag + '/loss'] = _np(loss)
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        out[tag + '/genotype'] = np.array(_geno_json(geno))
+        _net_record(net, tag, out, full_grad=lambda k: False)
+        net.eval()
+        with torch.no_grad():
+            out[tag + '/logits_eval'] = _np(net(x)[-1])
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'nets.npz'), **out)
+    print('nets: %d cases' % len(index))
+
+
+def gen_search_step(S, Loss):
+    """One full search step as experiments/search_arc.py:252-299 runs it after alpha_begin:
+    Architecture.step on a validation batch (Adam on arch params), then the weight step
+    (SGD + clip_grad_norm_ 5 over ALL parameters, arch included)."""
+    gen = torch.Generator().manual_seed(16)
+    torch.manual_seed(6)
+    net = S.NAS(input_c=1, c=8, num_classes=2, depth=5, meta_node_num=3, use_sharing=False, double_down_channel=False,
+                multi_gpus=False, device=torch.device('cpu'))
+    _rand_init(net, gen)
+    net.train()
+    crit = Loss('dice_ce')
+    opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
+    opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    arch = S.Architecture(net, opt_a, crit)
+    out = _pack(net.state_dict().items(), 'sd0/')
+    xs, ys = [], []
+    for _ in range(2):
+        xv, yv = torch.randn(2, 1, 128, 128, generator=gen), torch.randint(0, 2, (2, 128, 128), generator=gen)
+        xt, yt = torch.randn(2, 1, 128, 128, generator=gen), torch.randint(0, 2, (2, 128, 128), generator=gen)
+        arch.step(xv, yv)
+        opt_w.zero_grad()
+        loss = crit(net(xt), yt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 5)
+        opt_w.step()
+        xs += [_np(xv), _np(xt)]
+        ys += [_np(yv), _np(yt)]
+        out['loss%d' % (len(xs) // 2 - 1)] = _np(loss)
+    out['x'], out['y'] = np.stack(xs), np.stack(ys)
+    fl = [(k, v) for k, v in net.state_dict().items() if v.dtype.is_floating_point]
+    out.update(_digest(fl, 'sd2/'))
+    for k, v in fl:
+        if not k.startswith('net.'):
+            out['sd2full/' + k] = _np(v)
+    for k, v in fl[:: max(1, len(fl) // 16)]:
+        out['sd2full/' + k] = _np(v)
+    out['genotype'] = np.array(_geno_json(net.genotype()))
+    np.savez_compressed(os.path.join(OUT, 'search_step.npz'), **out)
+    print('search_step: done')
+
+
+def gen_genoparse(S, G):
+    out = {}
+    rng = np.random.default_rng(0)
+    cases = []
+    for nodes in (2, 3, 4):
+        rows = sum(2 + i for i in range(nodes))
+        for rep in range(12):
+            w1 = rng.random((rows, 6)).astype(np.float32)
+            w2 = rng.random((rows, 6)).astype(np.float32)
+            if rep % 4 == 3:          # force exact ties
+                w1 = np.round(w1 * 4) / 4
+                w2 = np.round(w2 * 4) / 4
+            tag = 'parse.%d.%d' % (nodes, rep)
+            p = G.GenoParser(nodes)
+            out[tag + '/w1'], out[tag + '/w2'] = w1, w2
+            out[tag + '/down'] = np.array(json.dumps(p.parse(w1, w2, 'down')))
+            out[tag + '/up'] = np.array(json.dumps(p.parse(w1, w2, 'up')))
+            cases.append(tag)
+    gen = torch.Generator().manual_seed(17)
+    for rep in range(10):
+        for depth, nodes in ((5, 3), (4, 4), (6, 2)):
+            torch.manual_seed(100 + rep)
+            net = S.NAS(input_c=1, c=4, num_classes=2, depth=depth, meta_node_num=nodes, use_sharing=False,
+                        double_down_channel=False, multi_gpus=False, device=torch.device('cpu'))
+            tag = 'nasgeno.%d.%d.%d' % (depth, nodes, rep)
+            with torch.no_grad():
+                for p in net.arch_parameters():
+                    p.copy_(torch.randn(p.shape, generator=gen) * (2.0 if rep % 2 else 0.05))
+            for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma'):
+                out[tag + '/' + k] = _np(getattr(net, k))
+            out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+            cases.append(tag)
+    out['index'] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, 'genoparse.npz'), **out)
+    print('genoparse: %d cases' % len(cases))
+
+
+def gen_loss_metric(Loss, Metric):
+    gen = torch.Generator().manual_seed(18)
+    out, cases = {}, []
+    crit = Loss('dice_ce')
+    for tag, shape, ncls in (('lm.2c', (3, 2, 24, 24), 2), ('lm.4c', (2, 4, 16, 16), 4)):
+        logits = (2.0 * torch.randn(*shape, generator=gen)).requires_grad_(True)
+        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+        loss = crit([logits], tgt)
+        loss.backward()
+        m = Metric(ncls)
+        m.update(tgt, logits.detach())
+        m.update(tgt, (logits.detach() * 0.5 + 0.1))
+        out[tag + '/logits'], out[tag + '/target'] = _np(logits), _np(tgt)
+        out[tag + '/loss'], out[tag + '/dlogits'] = _np(loss), _np(logits.grad)
+        out[tag + '/metric'] = np.array(m.get(), dtype=np.float64)
+        cases.append(tag)
+    out['index'] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, 'loss_metric.npz'), **out)
+    print('loss_metric: %d cases' % len(cases))
+
+
+def main():
+    torch.set_num_threads(4)
+    S, C, O, G, M, GS, Loss, Metric = _import_reference()
+    gen_prims(O)
+    gen_blocks(O)
+    gen_mixed(C, O)
+    gen_cells(C, M, GS)
+    gen_nets(S, M, GS, Loss)
+    gen_search_step(S, Loss)
+    gen_genoparse(S, G)
+    gen_loss_metric(Loss, Metric)
+    with open(os.path.join(OUT, 'PROVENANCE.json'), 'w') as f:
+        json.dump({'generator': 'tests/golden/make_golden.py', 'reference': 'RayburnChen/senas @ /root/reference',
+                   'torch': torch.__version__, 'numpy': np.__version__, 'device': 'cpu', 'dtype': 'float32'}, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,243 @@
+"""Pins the CPU oracle (oracle/senas_ref.py) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU-only; runs in the `-m "not gpu"` suite."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from oracle import senas_ref as R
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(autouse=True)
+def _generator_threads():
+    """make_golden.py ran with 4 intra-op threads; same count here keeps CPU reductions in the same order."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(4)
+    yield
+    torch.set_num_threads(old)
+
+
+def _close(a, b, what='', rtol=RTOL, atol=ATOL):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol, err_msg=what)
+
+
+def _grads_of(sd):
+    return {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+def _check_bn_after(npz, tag, sd):
+    for k, e in gio.sub(npz, tag + '/sd1/').items():
+        _close(sd[k].numpy(), e, '%s sd1 %s' % (tag, k))
+
+
+# ------------------------------------------------------------------ primitives
+@pytest.mark.parametrize('tag', gio.index('prims'))
+def test_primitive(tag):
+    z = gio.load('prims')
+    kind, name, ci, co = tag.split('.')
+    sd = gio.torch_sd(gio.sub(z, tag + '/sd0/'))
+    x = torch.from_numpy(z[tag + '/x']).requires_grad_(True)
+    y = R.candidate(name, kind, R.View(sd), x, True)
+    _close(y.detach(), z[tag + '/y'], tag + ' y')
+    (y * torch.from_numpy(z[tag + '/gy'])).sum().backward()
+    _close(x.grad, z[tag + '/dx'], tag + ' dx')
+    seen = gio.check_grads(gio.sub(z, tag + '/grad/'), _grads_of(sd), RTOL, ATOL, tag)
+    assert seen == set(_grads_of(sd)), 'gradient set differs'
+    _check_bn_after(z, tag, sd)
+    if tag + '/y_eval' in z.files:
+        with torch.no_grad():
+            _close(R.candidate(name, kind, R.View(sd), x, False), z[tag + '/y_eval'], tag + ' eval')
+
+
+_BLOCK_FN = {
+    'rectify_pool': lambda p, x: R.preprocess0(p, x, 'down', True),
+    'rectify_conv': lambda p, x: R.preprocess0(p, x, 'down', True),
+    'shrink64': lambda p, x: R.preprocess0(p, x, 'up', True),
+    'shrink32': lambda p, x: R.preprocess0(p, x, 'up', True),
+    'rectify24': lambda p, x: R.post_process(p, x, True),
+    'rectify128': lambda p, x: R.post_process(p, x, True),
+    'reluconv': lambda p, x: R.relu_conv(p, x),
+    'reluconv4': lambda p, x: R.relu_conv(p, x),
+    'stem0': lambda p, x: R.stem0(p, x, True),
+    'stem0_rgb': lambda p, x: R.stem0(p, x, True),
+    'stem1': lambda p, x: R.stem1(p, x, True),
+}
+
+
+@pytest.mark.parametrize('tag', gio.index('blocks'))
+def test_block(tag):
+    z = gio.load('blocks')
+    sd = gio.torch_sd(gio.sub(z, tag + '/sd0/'))
+    x = torch.from_numpy(z[tag + '/x']).requires_grad_(True)
+    y = _BLOCK_FN[tag](R.View(sd), x)
+    _close(y.detach(), z[tag + '/y'], tag + ' y')
+    (y * torch.from_numpy(z[tag + '/gy'])).sum().backward()
+    _close(x.grad, z[tag + '/dx'], tag + ' dx')
+    gio.check_grads(gio.sub(z, tag + '/grad/'), _grads_of(sd), RTOL, ATOL, tag)
+    _check_bn_after(z, tag, sd)
+
+
+@pytest.mark.parametrize('tag', gio.index('mixed'))
+def test_mixed_op(tag):
+    z = gio.load('mixed')
+    kind = tag.split('.')[1]
+    sd = gio.torch_sd(gio.sub(z, tag + '/sd0/'))
+    x = torch.from_numpy(z[tag + '/x']).requires_grad_(True)
+    araw = torch.from_numpy(z[tag + '/alpha_raw']).requires_grad_(True)
+    y = R.mixed_op(R.View(sd), x, kind, torch.softmax(araw, -1), True)
+    _close(y.detach(), z[tag + '/y'], tag + ' y')
+    (y * torch.from_numpy(z[tag + '/gy'])).sum().backward()
+    _close(x.grad, z[tag + '/dx'], tag + ' dx')
+    _close(araw.grad, z[tag + '/dalpha_raw'], tag + ' dalpha')
+    gio.check_grads(gio.sub(z, tag + '/grad/'), _grads_of(sd), RTOL, ATOL, tag)
+    _check_bn_after(z, tag, sd)
+
+
+@pytest.mark.parametrize('tag', gio.index('cells'))
+def test_cell(tag):
+    z = gio.load('cells')
+    fam, ctype = tag.split('.')
+    sd = gio.torch_sd(gio.sub(z, tag + '/sd0/'))
+    in0 = torch.from_numpy(z[tag + '/in0']).requires_grad_(True)
+    in1 = torch.from_numpy(z[tag + '/in1']).requires_grad_(True)
+    if fam == 'cell':
+        raws = [torch.from_numpy(z[tag + '/' + k]).requires_grad_(True) for k in ('wn_raw', 'wc_raw', 'beta_raw')]
+        y = R.search_cell(R.View(sd), in0, in1, torch.softmax(raws[0], -1), torch.softmax(raws[1], -1),
+                          torch.softmax(raws[2], -1), ctype, 3, True)
+    else:
+        from senas_amd.geno_searched import senas_node_4
+        y = R.build_cell(R.View(sd), in0, in1, R.Genotype(*senas_node_4), ctype, True)
+    _close(y.detach(), z[tag + '/y'], tag + ' y')
+    (y * torch.from_numpy(z[tag + '/gy'])).sum().backward()
+    _close(in0.grad, z[tag + '/din0'], tag + ' din0', rtol=1e-4, atol=1e-5)
+    _close(in1.grad, z[tag + '/din1'], tag + ' din1', rtol=1e-4, atol=1e-5)
+    if fam == 'cell':
+        for r, k in zip(raws, ('dwn_raw', 'dwc_raw', 'dbeta_raw')):
+            _close(r.grad, z[tag + '/' + k], tag + ' ' + k, rtol=1e-4, atol=1e-5)
+    gio.check_grads(gio.sub(z, tag + '/grad/'), _grads_of(sd), 1e-4, 1e-5, tag)
+    _check_bn_after(z, tag, sd)
+
+
+# ------------------------------------------------------------------ whole nets
+def _run_net(z, tag):
+    kw = json.loads(str(z[tag + '/kw']))
+    sd = gio.add_missing_counters(gio.torch_sd(gio.unpack(z, tag + '/sd0/')))
+    gio.share_stem(sd, 'net.' if tag.startswith('nas') else '')
+    x = torch.from_numpy(z[tag + '/x'])
+    tgt = torch.from_numpy(z[tag + '/target'])
+    if tag.startswith('nas'):
+        outs = R.nas_forward(sd, x, depth=kw['depth'], nodes=kw['meta_node_num'],
+                             supervision=kw.get('supervision', False))
+    else:
+        geno = gio.geno_from_json(z[tag + '/genotype'], R.Genotype)
+        outs = R.derived_forward(sd, x, geno, depth=kw['depth'], supervision=kw.get('supervision', False))
+    return sd, x, tgt, outs, kw
+
+
+@pytest.mark.parametrize('tag', gio.index('nets'))
+def test_whole_net(tag):
+    z = gio.load('nets')
+    sd, x, tgt, outs, kw = _run_net(z, tag)
+    for i, o in enumerate(outs):
+        _close(o.detach(), z[tag + '/logits%d' % i], '%s logits%d' % (tag, i), rtol=2e-4, atol=2e-5)
+    loss = R.dice_ce_loss(outs[-1], tgt)
+    _close(loss.detach(), z[tag + '/loss'], tag + ' loss', rtol=1e-5, atol=1e-6)
+    loss.backward()
+    got = gio.alias_shared_stem(_grads_of(sd), 'net.' if tag.startswith('nas') else '')
+    for k, e in gio.sub(z, tag + '/gradfull/').items():
+        _close(got[k], e, '%s grad %s' % (tag, k), rtol=1e-3, atol=2e-6 + 1e-4 * float(np.abs(e).max()))
+    exp = gio.digest(z, tag + '/grad/')
+    assert set(exp) <= set(got)
+    gio.check_digest(exp, got, rtol=2e-3, what=tag)
+    gio.check_digest(gio.digest(z, tag + '/bn1/'), {k: v.detach().numpy() for k, v in sd.items()}, rtol=1e-4, what=tag + ' bn')
+    if tag.startswith('nas'):
+        g = R.derive_genotype({k: v.detach() for k, v in gio.torch_sd(gio.unpack(z, tag + '/sd0/')).items()},
+                              depth=kw['depth'], nodes=kw['meta_node_num'])
+        assert g == gio.geno_from_json(z[tag + '/genotype'], R.Genotype)
+    if tag + '/logits_eval' in z.files:
+        geno = gio.geno_from_json(z[tag + '/genotype'], R.Genotype)
+        with torch.no_grad():
+            ev = R.derived_forward(sd, x, geno, depth=kw['depth'], supervision=kw.get('supervision', False),
+                                   training=False)[-1]
+        _close(ev, z[tag + '/logits_eval'], tag + ' eval', rtol=2e-4, atol=2e-5)
+
+
+def test_search_step_trajectory():
+    """Two full search steps (arch Adam step on a validation batch, then SGD weight step with
+    clip 5 over all parameters) -- experiments/search_arc.py:252-299."""
+    z = gio.load('search_step')
+    sd = gio.add_missing_counters(gio.torch_sd(gio.unpack(z, 'sd0/')))
+    arch_keys = ['alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma']
+    seen, params = set(), []
+    for k, v in sd.items():               # named_parameters order, shared stem1 reported once
+        if v.requires_grad and not k.startswith('net.blocks.0.0.'):
+            params.append(v)
+    # alias the duplicate stem1 keys onto the same leaves, as in the reference module tree
+    for k in list(sd):
+        if k.startswith('net.blocks.0.0.'):
+            sd[k] = sd['net.stem1.' + k[len('net.blocks.0.0.'):]]
+    opt_w = torch.optim.SGD(params, lr=5e-3, weight_decay=3e-4, momentum=0.9)
+    opt_a = torch.optim.Adam([sd[k] for k in arch_keys], lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    xs, ys = torch.from_numpy(z['x']), torch.from_numpy(z['y'])
+    for step in range(2):
+        opt_a.zero_grad()
+        R.dice_ce_loss(R.nas_forward(sd, xs[2 * step])[-1], ys[2 * step]).backward()
+        opt_a.step()
+        opt_w.zero_grad()
+        loss = R.dice_ce_loss(R.nas_forward(sd, xs[2 * step + 1])[-1], ys[2 * step + 1])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt_w.step()
+        _close(loss.detach(), z['loss%d' % step], 'loss%d' % step, rtol=1e-4)
+    got = {k: v.detach().numpy() for k, v in sd.items()}
+    for k, e in gio.sub(z, 'sd2full/').items():
+        _close(got[k], e, 'after-step ' + k, rtol=1e-4, atol=1e-6)
+    gio.check_digest(gio.digest(z, 'sd2/'), got, rtol=1e-4, what='after-step')
+    assert R.derive_genotype({k: v.detach() for k, v in sd.items()}) == gio.geno_from_json(z['genotype'], R.Genotype)
+
+
+# ------------------------------------------------------------------ genotype parser, loss, metric
+@pytest.mark.parametrize('tag', [t for t in gio.index('genoparse') if t.startswith('parse')])
+def test_parse_tables(tag):
+    z = gio.load('genoparse')
+    nodes = int(tag.split('.')[1])
+    for cell in ('down', 'up'):
+        exp = [tuple(t) for t in json.loads(str(z[tag + '/' + cell]))]
+        got = R.parse_cell(z[tag + '/w1'], z[tag + '/w2'], cell, nodes)
+        assert [(a, int(b)) for a, b in got] == [(a, int(b)) for a, b in exp], (tag, cell)
+
+
+@pytest.mark.parametrize('tag', [t for t in gio.index('genoparse') if t.startswith('nasgeno')])
+def test_nas_genotype(tag):
+    z = gio.load('genoparse')
+    _, depth, nodes, _ = tag.split('.')
+    sd = {k: torch.from_numpy(z[tag + '/' + k]) for k in
+          ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma')}
+    assert R.derive_genotype(sd, depth=int(depth), nodes=int(nodes)) == gio.geno_from_json(z[tag + '/genotype'], R.Genotype)
+
+
+@pytest.mark.parametrize('tag', gio.index('loss_metric'))
+def test_loss_and_metric(tag):
+    z = gio.load('loss_metric')
+    logits = torch.from_numpy(z[tag + '/logits']).requires_grad_(True)
+    tgt = torch.from_numpy(z[tag + '/target'])
+    loss = R.dice_ce_loss(logits, tgt)
+    _close(loss.detach(), z[tag + '/loss'], tag + ' loss', rtol=1e-6)
+    loss.backward()
+    _close(logits.grad, z[tag + '/dlogits'], tag + ' dlogits', rtol=1e-5, atol=1e-9)
+    # SegmentationMetric after two updates: pixAcc is the mean of the per-batch values,
+    # mIoU/Dice come from the summed hard counts (utils/metrics.py:48-64)
+    accs, cnt = [], None
+    for lg in (logits.detach(), logits.detach() * 0.5 + 0.1):
+        accs.append(float(R.mean_pix_accuracy(lg, tgt)))
+        c = R.hard_counts(lg, tgt)
+        cnt = c if cnt is None else tuple(a + b for a, b in zip(cnt, c))
+    pix = round(100.0 * (sum(accs) / len(accs)), 3)
+    exp = z[tag + '/metric']
+    assert abs(pix - exp[0]) < 2e-3
+    assert R.miou_from_counts(*cnt) == pytest.approx(exp[1], abs=1e-3)
+    assert R.dice_from_counts(*cnt) == pytest.approx(exp[2], abs=1e-3)

@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Benchmark of the SENAS hot path on MI355X: images/sec of the derived-genotype train step
+(BASELINE.json configs[1]: models/senas_model.py, README genotype, 8x1x256x256 per GPU), plus --
+for reference in the same JSON line -- the supernet search step (configs[2], 4x1x256x256).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = zero_grad -> forward -> Dice+CE loss -> backward -> (gradient all-reduce) -> clip_grad_norm_(5)
+-> SGD step, on a synthetic batch already resident in HBM.  Weak scaling: 8 images per GPU.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_PEAK_TFLOPS = 157.3        # fp32 MFMA (= vector) dense peak
+
+
+def build_derived(dev):
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.models import get_segmentation_model
+    from senas_amd.utils import weights_init
+    torch.manual_seed(0)
+    net = get_segmentation_model('senas', dataset='promise12', c=32, depth=5, supervision=False, genotype=senas_node_4,
+                                 double_down_channel=False)
+    net.apply(weights_init)
+    return net.to(dev).train()
+
+
+def synthetic(batch, in_ch, ncls, size, rank, dev):
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(batch, in_ch, size, size, generator=g)
+    y = torch.randint(0, ncls, (batch, size, size), generator=g)
+    return x.to(dev), y.to(dev)
+
+
+def cpu_baseline_train(batch, size, reps=3):
+    """The CPU oracle (a port of the reference's torch-CPU path, pinned by the golden vectors) running the
+    identical train step on the host cores -- a reported baseline, not the thing measured."""
+    from oracle import senas_ref as R
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.utils import weights_init
+    torch.manual_seed(0)
+    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
+    net.apply(weights_init)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k in list(sd):
+        if k.startswith('blocks.0.0.'):
+            sd[k] = sd['stem1.' + k[len('blocks.0.0.'):]]
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k and not k.startswith('blocks.0.0.'):
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.SGD(params, lr=6e-3, weight_decay=5e-4, momentum=0.9)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, 1, size, size, generator=g)
+    y = torch.randint(0, 2, (batch, size, size), generator=g)
+    geno = R.Genotype(*senas_node_4)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.dice_ce_loss(R.derived_forward(sd, x, geno)[-1], y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt.step()
+        log('cpu baseline step %d: %.2f s' % (i, time.perf_counter() - t0))
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    return batch / min(times)
+
+
+def log(msg):
+    """Progress on stderr (the one JSON line goes to stdout)."""
+    sys.stderr.write('[bench %s] %s\n' % (time.strftime('%H:%M:%S'), msg))
+    sys.stderr.flush()
+
+
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may run on, capped at the GPU box's
+    per-GPU CPU share (16) -- os.cpu_count() reports the whole host and would oversubscribe."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--search-steps', type=int, default=2, help='timed supernet search steps (0 = skip)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from senas_amd import _lib, functional as F
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.parallel import GradAllReducer, broadcast_parameters
+    _lib.lib()
+
+    net = build_derived(dev)
+    if world > 1:
+        broadcast_parameters(net)
+    crit = SegmentationLosses('dice_ce')
+    opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)     # senas_promise12.yml training block
+    reducer = GradAllReducer(net.parameters(), world_size=world)
+    x, y = synthetic(args.batch, 1, 2, args.size, rank, dev)
+    params = [p for p in net.parameters()]
+
+    def step():
+        reducer.zero_grad()
+        loss = crit(net(x), y)
+        loss.backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt.step()
+        return loss
+
+    log('model on %s, %d params; warm-up x%d' % (dev, sum(p.numel() for p in params), args.warmup))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    log('timing %d steps' % args.steps)
+    F.TIMER = F.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer, F.TIMER = F.TIMER, None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    images = args.batch * world * args.steps
+    value = images / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, over the timed region)
+    agg = timer.summary()
+    roof = None
+    if agg:
+        name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        per_launch_ms = a['ms'] / a['launches']
+        tflops = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(tflops, 3), 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': None, 'launches': a['launches'],
+                'avg_launch_ms': round(per_launch_ms, 4),
+                'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 3),
+                'share_of_step': round(a['ms'] / (elapsed * 1e3), 3),
+                'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / args.steps, 2)}
+
+    out = {
+        'metric': 'images/sec at 256x256 - senas derived-genotype train step (fwd+loss+bwd+clip+SGD)',
+        'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (randn slices, randint labels, seed 1+rank), random-init weights',
+        'config': {'workload': 'BASELINE configs[1]: SenasModel README genotype (senas_node_4), c=32 depth=5, '
+                               '%dx1x%dx%d per GPU, fp32' % (args.batch, args.size, args.size),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach())},
+        'roofline': roof,
+    }
+
+    log('train step: %.2f ms/step, %.2f images/s' % (1e3 * elapsed / args.steps, value))
+    if rank == 0 and world == 1 and args.search_steps > 0:
+        out['search_step'] = bench_search(dev, args.search_steps)
+        log('search step: %s' % json.dumps(out['search_step']))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(host_threads())
+        log('cpu baseline on %d threads (cpu_count %s)' % (torch.get_num_threads(), os.cpu_count()))
+        cb = args.batch
+        v = cpu_baseline_train(cb, args.size, reps=2)
+        out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'cpu': cpu_model_name(),
+                               'sample': 'same train step (oracle/senas_ref.py, torch-CPU fp32) on %dx1x%dx%d, best of 2 after 1 warm-up' % (cb, args.size, args.size)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_search(dev, steps):
+    """Supernet search step (BASELINE configs[2]): arch step on 4 validation images (Adam) + weight step on
+    4 train images (SGD, clip 5) -- experiments/search_arc.py:252-299.  images/sec counts train images."""
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS, Architecture
+    torch.manual_seed(0)
+    net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev).to(dev).train()
+    crit = SegmentationLosses('dice_ce')
+    opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
+    opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    arch = Architecture(net, opt_a, crit)
+    xt, yt = synthetic(4, 1, 2, 256, 0, dev)
+    xv, yv = synthetic(4, 1, 2, 256, 100, dev)
+    params = list(net.parameters())
+
+    def step():
+        arch.step(xv, yv)
+        opt_w.zero_grad()
+        loss = crit(net(xt), yt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt_w.step()
+
+    log('search: supernet built, warm-up step')
+    step()
+    torch.cuda.synchronize()
+    log('search: timing %d steps' % steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'workload': 'BASELINE configs[2]: NAS supernet c=32 depth=5 nodes=3, arch step (4 val) + weight step (4 train), 1x256x256',
+            'train_images_per_sec': round(4 / dt, 3), 'ms_per_step': round(dt * 1e3, 2), 'steps': steps}
+
+
+if __name__ == '__main__':
+    main()

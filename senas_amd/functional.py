@@ -49,6 +49,62 @@ def new_stats(n, c, like):
     return torch.zeros((n, c, 2), device=like.device, dtype=torch.float64)
 
 
+class KernelTimer(object):
+    """HIP-event timing of individual launches on the stream they are launched on (torch's current
+    stream), used by bench.py for the roofline of the dominant kernel.  Off unless installed."""
+
+    def __init__(self):
+        self.records = []
+
+    def span(self, name, flops, nbytes):
+        return _Span(self, name, flops, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            a['launches'] += 1
+            a['ms'] += e0.elapsed_time(e1)
+            a['flops'] += flops
+            a['bytes'] += nbytes
+        return agg
+
+
+class _Span(object):
+    def __init__(self, timer, name, flops, nbytes):
+        self.t, self.name, self.flops, self.nbytes = timer, name, flops, nbytes
+
+    def __enter__(self):
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.t.records.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER = None
+_NOSPAN = _NoSpan()
+
+
+def _span(kind, g, x, w, y):
+    if TIMER is None:
+        return _NOSPAN
+    dense = g.groups == 1
+    macs = (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
+    shape = '%s%dx%d d%d s%d %s%d->%d' % ('T' if g.transposed else '', g.kh, g.kw, g.dil, g.stride, '' if dense else 'dw ', g.ci, g.co)
+    return TIMER.span('%s[%s]' % (kind, shape), 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()))
+
+
 # ------------------------------------------------------------------------------------------ convolution
 def conv_out_size(i, k, stride, pad, dil, transposed, out_pad):
     if transposed:
@@ -80,8 +136,9 @@ class _Conv2d(torch.autograd.Function):
         y = new_nhwc(n, co, ho, wo, x)
         stats = new_stats(n, co, x) if want_stats else None
         ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
-        _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
-                                      ws.data_ptr(), _stream()), 'senas_conv2d_fwd')
+        with _span('conv_fwd', g, x, w, y):
+            _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
+                                          ws.data_ptr(), _stream()), 'senas_conv2d_fwd')
         ctx.save_for_backward(x, w)
         ctx.g, ctx.in_relu = g, int(in_relu)
         if stats is not None:
@@ -97,12 +154,14 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
-            _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
-                                               x.data_ptr(), ws.data_ptr(), _stream()), 'senas_conv2d_bwd_data')
+            with _span('conv_dgrad', g, x, w, dy):
+                _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
+                                                   x.data_ptr(), ws.data_ptr(), _stream()), 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dw.data_ptr(),
-                                                 ws.data_ptr(), _stream()), 'senas_conv2d_bwd_weight')
+            with _span('conv_wgrad', g, x, w, dy):
+                _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dw.data_ptr(),
+                                                     ws.data_ptr(), _stream()), 'senas_conv2d_bwd_weight')
         return dx, dw, None, None, None, None, None, None, None, None
 
 
@@ -201,6 +260,26 @@ class _ReLU(torch.autograd.Function):
         _lib.check(_lib.lib().senas_relu_bwd(y.numel(), dy.data_ptr(), y.data_ptr(), dx.data_ptr(), _stream()),
                    'senas_relu_bwd')
         return dx
+
+
+class _ZeroFeature(torch.autograd.Function):
+    """The all-zero feature map ZeroOp feeds its adapter (x.mul(0.)): zeros forward, and -- as in the
+    reference's autograd -- an exactly-zero (not absent) gradient for x."""
+
+    @staticmethod
+    def forward(ctx, x, c_out):
+        n, _, h, w = x.shape
+        ctx.save_for_backward(x)
+        return torch.zeros((n, c_out, h, w), device=x.device, dtype=torch.float32).contiguous(memory_format=CL)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return torch.zeros_like(x), None
+
+
+def zero_feature(x, c_out):
+    return _ZeroFeature.apply(_dev(x), c_out)
 
 
 def avg_pool3(x, stride, in_relu=False):

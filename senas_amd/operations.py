@@ -202,9 +202,7 @@ class AdapterBlock(nn.Module):
     def forward(self, x):
         t = self.raw(x)
         if t.z is None:     # 'none': the output is the batch-norm bias broadcast over the input's grid
-            n, _, h, w = x.shape
-            zero = torch.zeros((n, self.c_ot, h, w), device=x.device, dtype=torch.float32).contiguous(memory_format=F.CL)
-            return F.bn_combine([t], residual=zero)
+            return F.bn_combine([t], residual=F.zero_feature(x, self.c_ot))
         return F.bn_combine([t])
 
 

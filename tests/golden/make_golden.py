@@ -300,13 +300,44 @@ def _geno_json(g):
                        'up': [list(t) for t in g.up], 'up_concat': list(g.up_concat), 'gamma': list(g.gamma)})
 
 
+def _net_case(net, x, tgt, crit, tag, out, arch_full):
+    """fp32 forward/backward of the reference net (the golden values) plus the same computation in
+    fp64 on a copy: ReLU nets have gradient kinks, so the fp32 reference is itself only accurate to
+    |ref32 - ref64|; tests scale their gradient tolerance with that measured error."""
+    import copy
+    net64 = copy.deepcopy(net).double()
+    out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
+    logits = net(x)
+    loss = crit(logits, tgt)
+    loss.backward()
+    out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
+    for i, l in enumerate(logits):
+        out[tag + '/logits%d' % i] = _np(l)
+    out[tag + '/loss'] = _np(loss)
+    _net_record(net, tag, out, full_grad=(lambda k: not k.startswith('net.') and '.' not in k) if arch_full else (lambda k: False))
+    logits64 = net64(x.double())
+    loss64 = crit(logits64, tgt)
+    loss64.backward()
+    out[tag + '/loss64'] = _np(loss64)
+    out[tag + '/logits64_last'] = _np(logits64[-1]).astype(np.float64)
+    g64 = dict((k, p.grad) for k, p in net64.named_parameters() if p.grad is not None)
+    out.update(_digest(list(g64.items()), tag + '/grad64/'))
+    for k in list(out):
+        if k.startswith(tag + '/gradfull/'):
+            out[tag + '/gradfull64/' + k[len(tag + '/gradfull/'):]] = _np(g64[k[len(tag + '/gradfull/'):]])
+
+
 def gen_nets(S, M, GS, Loss):
     gen = torch.Generator().manual_seed(15)
     out, index = {}, []
     crit = Loss('dice_ce')
-    # supernet, real topology (depth 5, 3 nodes), narrow (c=8 -> c_part=2)
-    for tag, kw, shape, ncls in (('nas.c8', dict(input_c=1, c=8, num_classes=2, depth=5, meta_node_num=3),
+    # supernets: real cell topology (3 nodes), narrow (c=8 -> c_part=2).  Gradient fixtures use depth 4 at
+    # 64x64 (few enough ReLU inputs that none sits within fp32 noise of zero); the depth-5 128x128 case
+    # pins the forward pass / genotype of the full grid, its gradients are checked against the fp64 spread.
+    for tag, kw, shape, ncls in (('nas.c8.d5', dict(input_c=1, c=8, num_classes=2, depth=5, meta_node_num=3),
                                   (2, 1, 128, 128), 2),
+                                 ('nas.c8.d4', dict(input_c=1, c=8, num_classes=2, depth=4, meta_node_num=3),
+                                  (2, 1, 64, 64), 2),
                                  ('nas.c8.sup', dict(input_c=3, c=8, num_classes=3, depth=4, meta_node_num=3,
                                                      supervision=True), (2, 3, 64, 64), 3)):
         torch.manual_seed(5)
@@ -315,43 +346,26 @@ def gen_nets(S, M, GS, Loss):
         net.train()
         x = torch.randn(*shape, generator=gen)
         tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
-        out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
         out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
-        logits = net(x)
-        loss = crit(logits, tgt)
-        loss.backward()
-        out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
-        for i, l in enumerate(logits):
-            out[tag + '/logits%d' % i] = _np(l)
-        out[tag + '/loss'] = _np(loss)
-        out[tag + '/kw'] = np.array(json.dumps({k: v for k, v in kw.items()}))
-        _net_record(net, tag, out)
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        _net_case(net, x, tgt, crit, tag, out, arch_full=True)
         index.append(tag)
-    # derived nets
-    for tag, geno, kw, shape in (('derived.node4.c8', GS.senas_node_4, dict(nclass=2, in_channels=1, c=8, depth=5),
-                                  (2, 1, 128, 128)),
-                                 ('derived.node4.c8.rgb4', GS.senas_node_4, dict(nclass=4, in_channels=3, c=8, depth=5),
-                                  (2, 3, 128, 128)),
-                                 ('derived.node3.c8', GS.senas_node_3, dict(nclass=2, in_channels=1, c=8, depth=5),
-                                  (2, 1, 128, 128)),
-                                 ('derived.node2.c8.sup', GS.senas_node_2._replace(gamma=[1] * 6), dict(nclass=2, in_channels=1, c=8, depth=5,
-                                                                               supervision=True), (2, 1, 128, 128))):
+    ones = [1] * 6
+    for tag, geno, kw, shape in (
+            ('derived.node4.c8.d5', GS.senas_node_4, dict(nclass=2, in_channels=1, c=8, depth=5), (2, 1, 128, 128)),
+            ('derived.node4.c8', GS.senas_node_4, dict(nclass=2, in_channels=1, c=8, depth=4), (2, 1, 64, 64)),
+            ('derived.node4.c8.rgb4', GS.senas_node_4, dict(nclass=4, in_channels=3, c=8, depth=4), (2, 3, 64, 64)),
+            ('derived.node3.c8', GS.senas_node_3, dict(nclass=2, in_channels=1, c=8, depth=4), (2, 1, 64, 64)),
+            ('derived.node2.c8.sup', GS.senas_node_2._replace(gamma=ones), dict(nclass=2, in_channels=1, c=8, depth=4,
+                                                                              supervision=True), (2, 1, 64, 64))):
         net = M.SenasModel(genotype=geno, **kw)
         _rand_init(net, gen)
         net.train()
         x = torch.randn(*shape, generator=gen)
         tgt = torch.randint(0, kw['nclass'], (shape[0],) + shape[2:], generator=gen)
-        out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
-        logits = net(x)
-        loss = crit(logits, tgt)
-        loss.backward()
-        out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
-        for i, l in enumerate(logits):
-            out[tag + '/logits%d' % i] = _np(l)
-        out[tag + '/loss'] = _np(loss)
         out[tag + '/kw'] = np.array(json.dumps(kw))
         out[tag + '/genotype'] = np.array(_geno_json(geno))
-        _net_record(net, tag, out, full_grad=lambda k: False)
+        _net_case(net, x, tgt, crit, tag, out, arch_full=False)
         net.eval()
         with torch.no_grad():
             out[tag + '/logits_eval'] = _np(net(x)[-1])

@@ -1,0 +1,178 @@
+"""CPU-side checks (run in the `-m "not gpu"` suite): the C-ABI library loads and exports every
+symbol include/senas_hip.h declares, the module tree emits the reference's state_dict keys, the
+genotype logic is bit-exact, and the product path refuses to compute without a GPU."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KINDS = None
+
+
+def _kinds():
+    from senas_amd.operations import OpType
+    return {'up': OpType.UP, 'down': OpType.DOWN, 'norm': OpType.NORM}
+
+
+# ------------------------------------------------------------------ C ABI
+def test_abi_header_matches_binding_and_library():
+    from senas_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'senas_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(senas_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.lib()                      # raises if libsenas_hip.so is missing or lacks a symbol
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.senas_abi_version() == 1
+    # argument counts of the binding agree with the header
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r'\b%s\s*\(([^;]*?)\)\s*;' % name, hdr, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(',') if p.strip() and p.strip() != 'void']
+        assert len(params) == len(args), (name, len(params), len(args))
+
+
+def test_invalid_arguments_are_reported_not_executed():
+    """Entry points validate before launching: a null pointer / inconsistent geometry returns
+    SENAS_EINVAL with a message (no GPU needed -- nothing is launched)."""
+    import ctypes as C
+    from senas_amd import _lib
+    lib = _lib.lib()
+    g = _lib.ConvGeom(1, 8, 8, 4, 9, 9, 4, 3, 3, 1, 1, 1, 0, 1)      # ho/wo inconsistent with the rest
+    assert lib.senas_conv2d_fwd(C.byref(g), None, None, None, 0, None, None, None) == -1
+    assert b'geometry' in lib.senas_last_error()
+    assert lib.senas_relu_fwd(16, None, None, None) == -1
+    assert lib.senas_chan_stats(1, 16, 300, None, None, None) == -1
+    with pytest.raises(_lib.SenasHipError):
+        _lib.check(-1, 'probe')
+
+
+def test_no_cpu_fallback():
+    from senas_amd._lib import SenasHipError
+    from senas_amd.operations import OPS, OpType
+    op = OPS['dil_3_conv_5'](8, 8, OpType.NORM, 0)
+    with pytest.raises(SenasHipError):
+        op(torch.zeros(1, 8, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'senas_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in re.sub(r'""".*?"""', '', src, flags=re.S), f
+
+
+# ------------------------------------------------------------------ state_dict interchange
+def _keys_shapes(module):
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+@pytest.mark.parametrize('tag', gio.index('prims'))
+def test_primitive_state_dict_keys(tag):
+    from senas_amd.operations import OPS
+    z = gio.load('prims')
+    kind, name, ci, co = tag.split('.')
+    mod = OPS[name](int(ci), int(co), _kinds()[kind], 0)
+    exp = {k: tuple(v.shape) for k, v in gio.sub(z, tag + '/sd0/').items()}
+    assert _keys_shapes(mod) == exp
+
+
+@pytest.mark.parametrize('tag', gio.index('nets'))
+def test_net_state_dict_keys(tag):
+    from senas_amd.genotype import Genotype
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import NAS
+    z = gio.load('nets')
+    kw = json.loads(str(z[tag + '/kw']))
+    if tag.startswith('nas'):
+        net = NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+    else:
+        net = SenasModel(genotype=gio.geno_from_json(z[tag + '/genotype'], Genotype), **kw)
+    exp = {k: tuple(s) for k, s, _ in json.loads(str(z[tag + '/sd0/index']))}
+    got = {k: s for k, s in _keys_shapes(net).items() if not k.endswith('num_batches_tracked')}
+    assert got == exp
+    # same key ORDER as the reference (checkpoints are ordered dicts)
+    assert [k for k in net.state_dict() if not k.endswith('num_batches_tracked')] == \
+        [k for k, _, _ in json.loads(str(z[tag + '/sd0/index']))]
+    # named_parameters() reports exactly the names the reference's optimizer sees
+    assert {k for k, _ in net.named_parameters()} == set(gio.digest(z, tag + '/grad/'))
+
+
+def test_full_width_parameter_counts():
+    """supernet 1 967 552 weights (+246 arch scalars), derived net 2 164 128."""
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import NAS
+    nas = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=torch.device('cpu'))
+    arch = sum(p.numel() for p in nas.arch_parameters())
+    assert arch == 246
+    assert sum(p.numel() for p in nas.parameters()) - arch == 1967552
+    assert len(nas.state_dict()) == 6718
+    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
+    assert sum(p.numel() for p in net.parameters()) == 2164128
+    assert len(net.state_dict()) == 807
+    assert sum(p.numel() for p in SenasModel(4, 3, c=32, depth=5, genotype=senas_node_4).parameters()) == 2167840
+
+
+# ------------------------------------------------------------------ genotype logic (bit-exact)
+@pytest.mark.parametrize('tag', [t for t in gio.index('genoparse') if t.startswith('parse')])
+def test_geno_parser(tag):
+    from senas_amd.genotype import GenoParser
+    z = gio.load('genoparse')
+    nodes = int(tag.split('.')[1])
+    for cell in ('down', 'up'):
+        exp = [(a, int(b)) for a, b in json.loads(str(z[tag + '/' + cell]))]
+        got = GenoParser(nodes).parse(z[tag + '/w1'], z[tag + '/w2'], cell)
+        assert [(a, int(b)) for a, b in got] == exp, (tag, cell)
+
+
+@pytest.mark.parametrize('tag', [t for t in gio.index('genoparse') if t.startswith('nasgeno')])
+def test_nas_genotype(tag):
+    from senas_amd.genotype import Genotype
+    from senas_amd.senas_search import NAS
+    z = gio.load('genoparse')
+    _, depth, nodes, _ = tag.split('.')
+    net = NAS(1, 4, 2, int(depth), meta_node_num=int(nodes), use_sharing=False, double_down_channel=False,
+              device=torch.device('cpu'))
+    with torch.no_grad():
+        for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma'):
+            getattr(net, k).copy_(torch.from_numpy(z[tag + '/' + k]))
+    assert net.genotype() == gio.geno_from_json(z[tag + '/genotype'], Genotype)
+
+
+def test_genotype_text_round_trip():
+    """train_model.py:118 eval()s the genotype text in the namespace of the genotype module."""
+    from senas_amd import genotype as G
+    from senas_amd.geno_searched import senas_node_4
+    txt = ("Genotype(down=[('se_conv_3', 1), ('avg_pool', 0), ('dil_3_conv_5', 2), ('dep_sep_conv_5', 1), "
+           "('dil_3_conv_5', 2), ('avg_pool', 0), ('avg_pool', 1), ('dil_3_conv_5', 3)], down_concat=range(2, 6), "
+           "up=[('up_sample', 1), ('dil_3_conv_5', 0), ('dil_3_conv_5', 0), ('dil_2_conv_5', 2), ('dil_3_conv_5', 1), "
+           "('dil_2_conv_5', 2), ('dep_sep_conv_3', 0), ('dil_2_conv_5', 4)], up_concat=range(2, 6), gamma=[0, 0, 0, 1, 1, 1])")
+    assert eval('G.%s' % txt) == senas_node_4     # README.md:44
+    assert repr(senas_node_4) == txt
+
+
+# ------------------------------------------------------------------ loss / metric host logic
+@pytest.mark.parametrize('tag', gio.index('loss_metric'))
+def test_loss_and_metric(tag):
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.metrics import SegmentationMetric
+    z = gio.load('loss_metric')
+    logits = torch.from_numpy(z[tag + '/logits']).requires_grad_(True)
+    tgt = torch.from_numpy(z[tag + '/target'])
+    loss = SegmentationLosses('dice_ce')([logits], tgt)
+    np.testing.assert_allclose(loss.item(), float(z[tag + '/loss']), rtol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(logits.grad.numpy(), z[tag + '/dlogits'], rtol=1e-5, atol=1e-9)
+    m = SegmentationMetric(logits.shape[1])
+    m.update(tgt, logits.detach())
+    m.update(tgt, logits.detach() * 0.5 + 0.1)
+    np.testing.assert_allclose(np.array(m.get()), z[tag + '/metric'], atol=2e-3)

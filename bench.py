@@ -119,6 +119,7 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--search-steps', type=int, default=2, help='timed supernet search steps (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run forward+backward eagerly instead of replaying a HIP graph')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -134,7 +135,7 @@ def main():
 
     from senas_amd import _lib, functional as F
     from senas_amd.loss import SegmentationLosses
-    from senas_amd.parallel import GradAllReducer, broadcast_parameters
+    from senas_amd.parallel import broadcast_parameters
     _lib.lib()
 
     net = build_derived(dev)
@@ -142,25 +143,17 @@ def main():
         broadcast_parameters(net)
     crit = SegmentationLosses('dice_ce')
     opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)     # senas_promise12.yml training block
-    reducer = GradAllReducer(net.parameters(), world_size=world)
     x, y = synthetic(args.batch, 1, 2, args.size, rank, dev)
     params = [p for p in net.parameters()]
-
-    def step():
-        reducer.zero_grad()
-        loss = crit(net(x), y)
-        loss.backward()
-        reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, 5)
-        opt.step()
-        return loss
-
-    log('model on %s, %d params; warm-up x%d' % (dev, sum(p.numel() for p in params), args.warmup))
+    from senas_amd.step import TrainStep
+    log('model on %s, %d params; %s forward+backward' % (dev, sum(p.numel() for p in params),
+                                                          'eager' if args.no_graph else 'capturing HIP graph of'))
+    step = TrainStep(net, crit, opt, x, y, world_size=world, grad_clip=5.0, use_graph=not args.no_graph)
+    log('warm-up x%d' % args.warmup)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     log('timing %d steps' % args.steps)
-    F.TIMER = F.KernelTimer()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -171,6 +164,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event timing: the same step run eagerly right after the timed region (events cannot
+    # be read back from inside a replayed graph; kernel durations are the same in both modes)
+    probe_steps = 2
+    F.TIMER = F.KernelTimer()
+    for _ in range(probe_steps):
+        step.fb._eager()
     timer, F.TIMER = F.TIMER, None
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -182,6 +181,10 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the launch stream, over the timed region)
     agg = timer.summary()
     roof = None
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:14]:
+        log('  %-44s %4d launches %8.3f ms/step  %7.2f TFLOP/s  %7.1f GB/s(alg)' % (
+            name, a['launches'] // probe_steps, a['ms'] / probe_steps, a['flops'] / (a['ms'] * 1e-3) / 1e12,
+            a['bytes'] / (a['ms'] * 1e-3) / 1e9))
     if agg:
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         per_launch_ms = a['ms'] / a['launches']
@@ -190,8 +193,9 @@ def main():
                 'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': None, 'launches': a['launches'],
                 'avg_launch_ms': round(per_launch_ms, 4),
                 'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 3),
-                'share_of_step': round(a['ms'] / (elapsed * 1e3), 3),
-                'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / args.steps, 2)}
+                'share_of_step': round((a['ms'] / probe_steps) / (1e3 * elapsed / args.steps), 3),
+                'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / probe_steps, 2),
+                'timing_source': 'HIP events around each launch, %d eager steps right after the timed region' % probe_steps}
 
     out = {
         'metric': 'images/sec at 256x256 - senas derived-genotype train step (fwd+loss+bwd+clip+SGD)',
@@ -200,7 +204,8 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (randn slices, randint labels, seed 1+rank), random-init weights',
         'config': {'workload': 'BASELINE configs[1]: SenasModel README genotype (senas_node_4), c=32 depth=5, '
                                '%dx1x%dx%d per GPU, fp32' % (args.batch, args.size, args.size),
-                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach())},
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach()),
+                   'hip_graph': bool(step.graphed)},
         'roofline': roof,
     }
 

@@ -121,6 +121,51 @@ int senas_combine_bwd_apply(int n, int64_t hw, int c, int nterms, const float* c
                             const float* y, int relu, const float* a, const float* b, const float* k,
                             float* const* dz, float* ds_out, void* stream);
 
+/* ---- one cell node in two / three launches --------------------------------------------------------
+ * The production path of the fused node: the per-term bookkeeping (batch statistics -> scale/shift,
+ * running-stat update of every nn.BatchNorm2d, the SE gate of se_conv_3 -- operations.py:186-203 --
+ * and the alpha*beta mixing weight, search/cell.py:34-36,104) is done by one small "prepare" kernel
+ * instead of dozens of elementwise launches; senas_combine_* above stay as the building blocks.
+ *
+ * Term t (t < nterms <= SENAS_MAX_TERMS) is described column-wise; z[t] == NULL marks the all-zero
+ * input of the 'none' op (operations.py:9,155-164), which contributes its batch-norm bias only.
+ *   stats[t]      : double[n][c][2] per-image sum / sum-of-squares of z_t (NULL for a 'none' term)
+ *   gamma/beta    : float[c] BatchNorm2d weight / bias
+ *   running_mean, running_var, num_batches_tracked: updated in place when training != 0 (may be
+ *                   NULL in training mode; required in eval mode)
+ *   se_w1[t]      : float[mid][c] or NULL (no SE);  se_w2[t]: float[c][mid];  se_mid[t] <= 16
+ *   mix           : device float[nterms] mixing weights, or NULL for all ones                      */
+typedef struct senas_node_desc {
+    int32_t nterms, n, c, training, relu;
+    int64_t hw;
+    float eps, momentum;
+    const double* stats[SENAS_MAX_TERMS];
+    const float* gamma[SENAS_MAX_TERMS];
+    const float* beta[SENAS_MAX_TERMS];
+    float* running_mean[SENAS_MAX_TERMS];
+    float* running_var[SENAS_MAX_TERMS];
+    int64_t* num_batches_tracked[SENAS_MAX_TERMS];
+    const float* se_w1[SENAS_MAX_TERMS];
+    const float* se_w2[SENAS_MAX_TERMS];
+    int32_t se_mid[SENAS_MAX_TERMS];
+    const float* mix;
+} senas_node_desc;
+
+/* y = act(sum_t mix_t * gate_t * BN_t(z_t) + residual).  Saved for backward (caller-allocated):
+ *   coefs  float[nterms][4][c]  (mean, invstd, scale, shift)      gate   float[nterms][n][c]
+ *   coef   float[nterms][n][c]  shiftc float[nterms][n][c]        (scratch of the forward pass)
+ *   se_m   float[nterms][n][c], se_a1 float[nterms][n][16]        (only touched for SE terms; may be NULL without) */
+int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
+                   float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, void* stream);
+/* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
+ *   dgamma, dbeta: float[nterms][c]; dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
+ *   abk: float[3][nterms][n][c] scratch; dz[t]: gradient of z_t or NULL (skipped); ds_out: gradient of
+ *   the residual input or NULL.                                                                    */
+int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
+                   const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+                   double* p1, double* p2, float* dgamma, float* dbeta, float* dmix, float* const* dse_w1,
+                   float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 const char* senas_last_error(void);
 int senas_abi_version(void);

@@ -19,8 +19,22 @@ class ConvGeom(C.Structure):
                                          'transposed', 'groups')]
 
 
+_T = MAX_TERMS
+
+
+class NodeDesc(C.Structure):
+    """senas_node_desc (include/senas_hip.h)."""
+    _fields_ = [('nterms', C.c_int32), ('n', C.c_int32), ('c', C.c_int32), ('training', C.c_int32), ('relu', C.c_int32),
+                ('hw', C.c_int64), ('eps', C.c_float), ('momentum', C.c_float),
+                ('stats', C.c_void_p * _T), ('gamma', C.c_void_p * _T), ('beta', C.c_void_p * _T),
+                ('running_mean', C.c_void_p * _T), ('running_var', C.c_void_p * _T),
+                ('num_batches_tracked', C.c_void_p * _T), ('se_w1', C.c_void_p * _T), ('se_w2', C.c_void_p * _T),
+                ('se_mid', C.c_int32 * _T), ('mix', C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _G = C.POINTER(ConvGeom)
+_N = C.POINTER(NodeDesc)
 _PP = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/senas_hip.h one to one
@@ -42,6 +56,8 @@ SIGNATURES = {
     'senas_combine_fwd': (_I, [_I, _L, _I, _I, _PP, _P, _P, _P, _I, _P, _P]),
     'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
     'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),
+    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_node_bwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _PP, _P, _P]),
     'senas_last_error': (C.c_char_p, []),
     'senas_abi_version': (_I, []),
 }

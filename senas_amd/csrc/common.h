@@ -56,6 +56,22 @@ __device__ __forceinline__ bool tap_src(const GatherGeom& g, int o, int k, int l
     return i >= 0 && i < lim;
 }
 
+// Weight-gradient geometry: G lives on the coarse grid (hg x wg, B channels), I on the fine grid
+// (hi x wi, A channels); dW[b][a][tap] = sum_{n,p} I[n, p*stride - pad + k*dil][a] * G[n, p][b].
+struct WgradGeom {
+    int n, hg, wg, B, hi, wi, A, kh, kw, stride, pad, dil, chunk;
+};
+
+// conv_mfma.hip
+bool mfma_gather_ok(const GatherGeom& g, bool tg);
+template <bool TG>
+int launch_mfma_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
+                       const float* mask, double* stats, hipStream_t st);
+void launch_pack_mfma(const float* w, float* wp, int d0, int d1, int taps, int swap, hipStream_t st);
+bool mfma_wgrad_ok(const WgradGeom& g);
+int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, float* ws, int i_relu, int g_relu,
+                      hipStream_t st);
+
 // V consecutive floats (V == 4: one 16-byte access; the caller guarantees 16-byte alignment)
 template <int V>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[V]) {

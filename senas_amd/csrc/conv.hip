@@ -127,9 +127,6 @@ static int launch_direct(const GatherGeom& g, const float* in, const float* wp, 
 // dense weight gradient.  dW[b][a][tap] = sum_{n,p} I[n, p*s - pad + k*d][a] * G[n,p][b]
 // G lives on the coarse grid (hg x wg, channels B), I on the fine grid (hi x wi, channels A).
 // grid = (pixel chunks, taps, a-tiles * b-tiles); block 256 = 32 b-lanes x 8 a-groups of 4.
-struct WgradGeom {
-    int n, hg, wg, B, hi, wi, A, kh, kw, stride, pad, dil, chunk;
-};
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGeom g, const float* __restrict__ I,
                                                          const float* __restrict__ G, float* __restrict__ dw,
@@ -220,38 +217,56 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
 }
 
 // depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
-// grid = (pixel chunks, taps); block = rows x C lanes, C <= 256.
+// grid = pixel chunks; block = rows x C lanes (C <= 256); every thread keeps one partial per tap, so
+// G is read once and the taps' I reads hit L1.
+template <int KS>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const float* __restrict__ I,
                                                            const float* __restrict__ G, float* __restrict__ dw,
                                                            int i_relu, int g_relu) {
     __shared__ float red[256];
+    constexpr int TAPS = KS * KS;
     const int C = g.A;
     const int rows = 256 / C;
     const int c = threadIdx.x % C, row = threadIdx.x / C;
-    const int tap = blockIdx.y, ky = tap / g.kw, kx = tap % g.kw;
     const int per_img = g.hg * g.wg;
     const long total = (long)g.n * per_img;
     long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
     if (p1 > total) p1 = total;
-    float acc = 0.f;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
     if (row < rows) {
         for (long p = p0 + row; p < p1; p += rows) {
             const int n = (int)(p / per_img), r = (int)(p % per_img);
             const int gy = r / g.wg, gx = r % g.wg;
-            const int iy = gy * g.stride - g.pad + ky * g.dil, ix = gx * g.stride - g.pad + kx * g.dil;
-            if (iy < 0 || iy >= g.hi || ix < 0 || ix >= g.wi) continue;
             float gv = G[(size_t)p * C + c];
-            float iv = I[((size_t)(n * g.hi + iy) * g.wi + ix) * C + c];
             if (g_relu) gv = fmaxf(gv, 0.f);
-            if (i_relu) iv = fmaxf(iv, 0.f);
-            acc = fmaf(iv, gv, acc);
+            const float* In = I + (size_t)n * g.hi * g.wi * C + c;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = gy * g.stride - g.pad + ky * g.dil;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int ix = gx * g.stride - g.pad + kx * g.dil;
+                    const bool ok = iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+                    float iv = In[ok ? (size_t)(iy * g.wi + ix) * C : 0];
+                    if (!ok) iv = 0.f;
+                    if (i_relu) iv = fmaxf(iv, 0.f);
+                    acc[ky * KS + kx] = fmaf(iv, gv, acc[ky * KS + kx]);
+                }
+            }
         }
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (row == 0) {
-        for (int r = 1; r < rows; ++r) acc += red[r * C + c];
-        atomicAdd(&dw[c * g.kh * g.kw + tap], acc);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        __syncthreads();
+        red[threadIdx.x] = row < rows ? acc[t] : 0.f;
+        __syncthreads();
+        if (row == 0) {
+            float v = acc[t];
+            for (int r = 1; r < rows; ++r) v += red[r * C + c];
+            atomicAdd(&dw[c * TAPS + t], v);
+        }
     }
 }
 
@@ -278,7 +293,10 @@ using namespace senas;
 extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     if (!g) return 0;
     if (g->groups != 1) return 16;
-    return (int64_t)g->kh * g->kw * g->ci * g->co * sizeof(float) + 256;
+    // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
+    const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
+    const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
+    return (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
 }
 
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
@@ -304,6 +322,11 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    if (mfma_gather_ok(gg, g->transposed != 0)) {
+        if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st); return launch_mfma_gather<false>(gg, x, wp, y, in_relu, nullptr, stats, st); }
+        launch_pack_mfma(w, wp, g->ci, g->co, taps, 0, st);
+        return launch_mfma_gather<true>(gg, x, wp, y, in_relu, nullptr, stats, st);
+    }
     // Conv2d w[co][ci][tap] -> wp[tap][ci][co] (swap); ConvTranspose2d w[ci][co][tap] -> wp[tap][ci][co]
     if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 1);
     else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 0);
@@ -336,6 +359,11 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     SENAS_REQUIRE(ws, "conv2d_bwd_data: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    if (mfma_gather_ok(gg, g->transposed == 0)) {
+        if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st); return launch_mfma_gather<true>(gg, dy, wp, dx, 0, mask, nullptr, st); }
+        launch_pack_mfma(w, wp, g->ci, g->co, taps, 1, st);
+        return launch_mfma_gather<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
+    }
     // wp[tap][a = co][b = ci]
     if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 0);
     else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 1);
@@ -345,7 +373,6 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
 
 extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw,
                                        void* ws, void* stream) {
-    (void)ws;
     SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_weight: inconsistent geometry");
     SENAS_REQUIRE(x && dy && dw, "conv2d_bwd_weight: null pointer");
     hipStream_t st = as_stream(stream);
@@ -365,10 +392,18 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         SENAS_REQUIRE(g->ci <= 256, "depthwise wgrad: more than 256 channels");
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * taps * sizeof(float), st);
         if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }
-        wg.chunk = 4096;
-        dim3 grid((unsigned)((total + wg.chunk - 1) / wg.chunk), taps);
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
+        SENAS_REQUIRE(g->kh == g->kw && (g->kh == 3 || g->kh == 5), "depthwise wgrad: only 3x3 and 5x5 are on the path");
+        long chunk = (total + 1023) / 1024;
+        if (chunk < 64) chunk = 64;
+        wg.chunk = (int)chunk;
+        dim3 grid((unsigned)((total + wg.chunk - 1) / wg.chunk));
+        if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_kernel<3>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<5>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
         return launch_status("dwconv_wgrad");
+    }
+    if (mfma_wgrad_ok(wg)) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        return launch_mfma_wgrad(wg, I, G, dw, reinterpret_cast<float*>(ws), i_relu, g_relu, st);
     }
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * g->co * taps * sizeof(float), st);
     if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }

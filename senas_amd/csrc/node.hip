@@ -1,0 +1,467 @@
+// Cell-node kernels: everything between the raw convolution outputs and the node tensor.
+//
+//   forward : [prepare]  per term: batch statistics -> mean / invstd / scale / shift, running-stat
+//                        update, SE gate (squeeze from the statistics, two tiny mat-vecs, sigmoid),
+//                        mixing weight folded in  ->  coef[t][n][c], shiftc[t][n][c]
+//             [combine]  y = act(sum_t coef * z_t + sum_t shiftc + residual)      (one pass over HBM)
+//   backward: [reduce]   p1 = sum ds, p2_t = sum ds * z_t per (n, c)             (one pass)
+//             [prepare]  d gamma, d beta, d mix, d SE weights, and the per-(n,c) coefficients of
+//                        dz_t = A * ds + B * z_t + K
+//             [apply]    writes every dz_t (and ds for a residual input)         (one pass)
+//
+// The prepare kernels are tiny (one block per term) and replace ~25 / ~40 elementwise launches.
+#include "common.h"
+
+namespace senas {
+
+constexpr int kMaxMid = 16;      // SE hidden width: c/16, c <= 256
+
+struct NodeDesc {                // device-visible copy of senas_node_desc
+    int nterms, n, c, training, relu;
+    long hw;
+    float eps, momentum;
+    const double* stats[SENAS_MAX_TERMS];
+    const float* gamma[SENAS_MAX_TERMS];
+    const float* beta[SENAS_MAX_TERMS];
+    float* rmean[SENAS_MAX_TERMS];
+    float* rvar[SENAS_MAX_TERMS];
+    int64_t* nbt[SENAS_MAX_TERMS];
+    const float* w1[SENAS_MAX_TERMS];
+    const float* w2[SENAS_MAX_TERMS];
+    int mid[SENAS_MAX_TERMS];
+    const float* mix;
+};
+
+struct ZTable {
+    const float* p[SENAS_MAX_TERMS];
+};
+struct DzTable {
+    float* p[SENAS_MAX_TERMS];
+};
+struct SeGradTable {
+    float* w1[SENAS_MAX_TERMS];
+    float* w2[SENAS_MAX_TERMS];
+};
+
+// ------------------------------------------------------------------------------------------ forward prepare
+// grid = nterms blocks of 256 threads; c <= 256.
+__global__ __launch_bounds__(256) void node_prepare_fwd_kernel(NodeDesc d, float* __restrict__ coefs, float* __restrict__ gate,
+                                                               float* __restrict__ coef, float* __restrict__ shiftc,
+                                                               float* __restrict__ se_m, float* __restrict__ se_a1) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // m[n][c] then a1[n][kMaxMid]
+    const int t = blockIdx.x, ch = threadIdx.x, n = d.n, c = d.c;
+    const bool act = ch < c;
+    float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
+    const double* st = d.stats[t];
+    if (act) {
+        if (d.training) {
+            double s = 0.0, q = 0.0;
+            if (st != nullptr)
+                for (int i = 0; i < n; ++i) { s += st[((size_t)i * c + ch) * 2]; q += st[((size_t)i * c + ch) * 2 + 1]; }
+            const double m = (double)n * (double)d.hw, mu = s / m;
+            double var = q / m - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            if (d.rmean[t] != nullptr) {
+                const double unbiased = m > 1.0 ? var * m / (m - 1.0) : var;
+                d.rmean[t][ch] = (1.f - d.momentum) * d.rmean[t][ch] + d.momentum * mean;
+                d.rvar[t][ch] = (1.f - d.momentum) * d.rvar[t][ch] + d.momentum * (float)unbiased;
+            }
+        } else {
+            mean = d.rmean[t][ch];
+            invstd = 1.f / sqrtf(d.rvar[t][ch] + d.eps);
+        }
+        scale = d.gamma[t][ch] * invstd;
+        shift = d.beta[t][ch] - mean * scale;
+        float* co = coefs + (size_t)t * 4 * c;
+        co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
+    }
+    if (threadIdx.x == 0 && d.training && d.nbt[t] != nullptr) *d.nbt[t] += 1;
+    const float w = d.mix != nullptr ? d.mix[t] : 1.f;
+    const size_t tb = (size_t)t * n * c;
+    if (d.w1[t] == nullptr) {
+        if (act)
+            for (int i = 0; i < n; ++i) {
+                gate[tb + (size_t)i * c + ch] = 1.f;
+                coef[tb + (size_t)i * c + ch] = w * scale;
+                shiftc[tb + (size_t)i * c + ch] = w * shift;
+            }
+        return;
+    }
+    // ---- squeeze-and-excitation: m = mean_hw(BN(z)) = scale * mean_hw(z) + shift
+    const int mid = d.mid[t];
+    float* m_s = lds;
+    float* a_s = lds + n * c;
+    if (act)
+        for (int i = 0; i < n; ++i) {
+            const double zbar = st != nullptr ? st[((size_t)i * c + ch) * 2] / (double)d.hw : 0.0;
+            const float mv = (float)((double)scale * zbar + (double)shift);
+            m_s[i * c + ch] = mv;
+            se_m[tb + (size_t)i * c + ch] = mv;
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * mid; idx += blockDim.x) {
+        const int i = idx / mid, j = idx % mid;
+        float a = 0.f;
+        for (int k = 0; k < c; ++k) a = fmaf(m_s[i * c + k], d.w1[t][j * c + k], a);
+        a_s[i * kMaxMid + j] = a;
+        se_a1[((size_t)t * n + i) * kMaxMid + j] = a;
+    }
+    __syncthreads();
+    if (act)
+        for (int i = 0; i < n; ++i) {
+            float a = 0.f;
+            for (int j = 0; j < mid; ++j) a = fmaf(fmaxf(a_s[i * kMaxMid + j], 0.f), d.w2[t][ch * mid + j], a);
+            const float g = 1.f / (1.f + expf(-a));
+            gate[tb + (size_t)i * c + ch] = g;
+            coef[tb + (size_t)i * c + ch] = w * g * scale;
+            shiftc[tb + (size_t)i * c + ch] = w * g * shift;
+        }
+}
+
+// ------------------------------------------------------------------------------------------ forward combine
+// grid = (tiles, n); coefficients of image n are staged in LDS once per block.
+template <int V>
+__global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, int nterms, int nimg, ZTable z,
+                                                               const float* __restrict__ coef, const float* __restrict__ shiftc,
+                                                               const float* __restrict__ residual, int relu,
+                                                               float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
+    const int n = blockIdx.y;
+    float* bias = lds + nterms * c;
+    for (int i = threadIdx.x; i < nterms * c; i += 256) {
+        const int t = i / c, ch = i % c;
+        lds[i] = coef[((size_t)t * nimg + n) * c + ch];
+    }
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float b = 0.f;
+        for (int t = 0; t < nterms; ++t) b += shiftc[((size_t)t * nimg + n) * c + ch];
+        bias[ch] = b;
+    }
+    __syncthreads();
+    const int cv = c / V;
+    const long per_img = hw * cv;
+    const size_t img_off = (size_t)n * hw * c;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cv) * V;
+        const size_t off = img_off + (size_t)(i / cv) * c + ch;
+        float acc[V], tmp[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = bias[ch + j];
+        if (residual != nullptr) {
+            ldv<V>(residual + off, tmp);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += tmp[j];
+        }
+        for (int t = 0; t < nterms; ++t) {
+            if (z.p[t] == nullptr) continue;
+            ldv<V>(z.p[t] + off, tmp);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+        stv<V>(y + off, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward reduce
+// p1[n][c] += sum_p ds ; p2[t][n][c] += sum_p ds * z_t for t in [t0, t0 + TT).  block = rows x c lanes.
+template <int TT>
+__global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
+                                                          const float* __restrict__ dy, const float* __restrict__ y,
+                                                          int relu, int do_p1, double* __restrict__ p1,
+                                                          double* __restrict__ p2) {
+    __shared__ double red[256];
+    const int rows = 256 / c;
+    const int ch = threadIdx.x % c, row = threadIdx.x / c;
+    const int n = blockIdx.y;
+    long q0 = (long)blockIdx.x * chunk, q1 = q0 + chunk;
+    if (q1 > hw) q1 = hw;
+    double a1 = 0.0, a2[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) a2[t] = 0.0;
+    if (row < rows) {
+        const size_t base = (size_t)n * hw * c + ch;
+        for (long p = q0 + row; p < q1; p += rows) {
+            const size_t o = base + (size_t)p * c;
+            float ds = dy[o];
+            if (relu && !(y[o] > 0.f)) ds = 0.f;
+            a1 += ds;
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                if (t < tt && z.p[t0 + t] != nullptr) a2[t] += (double)ds * (double)z.p[t0 + t][o];
+        }
+    }
+    auto reduce_to = [&](double v, double* dst) {
+        __syncthreads();
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (row == 0) {
+            for (int r = 1; r < rows; ++r) v += red[r * c + ch];
+            atomicAdd(dst, v);
+        }
+    };
+    if (do_p1) reduce_to(a1, p1 + (size_t)n * c + ch);
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+        if (t < tt && z.p[t0 + t] != nullptr) reduce_to(a2[t], p2 + ((size_t)(t0 + t) * nimg + n) * c + ch);
+}
+
+// ------------------------------------------------------------------------------------------ backward prepare
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+__global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
+                                                               const double* __restrict__ p2, const float* __restrict__ coefs,
+                                                               const float* __restrict__ gate, const float* __restrict__ se_m,
+                                                               const float* __restrict__ se_a1, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dmix,
+                                                               float* __restrict__ A, float* __restrict__ B, float* __restrict__ K,
+                                                               SeGradTable seg) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];     // da2[n][c], da1[n][kMaxMid]
+    __shared__ double red[256];
+    const int t = blockIdx.x, ch = threadIdx.x, n = d.n, c = d.c;
+    const bool act = ch < c;
+    const size_t tb = (size_t)t * n * c;
+    const double hw = (double)d.hw, M = (double)n * hw;
+    const float* co = coefs + (size_t)t * 4 * c;
+    const double mean = act ? co[ch] : 0.0, invstd = act ? co[c + ch] : 0.0, scale = act ? co[2 * c + ch] : 0.0,
+                 shift = act ? co[3 * c + ch] : 0.0;
+    const double w = d.mix != nullptr ? (double)d.mix[t] : 1.0;
+    const double* st = d.stats[t];
+    const bool se = d.w1[t] != nullptr;
+    const int mid = se ? d.mid[t] : 0;
+    double* da2 = ldsd;
+    double* da1 = ldsd + (size_t)n * c;
+
+    // d loss / d(mix_t * gate) per (n, c): full-tensor dot product of ds with BN_t(z_t)
+    double dmix_part = 0.0;
+    if (act)
+        for (int i = 0; i < n; ++i) {
+            const double dot = scale * p2[tb + (size_t)i * c + ch] + shift * p1[(size_t)i * c + ch];
+            const double g = gate[tb + (size_t)i * c + ch];
+            dmix_part += g * dot;
+            if (se) da2[i * c + ch] = w * dot * g * (1.0 - g);
+        }
+    const double dmix_tot = block_sum(dmix_part, red);
+    if (threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)dmix_tot;
+
+    if (se) {
+        __syncthreads();
+        // dW2[c][j] = sum_n da2[n][c] * relu(a1[n][j])
+        if (act)
+            for (int j = 0; j < mid; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < n; ++i) s += da2[i * c + ch] * fmaxf(se_a1[((size_t)t * n + i) * kMaxMid + j], 0.f);
+                seg.w2[t][ch * mid + j] = (float)s;
+            }
+        // da1[n][j] = (a1 > 0) * sum_c da2[n][c] * W2[c][j]
+        for (int idx = threadIdx.x; idx < n * mid; idx += blockDim.x) {
+            const int i = idx / mid, j = idx % mid;
+            double s = 0.0;
+            for (int k = 0; k < c; ++k) s += da2[i * c + k] * d.w2[t][k * mid + j];
+            da1[i * kMaxMid + j] = se_a1[((size_t)t * n + i) * kMaxMid + j] > 0.f ? s : 0.0;
+        }
+        __syncthreads();
+        // dW1[j][c] = sum_n da1[n][j] * m[n][c]
+        if (act)
+            for (int j = 0; j < mid; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < n; ++i) s += da1[i * kMaxMid + j] * se_m[tb + (size_t)i * c + ch];
+                seg.w1[t][j * c + ch] = (float)s;
+            }
+    }
+    if (!act) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double u1 = w * gate[tb + (size_t)i * c + ch];
+        double e = 0.0;
+        if (se) {
+            for (int j = 0; j < mid; ++j) e += da1[i * kMaxMid + j] * d.w1[t][j * c + ch];
+            e /= hw;
+        }
+        const double Z = st != nullptr ? st[((size_t)i * c + ch) * 2] : 0.0;
+        s1 += u1 * p1[(size_t)i * c + ch] + hw * e;
+        s2 += u1 * p2[tb + (size_t)i * c + ch] + e * Z;
+    }
+    const double kk = s2 - mean * s1;
+    dbeta[(size_t)t * c + ch] = (float)s1;
+    dgamma[(size_t)t * c + ch] = (float)(invstd * kk);
+    const double bcoef = d.training ? -scale * invstd * invstd * kk / M : 0.0;
+    const double kconst = d.training ? (-scale * s1 / M + scale * invstd * invstd * mean * kk / M) : 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double u1 = w * gate[tb + (size_t)i * c + ch];
+        double e = 0.0;
+        if (se) {
+            for (int j = 0; j < mid; ++j) e += da1[i * kMaxMid + j] * d.w1[t][j * c + ch];
+            e /= hw;
+        }
+        A[tb + (size_t)i * c + ch] = (float)(scale * u1);
+        B[tb + (size_t)i * c + ch] = (float)bcoef;
+        K[tb + (size_t)i * c + ch] = (float)(scale * e + kconst);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward apply
+template <int V>
+__global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nterms, int nimg, ZTable z,
+                                                         const float* __restrict__ dy, const float* __restrict__ y, int relu,
+                                                         const float* __restrict__ A, const float* __restrict__ B,
+                                                         const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
+    const int cv = c / V;
+    const long per_img = hw * cv;
+    const int n = blockIdx.y;
+    const size_t img_off = (size_t)n * hw * c;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cv) * V;
+        const size_t off = img_off + (size_t)(i / cv) * c + ch;
+        float ds[V], yv[V], zv[V], av[V], bv[V], kv[V];
+        ldv<V>(dy + off, ds);
+        if (relu) {
+            ldv<V>(y + off, yv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) if (!(yv[j] > 0.f)) ds[j] = 0.f;
+        }
+        if (ds_out != nullptr) stv<V>(ds_out + off, ds);
+        for (int t = 0; t < nterms; ++t) {
+            float* out = dz.p[t];
+            if (out == nullptr) continue;
+            const size_t ko = ((size_t)t * nimg + n) * c + ch;
+            ldv<V>(z.p[t] + off, zv);
+            ldv<V>(A + ko, av);
+            ldv<V>(B + ko, bv);
+            ldv<V>(K + ko, kv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) zv[j] = fmaf(av[j], ds[j], fmaf(bv[j], zv[j], kv[j]));
+            stv<V>(out + off, zv);
+        }
+    }
+}
+
+static bool fill_desc(const senas_node_desc* s, NodeDesc& d) {
+    if (!s || s->nterms < 1 || s->nterms > SENAS_MAX_TERMS || s->n < 1 || s->c < 1 || s->c > 256 || s->hw < 1) return false;
+    d.nterms = s->nterms; d.n = s->n; d.c = s->c; d.training = s->training; d.relu = s->relu; d.hw = (long)s->hw;
+    d.eps = s->eps; d.momentum = s->momentum; d.mix = s->mix;
+    for (int t = 0; t < SENAS_MAX_TERMS; ++t) {
+        const bool in = t < s->nterms;
+        d.stats[t] = in ? s->stats[t] : nullptr;
+        d.gamma[t] = in ? s->gamma[t] : nullptr;
+        d.beta[t] = in ? s->beta[t] : nullptr;
+        d.rmean[t] = in ? s->running_mean[t] : nullptr;
+        d.rvar[t] = in ? s->running_var[t] : nullptr;
+        d.nbt[t] = in ? s->num_batches_tracked[t] : nullptr;
+        d.w1[t] = in ? s->se_w1[t] : nullptr;
+        d.w2[t] = in ? s->se_w2[t] : nullptr;
+        d.mid[t] = in ? s->se_mid[t] : 0;
+        if (in) {
+            if (!d.gamma[t] || !d.beta[t]) return false;
+            if ((d.rmean[t] == nullptr) != (d.rvar[t] == nullptr)) return false;
+            if (!s->training && !d.rmean[t]) return false;
+            if (d.w1[t] && (!d.w2[t] || d.mid[t] < 1 || d.mid[t] > kMaxMid)) return false;
+        }
+    }
+    return true;
+}
+
+static long node_chunk(long hw, int n) {
+    long per_img = 1024 / (n > 0 ? n : 1);
+    if (per_img < 1) per_img = 1;
+    long chunk = (hw + per_img - 1) / per_img;
+    return chunk < 256 ? 256 : chunk;
+}
+
+static unsigned node_grid(long work, int n) {
+    long b = (work + 255) / 256;
+    const long cap = 4096 / (n > 0 ? n : 1);
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace senas
+
+using namespace senas;
+
+extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
+                              float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1,
+                              void* stream) {
+    NodeDesc d;
+    SENAS_REQUIRE(fill_desc(desc, d), "node_fwd: bad descriptor");
+    SENAS_REQUIRE(z && y && coefs && gate && coef && shiftc, "node_fwd: null pointer");
+    ZTable zt{};
+    bool any_se = false;
+    for (int t = 0; t < d.nterms; ++t) {
+        zt.p[t] = z[t];
+        if (d.w1[t]) { any_se = true; SENAS_REQUIRE(d.stats[t], "node_fwd: SE term without statistics"); }
+        SENAS_REQUIRE(!(d.training && z[t] && !d.stats[t]), "node_fwd: training-mode term without statistics");
+    }
+    SENAS_REQUIRE(!any_se || (se_m && se_a1), "node_fwd: SE scratch missing");
+    hipStream_t st = as_stream(stream);
+    const size_t lds1 = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(float) : 0;
+    hipLaunchKernelGGL(node_prepare_fwd_kernel, dim3(d.nterms), dim3(256), lds1, st, d, coefs, gate, coef, shiftc, se_m, se_a1);
+    const int V = (d.c % 4 == 0) ? 4 : 1;
+    dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+    const size_t lds2 = ((size_t)d.nterms * d.c + d.c) * sizeof(float);
+    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y);
+    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y);
+    return launch_status("node_fwd");
+}
+
+extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
+                              const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+                              double* p1, double* p2, float* dgamma, float* dbeta, float* dmix, float* const* dse_w1,
+                              float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream) {
+    NodeDesc d;
+    SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
+    SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y), "node_bwd: null pointer");
+    ZTable zt{};
+    DzTable dzt{};
+    SeGradTable seg{};
+    bool any_se = false, any_dz = false;
+    for (int t = 0; t < d.nterms; ++t) {
+        zt.p[t] = z[t];
+        dzt.p[t] = dz[t];
+        SENAS_REQUIRE(z[t] || !dz[t], "node_bwd: dz without z");
+        any_dz = any_dz || dz[t] != nullptr;
+        if (d.w1[t]) {
+            any_se = true;
+            SENAS_REQUIRE(dse_w1 && dse_w2 && dse_w1[t] && dse_w2[t] && se_m && se_a1, "node_bwd: SE gradient buffers missing");
+            seg.w1[t] = dse_w1[t];
+            seg.w2[t] = dse_w2[t];
+        }
+    }
+    hipStream_t st = as_stream(stream);
+    const long chunk = node_chunk(d.hw, d.n);
+    dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
+    int t0 = 0, first = 1;
+    do {
+        const int left = d.nterms - t0;
+        const int tt = left >= 8 ? 8 : left;
+        if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        t0 += tt;
+        first = 0;
+    } while (t0 < d.nterms);
+    const size_t tnc = (size_t)d.nterms * d.n * d.c;
+    const size_t lds = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(double) : 0;
+    hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds, st, d, p1, p2, coefs, gate, se_m, se_a1, dgamma, dbeta,
+                       dmix, abk, abk + tnc, abk + 2 * tnc, seg);
+    if (any_dz || ds_out) {
+        const int V = (d.c % 4 == 0) ? 4 : 1;
+        dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+        if (V == 4) hipLaunchKernelGGL((node_apply_kernel<4>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+        else hipLaunchKernelGGL((node_apply_kernel<1>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+    }
+    return launch_status("node_bwd");
+}

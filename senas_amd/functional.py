@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import ConvGeom, SenasHipError
+from .arena import zeros64
 
 CL = torch.channels_last
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -46,7 +47,7 @@ def _p(t):
 
 
 def new_stats(n, c, like):
-    return torch.zeros((n, c, 2), device=like.device, dtype=torch.float64)
+    return zeros64((n, c, 2), like.device)
 
 
 class KernelTimer(object):
@@ -307,7 +308,7 @@ def chan_stats(z):
     return st
 
 
-# ------------------------------------------------------------------------------------------ normalise + mix + activate
+# ------------------------------------------------------------------------------------------ node terms
 class Term(object):
     """One addend of a node: a raw tensor ``z`` (or None for the all-zero input of the 'none'
     op) that still has to go through its own BatchNorm2d ``bn`` and, for se_conv_3, its SE gate.
@@ -321,170 +322,7 @@ class Term(object):
         self.z, self.bn, self.se, self.stats, self.passengers = z, bn, se, stats, tuple(passengers)
 
 
-class _BNCombine(torch.autograd.Function):
-    """y = act( sum_t mix_t * gate_t * BN_t(z_t) + residual ), one pass over every z_t.
-
-    flat = [z (real terms)..., gamma (all terms)..., beta (all terms)..., se_w1 (se terms)..., se_w2 ..., passengers...]
-    """
-
-    @staticmethod
-    def forward(ctx, meta, mix, residual, *flat):
-        L = _lib.lib()
-        T, real, se_ids = meta['T'], meta['real'], meta['se']
-        nr, ns = len(real), len(se_ids)
-        zs = [nhwc(z) for z in flat[:nr]]
-        gammas, betas = flat[nr:nr + T], flat[nr + T:nr + 2 * T]
-        w1s, w2s = flat[nr + 2 * T:nr + 2 * T + ns], flat[nr + 2 * T + ns:nr + 2 * T + 2 * ns]
-        n, c, h, w = meta['shape']
-        hw = h * w
-        training = meta['training']
-        dev = gammas[0].device
-        for z in zs:
-            if tuple(z.shape) != (n, c, h, w):
-                raise SenasHipError('node terms disagree in shape: %s vs %s' % (tuple(z.shape), (n, c, h, w)))
-        # batch statistics (producer-side where available)
-        stats = torch.zeros((T, n, c, 2), device=dev, dtype=torch.float64)
-        for k, t in enumerate(real):
-            st = meta['stats'][t]
-            if st is None and (training or t in se_ids):
-                st = chan_stats(zs[k])
-            if st is not None:
-                stats[t].copy_(st)
-        coefs = torch.empty((T, 4, c), device=dev, dtype=torch.float32)      # mean, invstd, scale, shift
-        for t in range(T):
-            rm, rv, nbt = meta['buffers'][t]
-            _lib.check(L.senas_bn_finalize(n, hw, c, stats[t].data_ptr(), gammas[t].data_ptr(), betas[t].data_ptr(),
-                                           _p(rm), _p(rv), _p(nbt), BN_MOMENTUM, BN_EPS, int(training),
-                                           coefs[t, 0].data_ptr(), coefs[t, 1].data_ptr(), coefs[t, 2].data_ptr(),
-                                           coefs[t, 3].data_ptr(), _stream()), 'senas_bn_finalize')
-        scale, shift = coefs[:, 2], coefs[:, 3]
-        gate = torch.ones((T, n, c), device=dev, dtype=torch.float32)
-        se_saved = []
-        for k, t in enumerate(se_ids):
-            m = (scale[t].double() * (stats[t, :, :, 0] / hw) + shift[t].double()).float()          # [n, c]
-            a1 = m @ w1s[k].t()
-            hdn = torch.relu(a1)
-            gt = torch.sigmoid(hdn @ w2s[k].t())
-            gate[t] = gt
-            se_saved.append((m, a1, hdn, gt))
-        wmix = mix.detach().float() if mix is not None else torch.ones(T, device=dev)
-        wg = wmix.view(T, 1, 1) * gate                                       # [T, n, c]
-        coef = (wg * scale.view(T, 1, c)).contiguous()
-        bias = (wg * shift.view(T, 1, c)).sum(0).contiguous()
-        y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL)
-        res = nhwc(residual) if residual is not None else None
-        zp = _lib.ptr_array([z.data_ptr() for z in zs])
-        coef_real = coef[real].contiguous() if nr != T else coef
-        _lib.check(L.senas_combine_fwd(n, hw, c, nr, zp, coef_real.data_ptr(), bias.data_ptr(), _p(res),
-                                       int(meta['relu']), y.data_ptr(), _stream()), 'senas_combine_fwd')
-        ctx.meta = meta
-        ctx.has_mix, ctx.has_res = mix is not None, residual is not None
-        ctx.nflat = len(flat)
-        ctx.se_saved = se_saved
-        ctx.save_for_backward(y, stats, coefs, gate, wmix, *zs, *w1s, *w2s)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        L = _lib.lib()
-        meta = ctx.meta
-        T, real, se_ids = meta['T'], meta['real'], meta['se']
-        nr, ns = len(real), len(se_ids)
-        n, c, h, w = meta['shape']
-        hw, M = h * w, float(n * h * w)
-        saved = ctx.saved_tensors
-        y, stats, coefs, gate, wmix = saved[:5]
-        zs = saved[5:5 + nr]
-        w1s, w2s = saved[5 + nr:5 + nr + ns], saved[5 + nr + ns:5 + nr + 2 * ns]
-        dev = y.device
-        dy = nhwc(dy)
-        relu = int(meta['relu'])
-        zp = _lib.ptr_array([z.data_ptr() for z in zs])
-        p1 = torch.zeros((n, c), device=dev, dtype=torch.float64)
-        p2r = torch.zeros((max(nr, 1), n, c), device=dev, dtype=torch.float64)
-        _lib.check(L.senas_combine_bwd_reduce(n, hw, c, nr, zp, dy.data_ptr(), y.data_ptr(), relu, p1.data_ptr(),
-                                              p2r.data_ptr(), _stream()), 'senas_combine_bwd_reduce')
-        p2 = torch.zeros((T, n, c), device=dev, dtype=torch.float64)
-        if nr:
-            p2[real] = p2r[:nr]
-        mean, invstd, scale, shift = (coefs[:, i].double() for i in range(4))       # [T, c]
-        g64, w64 = gate.double(), wmix.double()
-        Z = stats[..., 0]                                                            # [T, n, c]
-        # d loss / d (mix_t * gate_t): full-tensor dot product of ds with BN_t(z_t), per (n, c)
-        dot = scale.view(T, 1, c) * p2 + shift.view(T, 1, c) * p1.view(1, n, c)      # [T, n, c]
-        dmix = (g64 * dot).sum((1, 2)) if ctx.has_mix else None
-        e = torch.zeros((T, n, c), device=dev, dtype=torch.float64)
-        dw1s, dw2s = [], []
-        for k, t in enumerate(se_ids):
-            m, a1, hdn, gt = ctx.se_saved[k]
-            dg = (w64[t] * dot[t]).float()
-            da2 = dg * gt * (1 - gt)
-            dw2s.append(da2.t() @ hdn)
-            dh = da2 @ w2s[k]
-            da1 = dh * (a1 > 0).float()
-            dw1s.append(da1.t() @ m)
-            e[t] = (da1 @ w1s[k]).double() / hw
-        u1 = w64.view(T, 1, 1) * g64                                                 # [T, n, c]
-        s1 = (u1 * p1.view(1, n, c) + hw * e).sum(1)                                 # [T, c]
-        s2 = (u1 * p2 + e * Z).sum(1)
-        dbeta = s1
-        kk = s2 - mean * s1
-        dgamma = invstd * kk
-        A = scale.view(T, 1, c) * u1
-        if meta['training']:
-            B = (-scale * invstd * invstd * kk / M).view(T, 1, c).expand(T, n, c)
-            Cc = scale.view(T, 1, c) * e + (-scale * s1 / M + scale * invstd * invstd * mean * kk / M).view(T, 1, c)
-        else:
-            B = torch.zeros((T, n, c), device=dev, dtype=torch.float64)
-            Cc = scale.view(T, 1, c) * e
-        need = ctx.needs_input_grad
-        dzs = [None] * nr
-        ds_out = None
-        want_dz = [need[3 + k] for k in range(nr)]
-        if any(want_dz) or (ctx.has_res and need[2]):
-            for k in range(nr):
-                if want_dz[k]:
-                    dzs[k] = torch.empty_like(zs[k], memory_format=CL)
-            if ctx.has_res and need[2]:
-                ds_out = torch.empty_like(y, memory_format=CL)
-            Af = A[real].float().contiguous() if nr else A.float()
-            Bf = B[real].float().contiguous() if nr else Af
-            Cf = Cc[real].float().contiguous() if nr else Af
-            dzp = _lib.ptr_array([_p(d) for d in dzs])
-            _lib.check(L.senas_combine_bwd_apply(n, hw, c, nr, zp, dy.data_ptr(), y.data_ptr(), relu, Af.data_ptr(),
-                                                 Bf.data_ptr(), Cf.data_ptr(), dzp, _p(ds_out), _stream()),
-                       'senas_combine_bwd_apply')
-        grads = list(dzs)
-        grads += [dgamma[t].float() for t in range(T)]
-        grads += [dbeta[t].float() for t in range(T)]
-        grads += dw1s + dw2s
-        grads += [torch.zeros_like(p) for p in meta['passengers']]
-        assert len(grads) == ctx.nflat
-        return (None, dmix.float() if dmix is not None else None, ds_out) + tuple(grads)
-
-
 def bn_combine(terms, mix=None, residual=None, relu=False):
-    """Normalise every term with its own BatchNorm2d (train or eval mode as the module says), apply
-    SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
-    and optionally ReLU -- one read of every term, one write."""
-    T = len(terms)
-    if T == 0 or T > _lib.MAX_TERMS:
-        raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))
-    real = [t for t, tm in enumerate(terms) if tm.z is not None]
-    se_ids = [t for t, tm in enumerate(terms) if tm.se is not None]
-    ref = next((tm.z for tm in terms if tm.z is not None), residual)
-    if ref is None:
-        raise SenasHipError('bn_combine: needs at least one tensor term or a residual to fix the shape')
-    training = terms[0].bn.training
-    passengers = [p for tm in terms for p in tm.passengers]
-    meta = {
-        'T': T, 'real': real, 'se': se_ids, 'shape': tuple(ref.shape), 'training': training, 'relu': bool(relu),
-        'stats': [tm.stats for tm in terms],
-        'buffers': [(tm.bn.running_mean, tm.bn.running_var, tm.bn.num_batches_tracked) for tm in terms],
-        'passengers': passengers,
-    }
-    flat = [terms[t].z for t in real]
-    flat += [tm.bn.weight for tm in terms] + [tm.bn.bias for tm in terms]
-    flat += [terms[t].se.excitation[0].weight for t in se_ids] + [terms[t].se.excitation[2].weight for t in se_ids]
-    flat += passengers
-    return _BNCombine.apply(meta, mix, residual, *flat)
+    """See senas_amd.node.bn_combine (the fused cell node)."""
+    from .node import bn_combine as _impl
+    return _impl(terms, mix=mix, residual=residual, relu=relu)

@@ -1,0 +1,172 @@
+"""The fused cell node as one autograd Function over ``senas_node_fwd`` / ``senas_node_bwd``.
+
+y = act( sum_t mix_t * gate_t * BN_t(z_t) + residual )
+
+Replaces, per node: every candidate's BatchNorm2d (training statistics, running-stat update), the SE
+gate of se_conv_3, the alpha- and beta-weighted sums of MixedOp / Cell (search/cell.py:34-36,100-107),
+the two-op sum of BuildCell (models/senas_model.py:55-63), BasicBlock's residual add and the ReLU.
+Forward = 2 launches (prepare + one pass over the z_t), backward = 3 (+1 per 8 terms beyond 8).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import functional as F
+from ._lib import NodeDesc, SenasHipError
+from .arena import zeros64
+
+CL = torch.channels_last
+SE_MID_MAX = 16
+
+
+def _arr(ptrs):
+    return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def _desc(meta, gammas, betas, w1s, w2s, stats, mix):
+    T = meta['T']
+    n, c, h, w = meta['shape']
+    d = NodeDesc()
+    d.nterms, d.n, d.c, d.training, d.relu = T, n, c, int(meta['training']), int(meta['relu'])
+    d.hw, d.eps, d.momentum = h * w, F.BN_EPS, F.BN_MOMENTUM
+    se_pos = {t: k for k, t in enumerate(meta['se'])}
+    for t in range(T):
+        rm, rv, nbt = meta['buffers'][t]
+        d.stats[t] = stats[t].data_ptr() if stats[t] is not None else None
+        d.gamma[t], d.beta[t] = gammas[t].data_ptr(), betas[t].data_ptr()
+        d.running_mean[t] = rm.data_ptr() if rm is not None else None
+        d.running_var[t] = rv.data_ptr() if rv is not None else None
+        d.num_batches_tracked[t] = nbt.data_ptr() if nbt is not None else None
+        if t in se_pos:
+            k = se_pos[t]
+            d.se_w1[t], d.se_w2[t], d.se_mid[t] = w1s[k].data_ptr(), w2s[k].data_ptr(), w1s[k].shape[0]
+    d.mix = mix.data_ptr() if mix is not None else None
+    return d
+
+
+class _Node(torch.autograd.Function):
+    """flat = [z (real terms)..., gamma (all terms)..., beta (all terms)..., se_w1 (se terms)..., se_w2 ..., passengers...]"""
+
+    @staticmethod
+    def forward(ctx, meta, mix, residual, *flat):
+        L = _lib.lib()
+        T, real, se_ids = meta['T'], meta['real'], meta['se']
+        nr, ns = len(real), len(se_ids)
+        zs = [F.nhwc(z) for z in flat[:nr]]
+        gammas = [F._dev(g).contiguous() for g in flat[nr:nr + T]]
+        betas = [F._dev(b).contiguous() for b in flat[nr + T:nr + 2 * T]]
+        w1s = [w.contiguous() for w in flat[nr + 2 * T:nr + 2 * T + ns]]
+        w2s = [w.contiguous() for w in flat[nr + 2 * T + ns:nr + 2 * T + 2 * ns]]
+        n, c, h, w = meta['shape']
+        training = meta['training']
+        dev = gammas[0].device
+        for wt in w1s:
+            if wt.shape[0] > SE_MID_MAX:
+                raise SenasHipError('SE hidden width %d > %d' % (wt.shape[0], SE_MID_MAX))
+        zfull, stats = [None] * T, [None] * T
+        for k, t in enumerate(real):
+            z = zs[k]
+            if tuple(z.shape) != (n, c, h, w):
+                raise SenasHipError('node terms disagree in shape: %s vs %s' % (tuple(z.shape), (n, c, h, w)))
+            zfull[t] = z
+            st = meta['stats'][t]
+            if st is None and (training or t in se_ids):
+                st = F.chan_stats(z)
+            stats[t] = st
+        mixc = mix.detach().float().contiguous() if mix is not None else None
+        d = _desc(meta, gammas, betas, w1s, w2s, stats, mixc)
+        coefs = torch.empty((T, 4, c), device=dev, dtype=torch.float32)
+        gate = torch.empty((T, n, c), device=dev, dtype=torch.float32)
+        scratch = torch.empty((2, T, n, c), device=dev, dtype=torch.float32)
+        se_m = torch.empty((T, n, c), device=dev, dtype=torch.float32) if ns else None
+        se_a1 = torch.empty((T, n, SE_MID_MAX), device=dev, dtype=torch.float32) if ns else None
+        y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL)
+        res = F.nhwc(residual) if residual is not None else None
+        zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
+        _lib.check(L.senas_node_fwd(C.byref(d), zp, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
+                                    scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._stream()),
+                   'senas_node_fwd')
+        ctx.meta = meta
+        ctx.has_mix, ctx.has_res, ctx.nflat = mix is not None, residual is not None, len(flat)
+        ctx.stats = stats
+        ctx.se_buf = (se_m, se_a1)
+        ctx.save_for_backward(y, coefs, gate, mixc if mixc is not None else coefs, *zs, *gammas, *betas, *w1s, *w2s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        meta = ctx.meta
+        T, real, se_ids = meta['T'], meta['real'], meta['se']
+        nr, ns = len(real), len(se_ids)
+        n, c, h, w = meta['shape']
+        saved = ctx.saved_tensors
+        y, coefs, gate, mixc = saved[:4]
+        zs = saved[4:4 + nr]
+        gammas, betas = saved[4 + nr:4 + nr + T], saved[4 + nr + T:4 + nr + 2 * T]
+        w1s = saved[4 + nr + 2 * T:4 + nr + 2 * T + ns]
+        w2s = saved[4 + nr + 2 * T + ns:4 + nr + 2 * T + 2 * ns]
+        dev = y.device
+        dy = F.nhwc(dy)
+        mix = mixc if ctx.has_mix else None
+        d = _desc(meta, gammas, betas, w1s, w2s, ctx.stats, mix)
+        zfull = [None] * T
+        for k, t in enumerate(real):
+            zfull[t] = zs[k]
+        need = ctx.needs_input_grad
+        dzs = [None] * T
+        for k, t in enumerate(real):
+            if need[3 + k]:
+                dzs[t] = torch.empty_like(zs[k], memory_format=CL)
+        ds_out = torch.empty_like(y, memory_format=CL) if (ctx.has_res and need[2]) else None
+        p = zeros64((T + 1, n, c), dev)
+        dgb = torch.empty((2, T, c), device=dev, dtype=torch.float32)
+        dmix = torch.empty(T, device=dev, dtype=torch.float32) if ctx.has_mix else None
+        abk = torch.empty((3, T, n, c), device=dev, dtype=torch.float32)
+        dw1s = [torch.empty_like(wt) for wt in w1s]
+        dw2s = [torch.empty_like(wt) for wt in w2s]
+        se_pos = {t: k for k, t in enumerate(se_ids)}
+        dw1p = _arr([dw1s[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
+        dw2p = _arr([dw2s[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
+        zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
+        dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
+        se_m, se_a1 = ctx.se_buf
+        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
+                                    F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(), dgb[0].data_ptr(),
+                                    dgb[1].data_ptr(), F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),
+                                    F._stream()), 'senas_node_bwd')
+        grads = [dzs[t] for t in real]
+        grads += [dgb[0, t] for t in range(T)] + [dgb[1, t] for t in range(T)]
+        grads += dw1s + dw2s
+        grads += [torch.zeros_like(q) for q in meta['passengers']]
+        assert len(grads) == ctx.nflat
+        return (None, dmix, ds_out) + tuple(grads)
+
+
+def bn_combine(terms, mix=None, residual=None, relu=False):
+    """Normalise every term with its own BatchNorm2d (train or eval mode as the module says), apply
+    SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
+    and optionally ReLU -- one read of every term, one write."""
+    T = len(terms)
+    if T == 0 or T > _lib.MAX_TERMS:
+        raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))
+    real = [t for t, tm in enumerate(terms) if tm.z is not None]
+    se_ids = [t for t, tm in enumerate(terms) if tm.se is not None]
+    ref = next((tm.z for tm in terms if tm.z is not None), residual)
+    if ref is None:
+        raise SenasHipError('bn_combine: needs at least one tensor term or a residual to fix the shape')
+    if ref.shape[1] > 256:
+        raise SenasHipError('bn_combine: more than 256 channels is not on the SENAS path')
+    passengers = [p for tm in terms for p in tm.passengers]
+    meta = {
+        'T': T, 'real': real, 'se': se_ids, 'shape': tuple(ref.shape), 'training': terms[0].bn.training, 'relu': bool(relu),
+        'stats': [tm.stats for tm in terms],
+        'buffers': [(tm.bn.running_mean, tm.bn.running_var, tm.bn.num_batches_tracked) for tm in terms],
+        'passengers': passengers,
+    }
+    flat = [terms[t].z for t in real]
+    flat += [tm.bn.weight for tm in terms] + [tm.bn.bias for tm in terms]
+    flat += [terms[t].se.excitation[0].weight for t in se_ids] + [terms[t].se.excitation[2].weight for t in se_ids]
+    flat += passengers
+    return _Node.apply(meta, mix, residual, *flat)

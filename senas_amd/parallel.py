@@ -111,6 +111,15 @@ class GradAllReducer(object):
         self.flat.mul_(1.0 / self.world)
 
 
+    def reduce_all(self):
+        """Non-overlapped form (gradients produced by a replayed HIP graph): one all-reduce of the whole
+        flat buffer on the current stream, then the mean."""
+        if self.world == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / self.world)
+
+
 def broadcast_parameters(module, src=0, process_group=None):
     """Start every replica from rank ``src``'s parameters and buffers (one flat broadcast each)."""
     tensors = [t for t in list(module.parameters()) + list(module.buffers())]

@@ -1,0 +1,79 @@
+"""Stream-ordered train / search steps (the step loop of
+experiments/train_model.py:264-305 and experiments/search_arc.py:252-299, without the per-step host
+syncs), with the launch-bound part -- forward, loss, backward: ~10^3 short kernels -- captured once in
+a HIP graph and replayed.
+
+What is inside the graph: zero the flat gradient buffer, forward, criterion, backward (gradients land
+in the flat buffer the parameters' ``.grad`` view).  What stays eager: the gradient all-reduce (RCCL
+is never called inside a capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
+"""
+import torch
+
+from .arena import reset_arena
+from .parallel import GradAllReducer
+
+
+class GraphedForwardBackward(object):
+    """Captures ``loss = criterion(model(x), y); loss.backward()`` on static input buffers."""
+
+    def __init__(self, model, criterion, x, y, reducer, warmup=2, use_graph=True):
+        self.model, self.criterion, self.reducer = model, criterion, reducer
+        self.x, self.y = x, y                      # static buffers; refill with .copy_() between steps
+        self.loss = None
+        self.graph = None
+        if use_graph:
+            self._capture(warmup)
+
+    def _eager(self):
+        self.reducer.zero_grad()
+        loss = self.criterion(self.model(self.x), self.y)
+        loss.backward()
+        return loss.detach()
+
+    def _capture(self, warmup):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        was = self.reducer.enabled
+        self.reducer.enabled = False               # hooks must not launch collectives while capturing
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        reset_arena()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.loss = self._eager()
+        reset_arena()
+        self.graph = graph
+        self._hooks_enabled = was
+
+    def __call__(self):
+        if self.graph is None:
+            self.loss = self._eager()
+        else:
+            self.graph.replay()
+        return self.loss
+
+
+class TrainStep(object):
+    """One optimisation step of the derived network: graph(fwd+loss+bwd) -> all-reduce -> clip -> SGD."""
+
+    def __init__(self, model, criterion, optimizer, x, y, world_size=1, grad_clip=5.0, use_graph=True, num_buckets=2):
+        self.params = [p for p in model.parameters()]
+        self.reducer = GradAllReducer(self.params, world_size=world_size, num_buckets=num_buckets)
+        self.optimizer, self.grad_clip, self.world = optimizer, grad_clip, world_size
+        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
+        self.graphed = self.fb.graph is not None
+
+    def __call__(self):
+        loss = self.fb()
+        if self.world > 1:
+            if self.graphed:
+                self.reducer.reduce_all()          # gradients came out of the graph: reduce them now
+            else:
+                self.reducer.finish()
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        self.optimizer.step()
+        return loss

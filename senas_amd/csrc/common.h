@@ -72,6 +72,17 @@ bool mfma_wgrad_ok(const WgradGeom& g);
 int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, float* ws, int i_relu, int g_relu,
                       hipStream_t st);
 
+// wgrad_lds.hip (stride-1 "same" weight gradient, persistent, both operands in LDS); ws zeroed by the caller
+bool lds_wgrad_ok(const WgradGeom& g);
+int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, hipStream_t st);
+void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st);
+
+// conv_lds.hip (stride-1 "same" convolutions with the input window staged in LDS)
+bool lds_gather_ok(const GatherGeom& g);
+template <bool TG>
+int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
+                      const float* mask, double* stats, hipStream_t st);
+
 // V consecutive floats (V == 4: one 16-byte access; the caller guarantees 16-byte alignment)
 template <int V>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[V]) {

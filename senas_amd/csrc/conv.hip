@@ -322,6 +322,10 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    if (!g->transposed && lds_gather_ok(gg)) {
+        launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st);
+        return launch_lds_gather<false>(gg, x, wp, y, in_relu, nullptr, stats, st);
+    }
     if (mfma_gather_ok(gg, g->transposed != 0)) {
         if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st); return launch_mfma_gather<false>(gg, x, wp, y, in_relu, nullptr, stats, st); }
         launch_pack_mfma(w, wp, g->ci, g->co, taps, 0, st);
@@ -359,6 +363,10 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     SENAS_REQUIRE(ws, "conv2d_bwd_data: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
+    if (!g->transposed && lds_gather_ok(gg)) {
+        launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st);
+        return launch_lds_gather<true>(gg, dy, wp, dx, 0, mask, nullptr, st);
+    }
     if (mfma_gather_ok(gg, g->transposed == 0)) {
         if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st); return launch_mfma_gather<true>(gg, dy, wp, dx, 0, mask, nullptr, st); }
         launch_pack_mfma(w, wp, g->ci, g->co, taps, 1, st);
@@ -400,6 +408,16 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_kernel<3>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
         else hipLaunchKernelGGL((dwconv_wgrad_kernel<5>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
         return launch_status("dwconv_wgrad");
+    }
+    if (!g->transposed && lds_wgrad_ok(wg)) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        float* wsp = reinterpret_cast<float*>(ws);
+        hipError_t e0 = hipMemsetAsync(wsp, 0, (size_t)taps * wg.A * 32 * sizeof(float), st);
+        if (e0 != hipSuccess) { set_error("memset wgrad ws", e0); return SENAS_ELAUNCH; }
+        const int rc = launch_lds_wgrad(wg, I, G, wsp, i_relu, st);
+        if (rc != SENAS_OK) return rc;
+        launch_unpack_wgrad(wsp, dw, wg.A, wg.B, taps, st);
+        return launch_status("wgrad_lds unpack");
     }
     if (mfma_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");

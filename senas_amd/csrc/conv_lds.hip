@@ -1,0 +1,218 @@
+// Stride-1 dense convolution (forward, and data-gradient of a stride-1 conv) with the input tile
+// staged in LDS -- the main kernel of the derived network's 5x5 dilated / 3x3 layers.
+//
+// Why LDS here: the direct-global kernel (conv_mfma.hip) re-reads every input pixel once per tap as
+// 16-byte fragments, 32 cache lines per wave-instruction, and ends up L1/TA-bound at ~30% of the
+// fp32-MFMA rate.  Here a block loads its (8 + 2*halo) x (32 + 2*halo) input window ONCE, in full
+// 64-byte runs (ReLU applied on the way in, borders zero-filled so the tap loop has no bounds
+// checks), and all k*k taps read their A fragments from LDS with conflict-free ds_read_b128.
+//
+// Tile: 8 x 32 output pixels per 256-thread block; wave w owns rows 2w, 2w+1 (two 32-pixel MFMA
+// sub-tiles).  Channels go through LDS 16 at a time (pixel stride 80 B = 64 B data + 16 B pad: the 16
+// lanes of a ds_read_b128 group land on 16 distinct 4-bank slots), so the window costs
+// 880 px * 80 B = 69 KiB for 5x5 dilation 3 -- two blocks per CU, one loading while the other computes.
+// B fragments (weights) stream from the packed image in L2, 1 KiB per wave-instruction.
+#include "common.h"
+
+namespace senas {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+namespace {
+
+constexpr int TH = 8, TW = 32, CH = 16, PST = 20;     // PST: pixel stride in floats (16 data + 4 pad)
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
+
+struct Frag {
+    float4 a[2][2];      // [channel group within the pass][sub-tile]
+    float4 b[2];
+};
+
+}  // namespace
+
+// grid = (tiles_x, tiles_y, n * co_tiles); dynamic LDS = tile_h * tile_w * PST floats
+template <bool TG>
+__global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
+                                                       const float* __restrict__ wp, float* __restrict__ out,
+                                                       int in_relu, const float* __restrict__ mask,
+                                                       double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.z % g.n, cot = blockIdx.z / g.n;
+    const int co = cot * 32 + r;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int halo = g.pad;                              // = dil * (k / 2) on this path
+    const int tile_w = TW + 2 * halo, tile_h = TH + 2 * halo;
+    const int ngroups = g.cin >> 3, npass = g.cin / CH;
+    const int taps = g.kh * g.kw;
+    wp += (size_t)cot * taps * ngroups * 256 + lane * 4;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
+
+    // LDS offset (in 16-byte units, so the accesses are provably aligned -> ds_read_b128) of this lane's
+    // pixel for tap (0,0), channel chunk h, sub-tile m
+    constexpr int P4 = PST / 4;
+    float4* lds4 = reinterpret_cast<float4*>(lds);
+    const int lbase0 = ((2 * wave) * tile_w + r) * P4 + h;
+    const int lbase1 = lbase0 + tile_w * P4;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        __syncthreads();                                 // previous pass's readers are done
+        // ---- stage the window: thread = one 16-byte piece; 4 consecutive threads = one pixel's 64 B
+        const float* src = in + (size_t)n * g.hin * g.win * g.cin + pass * CH;
+        const int pieces = tile_h * tile_w * 4;
+        for (int base = 0; base < pieces; base += 256 * 4) {       // 4 loads in flight per thread
+            float4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + threadIdx.x;
+                const int pix = idx >> 2, q = idx & 3;
+                const int ty = pix / tile_w, tx = pix - ty * tile_w;
+                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+                const bool inb = idx < pieces && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+                dst[u] = idx < pieces ? pix * P4 + q : -1;
+                v[u] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.win + ix) * g.cin + q * 4 : 0));
+                if (!inb) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in_relu) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
+                if (dst[u] >= 0) lds4[dst[u]] = v[u];
+            }
+        }
+        __syncthreads();
+
+        // ---- taps, software-pipelined over two alternating fragment sets (no register copies):
+        // while tap t's 16 MFMAs issue, tap t+1's A fragments (LDS) and B fragments (L2) are in flight
+        auto tap_ptrs = [&](int t, int& toff, const float*& wt) {
+            const int ky = t / g.kw, kx = t - ky * g.kw;
+            // plain gather: window row = oy_local + ky*d ; transposed (stride 1): oy_local + (k-1-ky)*d
+            const int dy = (TG ? (g.kh - 1 - ky) : ky) * g.dil, dx = (TG ? (g.kw - 1 - kx) : kx) * g.dil;
+            toff = (dy * tile_w + dx) * P4;
+            wt = wp + ((size_t)t * ngroups + pass * 2) * 256;
+        };
+        auto load_a = [&](int toff, Frag& f) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                f.a[c2][0] = lds4[lbase0 + toff + c2 * 2];
+                f.a[c2][1] = lds4[lbase1 + toff + c2 * 2];
+            }
+        };
+        auto load_b = [&](const float* wt, Frag& f) {
+            f.b[0] = *reinterpret_cast<const float4*>(wt);
+            f.b[1] = *reinterpret_cast<const float4*>(wt + 256);
+        };
+        // One tap = 16 MFMAs (1024 cycles).  hipcc waits vmcnt(0) in front of the first MFMA that needs a
+        // weight fragment, so (a) both fragments of the tap are consumed by the first four MFMAs, while only
+        // they are outstanding, and (b) the NEXT tap's weight loads are issued right after those four
+        // (pinned by sched_barrier): by the time the next tap starts they have had ~768 cycles to land.
+        auto step = [&](const Frag& cur, Frag& nxt, bool more, int toff_n, const float* wt_n) {
+            if (more) load_a(toff_n, nxt);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = mfma32(cur.a[c2][m].x, cur.b[c2].x, acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_b(wt_n, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m] = mfma32(cur.a[c2][m].y, cur.b[c2].y, acc[m]);
+                    acc[m] = mfma32(cur.a[c2][m].z, cur.b[c2].z, acc[m]);
+                    acc[m] = mfma32(cur.a[c2][m].w, cur.b[c2].w, acc[m]);
+                }
+        };
+        Frag f0, f1;
+        int toff;
+        const float* wt;
+        tap_ptrs(0, toff, wt);
+        load_b(wt, f0);
+        load_a(toff, f0);
+        for (int t = 0;;) {
+            bool more = t + 1 < taps;
+            if (more) tap_ptrs(t + 1, toff, wt);
+            step(f0, f1, more, toff, wt);
+            if (++t >= taps) break;
+            more = t + 1 < taps;
+            if (more) tap_ptrs(t + 1, toff, wt);
+            step(f1, f0, more, toff, wt);
+            if (++t >= taps) break;
+        }
+    }
+
+    // ---- epilogue: lane = output channel, register v = pixel (row 2*wave + m, column acc_row(v, h))
+    const bool cok = co < g.cout;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int oy = oy0 + 2 * wave + m;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ox = ox0 + acc_row(v, h);
+            float val = acc[m][v];
+            if (oy < g.hout && ox < g.wout && cok) {
+                const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
+                if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
+                out[o] = val;
+                s += val;
+                q += (double)val * val;
+            }
+        }
+    }
+    if (stats != nullptr) {                              // block-level reduction: 2 atomics per channel per block
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);    // [4 waves][32 channels][2]
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (h == 0) { red[(wave * 32 + r) * 2] = s; red[(wave * 32 + r) * 2 + 1] = q; }
+        __syncthreads();
+        if (wave == 0 && h == 0 && cok) {
+            for (int w = 1; w < 4; ++w) { s += red[(w * 32 + r) * 2]; q += red[(w * 32 + r) * 2 + 1]; }
+            double* st = stats + ((size_t)n * g.cout + co) * 2;
+            atomicAdd(st, s);
+            atomicAdd(st + 1, q);
+        }
+    }
+}
+
+bool lds_gather_ok(const GatherGeom& g) {
+    // stride 1, "same" padding, 16-channel passes, maps at least one tile wide
+    if (g.stride != 1 || g.cin % CH != 0) return false;
+    if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hout != g.hin || g.wout != g.win) return false;
+    if (g.wout < TW || g.hout < TH) return false;
+    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    return bytes <= 150 * 1024 && (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
+}
+
+template <bool TG>
+int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
+                      const float* mask, double* stats, hipStream_t st) {
+    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (bytes > 64 * 1024 && !attr_set[TG ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
+        attr_set[TG ? 1 : 0] = true;
+    }
+    dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
+    hipLaunchKernelGGL((conv_lds_kernel<TG>), grid, dim3(256), bytes, st, g, in, wp, out, in_relu, mask, stats);
+    return launch_status("conv_lds");
+}
+
+template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);
+template int launch_lds_gather<true>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);
+
+}  // namespace senas

@@ -468,6 +468,11 @@ void launch_pack_mfma(const float* w, float* wp, int d0, int d1, int taps, int s
     hipLaunchKernelGGL(pack_weights_mfma_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, d0, d1, taps, swap);
 }
 
+void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st) {
+    const int n = A * B * taps;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, dw, A, B, taps);
+}
+
 bool mfma_wgrad_ok(const WgradGeom& g) {
     if (g.B > 32 || (long)g.n * g.hi * g.wi * g.A >= 0x7fffffffL) return false;
     return g.A % 8 == 0 || g.kh * g.kw * g.A <= 160;

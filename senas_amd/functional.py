@@ -142,6 +142,7 @@ class _Conv2d(torch.autograd.Function):
                                           ws.data_ptr(), _stream()), 'senas_conv2d_fwd')
         ctx.save_for_backward(x, w)
         ctx.g, ctx.in_relu = g, int(in_relu)
+        ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
         if stats is not None:
             ctx.mark_non_differentiable(stats)
         return y, stats
@@ -150,6 +151,8 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy, _ds):
         x, w = ctx.saved_tensors
         g, L = ctx.g, _lib.lib()
+        if dy is None:
+            return (None,) * 10
         dy = nhwc(dy)
         ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
         dx = dw = None

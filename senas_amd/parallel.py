@@ -1,80 +1,112 @@
 """Data parallelism for the search / train step: one process per GPU, weight gradients all-reduced
-with RCCL over xGMI (``torch.distributed`` backend "nccl" on ROCm), overlapped with backward.
+with RCCL over xGMI (``torch.distributed`` backend "nccl" on ROCm).
 
 The reference only has ``nn.DataParallel`` (train_model.py:135-137; the search-phase branch is
 broken).  Semantics kept: the batch is split across replicas, batch-norm
 statistics stay per replica, gradients are averaged.  Architecture gradients (246 scalars) ride in
-the same buckets -- both optimizers step them, so they must not diverge between ranks.
+the same flat buffer -- both optimizers step them, so they must not diverge between ranks.
 
-Mechanics: every parameter's ``.grad`` is a view into one flat fp32 buffer, cut into a few
-contiguous buckets in reverse registration order (the order backward produces gradients).  A
-post-accumulate hook counts the bucket's gradients; when the last one lands the bucket is
-all-reduced asynchronously on a side stream while backward keeps running on the compute stream.
-Message size is ~8 MB (2.2 M floats) in total: latency-bound over xGMI, so few large buckets.
+Two modes:
+  * ``overlap=False`` (default; what a HIP-graph-replayed backward needs): after backward the
+    gradients are gathered into one flat fp32 buffer by a multi-tensor copy, all-reduced in ONE call
+    (8 MB: latency-bound over xGMI, so one message), averaged, and ``p.grad`` is pointed at the
+    buffer's views.  On one GPU nothing is copied at all.
+  * ``overlap=True`` (eager backward): ``p.grad`` are views of the flat buffer from the start, cut
+    into a few buckets in reverse registration order (the order backward produces gradients); a
+    post-accumulate hook launches a bucket's all-reduce on a side stream as soon as its last gradient
+    has landed, while backward keeps running on the compute stream.
 """
 import torch
 import torch.distributed as dist
 
 
+def _unique(params):
+    seen, out = set(), []
+    for p in params:
+        if p.requires_grad and id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
+
+
 class GradAllReducer(object):
-    def __init__(self, params, world_size=None, num_buckets=2, process_group=None):
-        self.params = [p for p in params if p.requires_grad]
-        seen, uniq = set(), []
-        for p in self.params:
-            if id(p) not in seen:
-                seen.add(id(p))
-                uniq.append(p)
-        self.params = uniq
+    def __init__(self, params, world_size=None, num_buckets=2, process_group=None, overlap=False):
+        self.params = _unique(params)
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
-        dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        # gradients arrive roughly in reverse registration order: bucket 0 = last parameters
-        order = list(reversed(self.params))
-        per = (total + num_buckets - 1) // max(1, num_buckets)
-        self.buckets, self._bucket_of = [], {}
-        off, cur, cur_start = 0, [], 0
-        self._offsets = {}
-        for p in order:
-            n = p.numel()
-            self._offsets[id(p)] = off
-            p.grad = self.flat[off:off + n].view_as(p)
-            cur.append(p)
-            off += n
-            if off - cur_start >= per or p is order[-1]:
-                b = {'lo': cur_start, 'hi': off, 'count': len(cur), 'ready': 0, 'work': None}
-                for q in cur:
-                    self._bucket_of[id(q)] = len(self.buckets)
-                self.buckets.append(b)
-                cur, cur_start = [], off
-        self.cuda = dev.type == 'cuda'
-        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.overlap = bool(overlap) and self.world > 1
         self.enabled = True
+        dev = self.params[0].device
+        self.cuda = dev.type == 'cuda'
+        self.flat, self.views, self.buckets = None, None, []
+        if self.world > 1:
+            order = list(reversed(self.params))          # gradients arrive roughly in reverse registration order
+            total = sum(p.numel() for p in order)
+            self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            self._order, self._offsets, off = order, {}, 0
+            for p in order:
+                self._offsets[id(p)] = off
+                off += p.numel()
+            self.views = [self.flat[self._offsets[id(p)]:self._offsets[id(p)] + p.numel()].view_as(p) for p in order]
+        if self.overlap:
+            per = (self.flat.numel() + num_buckets - 1) // max(1, num_buckets)
+            self._bucket_of, cur, start = {}, [], 0
+            for p in self._order:
+                cur.append(p)
+                end = self._offsets[id(p)] + p.numel()
+                if end - start >= per or p is self._order[-1]:
+                    for q in cur:
+                        self._bucket_of[id(q)] = len(self.buckets)
+                    self.buckets.append({'lo': start, 'hi': end, 'count': len(cur), 'ready': 0, 'work': None})
+                    cur, start = [], end
+            self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+            self._attach()
 
-    # --------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------ common
     def zero_grad(self):
-        """Replaces optimizer.zero_grad(): one memset of the flat buffer; .grad views stay attached."""
-        self.flat.zero_()
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self._view_ptr(p):
-                self._reattach(p)
-        for b in self.buckets:
-            b['ready'], b['work'] = 0, None
+        """Replaces optimizer.zero_grad()."""
+        if self.overlap:
+            self.flat.zero_()
+            self._attach()
+            for b in self.buckets:
+                b['ready'], b['work'] = 0, None
+        else:
+            for p in self.params:
+                p.grad = None
 
-    def _view_ptr(self, p):
-        return self.flat.data_ptr() + self._offset(p) * 4
+    def finish(self):
+        """Call after backward; leaves the averaged gradients in ``p.grad``."""
+        if self.world == 1:
+            return
+        if self.overlap:
+            self._finish_overlapped()
+        else:
+            self.reduce_all()
 
-    def _offset(self, p):
-        return self._offsets[id(p)]
+    # ------------------------------------------------------------------ one-shot mode
+    def reduce_all(self):
+        if self.world == 1:
+            return
+        have = [(v, p.grad) for v, p in zip(self.views, self._order) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for v, p in zip(self.views, self._order) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v in missing:                                 # a parameter unused this step contributes zeros
+            v.zero_()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / self.world)
+        for v, p in zip(self.views, self._order):
+            p.grad = v
 
-    def _reattach(self, p):
-        off = self._offset(p)
-        p.grad = self.flat[off:off + p.numel()].view_as(p)
+    # ------------------------------------------------------------------ overlapped mode
+    def _attach(self):
+        for v, p in zip(self.views, self._order):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def _on_grad(self, p):
-        if not self.enabled or self.world == 1:
+        if not self.enabled:
             return
         b = self.buckets[self._bucket_of[id(p)]]
         b['ready'] += 1
@@ -92,13 +124,9 @@ class GradAllReducer(object):
         else:
             b['work'] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self):
-        """Call after backward: waits for the in-flight buckets (launching any that never filled,
-        e.g. parameters without a gradient this step) and turns sums into means."""
-        if self.world == 1:
-            return
+    def _finish_overlapped(self):
         for b in self.buckets:
-            if b['work'] is None:
+            if b['work'] is None:                         # never filled (parameters without a gradient this step)
                 self._launch(b)
         for b in self.buckets:
             if self.cuda:
@@ -111,24 +139,14 @@ class GradAllReducer(object):
         self.flat.mul_(1.0 / self.world)
 
 
-    def reduce_all(self):
-        """Non-overlapped form (gradients produced by a replayed HIP graph): one all-reduce of the whole
-        flat buffer on the current stream, then the mean."""
-        if self.world == 1:
-            return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / self.world)
-
-
 def broadcast_parameters(module, src=0, process_group=None):
-    """Start every replica from rank ``src``'s parameters and buffers (one flat broadcast each)."""
-    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    """Start every replica from rank ``src``'s parameters and buffers (one flat broadcast per dtype)."""
     seen, uniq = set(), []
-    for t in tensors:
+    for t in list(module.parameters()) + list(module.buffers()):
         if t.data_ptr() not in seen:
             seen.add(t.data_ptr())
             uniq.append(t)
-    for dtype in {t.dtype for t in uniq}:
+    for dtype in sorted({t.dtype for t in uniq}, key=str):
         group = [t for t in uniq if t.dtype == dtype]
         flat = torch.cat([t.detach().reshape(-1) for t in group])
         dist.broadcast(flat, src=src, group=process_group)

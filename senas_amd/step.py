@@ -3,9 +3,9 @@ experiments/train_model.py:264-305 and experiments/search_arc.py:252-299, withou
 syncs), with the launch-bound part -- forward, loss, backward: ~10^3 short kernels -- captured once in
 a HIP graph and replayed.
 
-What is inside the graph: zero the flat gradient buffer, forward, criterion, backward (gradients land
-in the flat buffer the parameters' ``.grad`` view).  What stays eager: the gradient all-reduce (RCCL
-is never called inside a capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
+What is inside the graph: forward, criterion, backward (gradients are written to tensors owned by the
+graph's memory pool).  What stays eager: the gradient all-reduce (RCCL is never called inside a
+capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
 """
 import torch
 
@@ -21,6 +21,7 @@ class GraphedForwardBackward(object):
         self.x, self.y = x, y                      # static buffers; refill with .copy_() between steps
         self.loss = None
         self.graph = None
+        self.graph_grads = None
         if use_graph:
             self._capture(warmup)
 
@@ -31,10 +32,10 @@ class GraphedForwardBackward(object):
         return loss.detach()
 
     def _capture(self, warmup):
+        if self.reducer.overlap:
+            raise ValueError('a graph-replayed backward cannot drive gradient hooks; use overlap=False')
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        was = self.reducer.enabled
-        self.reducer.enabled = False               # hooks must not launch collectives while capturing
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._eager()
@@ -46,33 +47,32 @@ class GraphedForwardBackward(object):
             self.loss = self._eager()
         reset_arena()
         self.graph = graph
-        self._hooks_enabled = was
+        self.graph_grads = [p.grad for p in self.reducer.params]     # written in place by every replay
 
     def __call__(self):
         if self.graph is None:
             self.loss = self._eager()
         else:
             self.graph.replay()
+            if self.reducer.world > 1:             # reduce_all() re-points p.grad at the flat buffer
+                for p, g in zip(self.reducer.params, self.graph_grads):
+                    p.grad = g
         return self.loss
 
 
 class TrainStep(object):
     """One optimisation step of the derived network: graph(fwd+loss+bwd) -> all-reduce -> clip -> SGD."""
 
-    def __init__(self, model, criterion, optimizer, x, y, world_size=1, grad_clip=5.0, use_graph=True, num_buckets=2):
+    def __init__(self, model, criterion, optimizer, x, y, world_size=1, grad_clip=5.0, use_graph=True, overlap=False):
         self.params = [p for p in model.parameters()]
-        self.reducer = GradAllReducer(self.params, world_size=world_size, num_buckets=num_buckets)
+        self.reducer = GradAllReducer(self.params, world_size=world_size, overlap=overlap and not use_graph)
         self.optimizer, self.grad_clip, self.world = optimizer, grad_clip, world_size
         self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
         self.graphed = self.fb.graph is not None
 
     def __call__(self):
         loss = self.fb()
-        if self.world > 1:
-            if self.graphed:
-                self.reducer.reduce_all()          # gradients came out of the graph: reduce them now
-            else:
-                self.reducer.finish()
+        self.reducer.finish()
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()

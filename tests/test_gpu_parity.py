@@ -332,3 +332,47 @@ def test_linearity_and_shapes_at_baseline_size():
     SegmentationLosses('dice_ce')(out, y).backward()
     for k, p in net.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+
+
+# ------------------------------------------------------------------ convolution kernels at sizes that reach the MFMA / LDS paths
+_CONV_CASES = [
+    # (n, ci, co, h, w, k, stride, dil, transposed, relu)
+    (2, 32, 32, 40, 64, 5, 1, 3, False, False),     # LDS window kernel, ragged tile rows (40 = 5 x 8)
+    (2, 32, 32, 36, 70, 5, 1, 2, False, True),      # ragged both ways + ReLU on load
+    (1, 128, 32, 16, 32, 3, 1, 1, False, True),     # 8 channel passes (ShrinkBlock shape)
+    (2, 24, 32, 24, 40, 3, 1, 1, False, False),     # c_in = 24: not a 16-channel multiple -> direct-global MFMA
+    (2, 32, 8, 32, 32, 5, 1, 3, False, False),      # supernet width (8 output channels)
+    (2, 32, 32, 32, 48, 5, 2, 3, False, False),     # stride-2 conv: dgrad runs the 4-phase transposed gather
+    (2, 32, 32, 16, 24, 5, 2, 2, True, False),      # ConvTranspose2d (UP ops), even dilation: 3 empty phases
+    (2, 32, 32, 16, 24, 3, 2, 1, True, True),
+    (3, 1, 32, 40, 40, 7, 1, 1, False, False),      # stem: small-c_in weight gradient
+    (2, 32, 2, 24, 24, 3, 1, 1, False, True),       # segmentation head (2 classes)
+    (2, 8, 8, 20, 20, 5, 1, 3, False, False),       # inner supernet edge
+]
+
+
+@pytest.mark.parametrize('case', _CONV_CASES, ids=lambda c: 'n%d_%dto%d_%dx%d_k%ds%dd%d%s%s' % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], '_T' if c[8] else '', '_relu' if c[9] else ''))
+def test_conv_kernels_vs_oracle(case):
+    """Forward, data gradient, weight gradient and producer-side statistics of one convolution launch
+    against the oracle's leaf arithmetic (torch CPU conv / conv_transpose)."""
+    from oracle import senas_ref as R
+    from senas_amd import functional as F
+    n, ci, co, h, w, k, stride, dil, tr, relu = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=g) * (1.0 / (ci * k * k) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = R.conv(torch.relu(xr) if relu else xr, wr, k, stride, dil, tr)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xg, wg = x.to(dev()).requires_grad_(True), wt.to(dev()).requires_grad_(True)
+    pad = (k // 2) * dil
+    y, st = F.conv2d(xg, wg, stride=stride, pad=pad, dil=dil, transposed=tr, out_pad=stride - 1 if tr else 0, in_relu=relu,
+                     want_stats=True)
+    close(y, ref.detach().numpy(), 'y', rel=2e-5)
+    y.backward(gy.to(dev()))
+    close(xg.grad, xr.grad.numpy(), 'dx', rel=2e-5)
+    close(wg.grad, wr.grad.numpy(), 'dw', rel=5e-5)
+    ref64 = ref.detach().double()
+    exp = torch.stack([ref64.sum((2, 3)), (ref64 ** 2).sum((2, 3))], -1)
+    close(st.float(), exp.float().numpy(), 'stats', rel=2e-5)

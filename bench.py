@@ -211,7 +211,7 @@ def main():
 
     log('train step: %.2f ms/step, %.2f images/s' % (1e3 * elapsed / args.steps, value))
     if rank == 0 and world == 1 and args.search_steps > 0:
-        out['search_step'] = bench_search(dev, args.search_steps)
+        out["search_step"] = bench_search(dev, args.search_steps, use_graph=not args.no_graph)
         log('search step: %s' % json.dumps(out['search_step']))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.set_num_threads(host_threads())
@@ -227,30 +227,26 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_search(dev, steps):
+def bench_search(dev, steps, use_graph=True):
     """Supernet search step (BASELINE configs[2]): arch step on 4 validation images (Adam) + weight step on
     4 train images (SGD, clip 5) -- experiments/search_arc.py:252-299.  images/sec counts train images."""
     from senas_amd.loss import SegmentationLosses
-    from senas_amd.senas_search import NAS, Architecture
+    from senas_amd.senas_search import NAS
+    from senas_amd.step import SearchStep
     torch.manual_seed(0)
     net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev).to(dev).train()
     crit = SegmentationLosses('dice_ce')
     opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
     opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
-    arch = Architecture(net, opt_a, crit)
     xt, yt = synthetic(4, 1, 2, 256, 0, dev)
     xv, yv = synthetic(4, 1, 2, 256, 100, dev)
-    params = list(net.parameters())
+    log('search: supernet built, capturing forward+backward')
+    search = SearchStep(net, crit, opt_w, opt_a, xt.clone(), yt.clone(), grad_clip=5.0, use_graph=use_graph)
 
     def step():
-        arch.step(xv, yv)
-        opt_w.zero_grad()
-        loss = crit(net(xt), yt)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 5)
-        opt_w.step()
+        search(xt, yt, xv, yv)
 
-    log('search: supernet built, warm-up step')
+    log('search: warm-up step')
     step()
     torch.cuda.synchronize()
     log('search: timing %d steps' % steps)
@@ -260,7 +256,7 @@ def bench_search(dev, steps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {'workload': 'BASELINE configs[2]: NAS supernet c=32 depth=5 nodes=3, arch step (4 val) + weight step (4 train), 1x256x256',
-            'train_images_per_sec': round(4 / dt, 3), 'ms_per_step': round(dt * 1e3, 2), 'steps': steps}
+            "train_images_per_sec": round(4 / dt, 3), "ms_per_step": round(dt * 1e3, 2), "steps": steps, "hip_graph": bool(search.graphed)}
 
 
 if __name__ == '__main__':

@@ -61,9 +61,10 @@ int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, f
 /* dx = d loss / d x.  If in_relu != 0, x must be given and dx is masked by (x > 0).            */
 int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx,
                           int in_relu, const float* x, void* ws, void* stream);
-/* dw (same layout as w) is OVERWRITTEN.                                                        */
+/* dw (same layout as w) is OVERWRITTEN.  ws_is_zero != 0: the caller guarantees that ws is zero-filled
+ * (lets the launcher skip its own memset of the split-K accumulation image).                    */
 int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
-                            float* dw, void* ws, void* stream);
+                            float* dw, void* ws, int ws_is_zero, void* stream);
 
 /* ---- pooling / resampling --------------------------------------------------------------------
  * nn.AvgPool2d(3, stride, 1, count_include_pad=False)  (operations.py:62,150)
@@ -158,12 +159,13 @@ typedef struct senas_node_desc {
 int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
                    float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
- *   dgamma, dbeta: float[nterms][c]; dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
+ *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
+ *   dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
  *   abk: float[3][nterms][n][c] scratch; dz[t]: gradient of z_t or NULL (skipped); ds_out: gradient of
  *   the residual input or NULL.                                                                    */
 int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
                    const float* coefs, const float* gate, const float* se_m, const float* se_a1,
-                   double* p1, double* p2, float* dgamma, float* dbeta, float* dmix, float* const* dse_w1,
+                   double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------- */

@@ -42,7 +42,7 @@ SIGNATURES = {
     'senas_conv2d_ws_bytes': (C.c_int64, [_G]),
     'senas_conv2d_fwd': (_I, [_G, _P, _P, _P, _I, _P, _P, _P]),
     'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P]),
-    'senas_conv2d_bwd_weight': (_I, [_G, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_bwd_weight': (_I, [_G, _P, _I, _P, _P, _P, _I, _P]),
     'senas_avgpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'senas_avgpool3_bwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'senas_maxpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
@@ -57,7 +57,7 @@ SIGNATURES = {
     'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
     'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),
     'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'senas_node_bwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _PP, _P, _P]),
+    'senas_node_bwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _PP, _PP, _P, _PP, _P, _P]),
     'senas_last_error': (C.c_char_p, []),
     'senas_abi_version': (_I, []),
 }

@@ -41,7 +41,15 @@ def zeros64(shape, device):
     return _ZEROS64.take(n, device)[:n].view(shape)
 
 
+_ZEROS32 = ZeroArena(torch.float32, 1 << 20)      # 4 MiB chunks
+
+
+def zeros32(numel, device):
+    return _ZEROS32.take(numel, device)[:numel]
+
+
 def reset_arena():
     """Drop the current chunks.  Call before HIP-graph capture begins and after it ends, so that every
     captured use of a chunk is preceded, inside the same graph, by the memset that zeroes it."""
     _ZEROS64.reset()
+    _ZEROS32.reset()

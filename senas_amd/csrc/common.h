@@ -70,7 +70,7 @@ int launch_mfma_gather(const GatherGeom& g, const float* in, const float* wp, fl
 void launch_pack_mfma(const float* w, float* wp, int d0, int d1, int taps, int swap, hipStream_t st);
 bool mfma_wgrad_ok(const WgradGeom& g);
 int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, float* ws, int i_relu, int g_relu,
-                      hipStream_t st);
+                      int ws_is_zero, hipStream_t st);
 
 // wgrad_lds.hip (stride-1 "same" weight gradient, persistent, both operands in LDS); ws zeroed by the caller
 bool lds_wgrad_ok(const WgradGeom& g);

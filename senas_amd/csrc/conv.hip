@@ -270,6 +270,94 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const fl
     }
 }
 
+// Two-stage, atomic-free form for C % 4 == 0 (every depthwise conv on the real path):
+// stage 1: thread = (pixel lane, 4-channel group); per-tap partial sums in registers, reduced over the
+//          pixel lanes of the wave by shuffles and over the 4 waves through LDS -> part[block][c][tap]
+// stage 2: dw[c][tap] = sum over blocks (fixed order: bitwise reproducible)
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, const float* __restrict__ I,
+                                                                const float* __restrict__ G, float* __restrict__ part,
+                                                                int i_relu, int g_relu) {
+    constexpr int TAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][c4 groups][TAPS][4]
+    const int C = g.A, C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;         // consecutive threads -> consecutive 16-byte pieces
+    const int lanes = 256 / C4;                                     // pixel lanes per block
+    const int per_img = g.hg * g.wg;
+    const long total = (long)g.n * per_img;
+    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    if (p1 > total) p1 = total;
+    float acc[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+    if (pl < lanes) {
+        for (long p = p0 + pl; p < p1; p += lanes) {
+            const int n = (int)(p / per_img), r = (int)(p % per_img);
+            const int gy = r / g.wg, gx = r % g.wg;
+            float gv[4];
+            ldv<4>(G + (size_t)p * C + c4 * 4, gv);
+            if (g_relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = fmaxf(gv[j], 0.f);
+            }
+            const float* In = I + (size_t)n * g.hi * g.wi * C + c4 * 4;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = gy * g.stride - g.pad + ky * g.dil;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int ix = gx * g.stride - g.pad + kx * g.dil;
+                    const bool ok = iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+                    float iv[4];
+                    ldv<4>(In + (ok ? (size_t)(iy * g.wi + ix) * C : 0), iv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = ok ? iv[j] : 0.f;
+                        if (i_relu) v = fmaxf(v, 0.f);
+                        acc[ky * KS + kx][j] = fmaf(v, gv[j], acc[ky * KS + kx][j]);
+                    }
+                }
+            }
+        }
+    }
+    // reduce over the pixel lanes that share c4 inside the wave: lanes differ by multiples of C4
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[t][j];
+            for (int o = C4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            acc[t][j] = v;
+        }
+    if (lane < C4) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((wave * C4 + lane) * TAPS + t) * 4 + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C4 * TAPS * 4; i += 256) {
+        const int j = i & 3, t = (i >> 2) % TAPS, cg = (i >> 2) / TAPS;
+        float v = 0.f;
+        for (int w = 0; w < 4; ++w) v += red[((w * C4 + cg) * TAPS + t) * 4 + j];
+        part[((size_t)blockIdx.x * C + cg * 4 + j) * TAPS + t] = v;
+    }
+}
+
+// one wave per output element: lanes stride over the blocks' partials, fixed-order shuffle tree at the end
+__global__ __launch_bounds__(256) void dwconv_wgrad_sum_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                               int n_elem, int n_blocks) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_elem) return;
+    float v = 0.f;
+    for (int b = lane; b < n_blocks; b += 64) v += part[(size_t)b * n_elem + i];
+    v = wave_sum(v);
+    if (lane == 0) dw[i] = v;
+}
+
 static bool geom_ok(const senas_conv_geom* g) {
     if (!g || g->n <= 0 || g->ci <= 0 || g->co <= 0 || g->kh <= 0 || g->kw <= 0) return false;
     if (g->stride != 1 && g->stride != 2) return false;
@@ -292,7 +380,7 @@ using namespace senas;
 
 extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     if (!g) return 0;
-    if (g->groups != 1) return 16;
+    if (g->groups != 1) return (int64_t)512 * g->ci * g->kh * g->kw * sizeof(float) + 256;   // per-block wgrad partials
     // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
     const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
     const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
@@ -380,7 +468,7 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
 }
 
 extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw,
-                                       void* ws, void* stream) {
+                                       void* ws, int ws_is_zero, void* stream) {
     SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_weight: inconsistent geometry");
     SENAS_REQUIRE(x && dy && dw, "conv2d_bwd_weight: null pointer");
     hipStream_t st = as_stream(stream);
@@ -398,10 +486,24 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
     const long total = (long)wg.n * wg.hg * wg.wg;
     if (g->groups != 1) {
         SENAS_REQUIRE(g->ci <= 256, "depthwise wgrad: more than 256 channels");
+        SENAS_REQUIRE(g->kh == g->kw && (g->kh == 3 || g->kh == 5), "depthwise wgrad: only 3x3 and 5x5 are on the path");
+        const int c4 = g->ci / 4;
+        if (g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64 && ws != nullptr) {     // two-stage, atomic-free
+            long nblk = (total + 255) / 256;
+            if (nblk > 512) nblk = 512;
+            wg.chunk = (int)((total + nblk - 1) / nblk);
+            nblk = (total + wg.chunk - 1) / wg.chunk;
+            float* part = reinterpret_cast<float*>(ws);
+            const size_t lds = (size_t)4 * c4 * taps * 4 * sizeof(float);
+            if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_kernel<3>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
+            else hipLaunchKernelGGL((dwconv_wgrad_part_kernel<5>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
+            const int n_elem = g->ci * taps;
+            hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, part, dw, n_elem, (int)nblk);
+            return launch_status("dwconv_wgrad");
+        }
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * taps * sizeof(float), st);
         if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }
-        SENAS_REQUIRE(g->kh == g->kw && (g->kh == 3 || g->kh == 5), "depthwise wgrad: only 3x3 and 5x5 are on the path");
-        long chunk = (total + 1023) / 1024;
+        long chunk = (total + 127) / 128;                 // few blocks: every block ends in atomics on the same addresses
         if (chunk < 64) chunk = 64;
         wg.chunk = (int)chunk;
         dim3 grid((unsigned)((total + wg.chunk - 1) / wg.chunk));
@@ -412,8 +514,10 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
     if (!g->transposed && lds_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         float* wsp = reinterpret_cast<float*>(ws);
-        hipError_t e0 = hipMemsetAsync(wsp, 0, (size_t)taps * wg.A * 32 * sizeof(float), st);
-        if (e0 != hipSuccess) { set_error("memset wgrad ws", e0); return SENAS_ELAUNCH; }
+        if (!ws_is_zero) {
+            hipError_t e0 = hipMemsetAsync(wsp, 0, (size_t)taps * wg.A * 32 * sizeof(float), st);
+            if (e0 != hipSuccess) { set_error("memset wgrad ws", e0); return SENAS_ELAUNCH; }
+        }
         const int rc = launch_lds_wgrad(wg, I, G, wsp, i_relu, st);
         if (rc != SENAS_OK) return rc;
         launch_unpack_wgrad(wsp, dw, wg.A, wg.B, taps, st);
@@ -421,7 +525,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
     }
     if (mfma_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
-        return launch_mfma_wgrad(wg, I, G, dw, reinterpret_cast<float*>(ws), i_relu, g_relu, st);
+        return launch_mfma_wgrad(wg, I, G, dw, reinterpret_cast<float*>(ws), i_relu, g_relu, ws_is_zero, st);
     }
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * g->co * taps * sizeof(float), st);
     if (e != hipSuccess) { set_error("memset dw", e); return SENAS_ELAUNCH; }

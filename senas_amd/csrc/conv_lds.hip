@@ -3,15 +3,16 @@
 //
 // Why LDS here: the direct-global kernel (conv_mfma.hip) re-reads every input pixel once per tap as
 // 16-byte fragments, 32 cache lines per wave-instruction, and ends up L1/TA-bound at ~30% of the
-// fp32-MFMA rate.  Here a block loads its (8 + 2*halo) x (32 + 2*halo) input window ONCE, in full
+// fp32-MFMA rate.  Here a block loads its (TH + 2*halo) x (32 + 2*halo) input window ONCE, in full
 // 64-byte runs (ReLU applied on the way in, borders zero-filled so the tap loop has no bounds
 // checks), and all k*k taps read their A fragments from LDS with conflict-free ds_read_b128.
 //
-// Tile: 8 x 32 output pixels per 256-thread block; wave w owns rows 2w, 2w+1 (two 32-pixel MFMA
-// sub-tiles).  Channels go through LDS 16 at a time (pixel stride 80 B = 64 B data + 16 B pad: the 16
-// lanes of a ds_read_b128 group land on 16 distinct 4-bank slots), so the window costs
-// 880 px * 80 B = 69 KiB for 5x5 dilation 3 -- two blocks per CU, one loading while the other computes.
-// B fragments (weights) stream from the packed image in L2, 1 KiB per wave-instruction.
+// Tile: TH x 32 output pixels per 256-thread block, TH = 4*MT; wave w owns rows MT*w .. MT*w+MT-1 (MT
+// 32-pixel MFMA sub-tiles).  MT = 2 for maps that fill the chip, MT = 1 when that would leave CUs idle
+// (twice the blocks, half the critical path).  Channels go through LDS 16 at a time (pixel stride 80 B =
+// 64 B data + 16 B pad: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots), so the
+// window costs 880 px * 80 B = 69 KiB for 5x5 dilation 3 at MT = 2 -- two blocks per CU, one loading
+// while the other computes.  B fragments (weights) stream from the packed image in L2.
 #include "common.h"
 
 namespace senas {
@@ -20,26 +21,29 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-constexpr int TH = 8, TW = 32, CH = 16, PST = 20;     // PST: pixel stride in floats (16 data + 4 pad)
+constexpr int TW = 32, CH = 16, PST = 20;     // PST: pixel stride in floats (16 data + 4 pad)
+constexpr int P4 = PST / 4;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
+template <int MT>
 struct Frag {
-    float4 a[2][2];      // [channel group within the pass][sub-tile]
+    float4 a[2][MT];     // [channel group within the pass][sub-tile]
     float4 b[2];
 };
 
 }  // namespace
 
 // grid = (tiles_x, tiles_y, n * co_tiles); dynamic LDS = tile_h * tile_w * PST floats
-template <bool TG>
+template <bool TG, int MT>
 __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
                                                        double* __restrict__ stats) {
+    constexpr int TH = 4 * MT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -52,18 +56,17 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
     const int taps = g.kh * g.kw;
     wp += (size_t)cot * taps * ngroups * 256 + lane * 4;
 
-    f32x16 acc[2];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
 
     // LDS offset (in 16-byte units, so the accesses are provably aligned -> ds_read_b128) of this lane's
-    // pixel for tap (0,0), channel chunk h, sub-tile m
-    constexpr int P4 = PST / 4;
+    // pixel for tap (0,0), channel chunk h, sub-tile 0; sub-tile m is tile_w * P4 * m further
     float4* lds4 = reinterpret_cast<float4*>(lds);
-    const int lbase0 = ((2 * wave) * tile_w + r) * P4 + h;
-    const int lbase1 = lbase0 + tile_w * P4;
+    const int lbase = ((MT * wave) * tile_w + r) * P4 + h;
+    const int lrow = tile_w * P4;
 
     for (int pass = 0; pass < npass; ++pass) {
         __syncthreads();                                 // previous pass's readers are done
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
         __syncthreads();
 
         // ---- taps, software-pipelined over two alternating fragment sets (no register copies):
-        // while tap t's 16 MFMAs issue, tap t+1's A fragments (LDS) and B fragments (L2) are in flight
+        // while tap t's MFMAs issue, tap t+1's A fragments (LDS) and B fragments (L2) are in flight
         auto tap_ptrs = [&](int t, int& toff, const float*& wt) {
             const int ky = t / g.kw, kx = t - ky * g.kw;
             // plain gather: window row = oy_local + ky*d ; transposed (stride 1): oy_local + (k-1-ky)*d
@@ -101,40 +104,39 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
             toff = (dy * tile_w + dx) * P4;
             wt = wp + ((size_t)t * ngroups + pass * 2) * 256;
         };
-        auto load_a = [&](int toff, Frag& f) {
+        auto load_a = [&](int toff, Frag<MT>& f) {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                f.a[c2][0] = lds4[lbase0 + toff + c2 * 2];
-                f.a[c2][1] = lds4[lbase1 + toff + c2 * 2];
-            }
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) f.a[c2][m] = lds4[lbase + m * lrow + toff + c2 * 2];
         };
-        auto load_b = [&](const float* wt, Frag& f) {
+        auto load_b = [&](const float* wt, Frag<MT>& f) {
             f.b[0] = *reinterpret_cast<const float4*>(wt);
             f.b[1] = *reinterpret_cast<const float4*>(wt + 256);
         };
-        // One tap = 16 MFMAs (1024 cycles).  hipcc waits vmcnt(0) in front of the first MFMA that needs a
-        // weight fragment, so (a) both fragments of the tap are consumed by the first four MFMAs, while only
-        // they are outstanding, and (b) the NEXT tap's weight loads are issued right after those four
-        // (pinned by sched_barrier): by the time the next tap starts they have had ~768 cycles to land.
-        auto step = [&](const Frag& cur, Frag& nxt, bool more, int toff_n, const float* wt_n) {
+        // One tap = 8*MT MFMAs (64 cycles each).  hipcc waits vmcnt(0) in front of the first MFMA that needs
+        // a weight fragment, so (a) both fragments of the tap are consumed by the first 2*MT MFMAs, while only
+        // they are outstanding, and (b) the NEXT tap's weight loads are issued right after those
+        // (pinned by sched_barrier): by the time the next tap starts they have had 6*MT*64 cycles to land.
+        auto step = [&](const Frag<MT>& cur, Frag<MT>& nxt, bool more, int toff_n, const float* wt_n) {
             if (more) load_a(toff_n, nxt);
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m] = mfma32(cur.a[c2][m].x, cur.b[c2].x, acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = mfma32(cur.a[c2][m].x, cur.b[c2].x, acc[m]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) load_b(wt_n, nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     acc[m] = mfma32(cur.a[c2][m].y, cur.b[c2].y, acc[m]);
                     acc[m] = mfma32(cur.a[c2][m].z, cur.b[c2].z, acc[m]);
                     acc[m] = mfma32(cur.a[c2][m].w, cur.b[c2].w, acc[m]);
                 }
         };
-        Frag f0, f1;
+        Frag<MT> f0, f1;
         int toff;
         const float* wt;
         tap_ptrs(0, toff, wt);
@@ -152,12 +154,12 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
         }
     }
 
-    // ---- epilogue: lane = output channel, register v = pixel (row 2*wave + m, column acc_row(v, h))
+    // ---- epilogue: lane = output channel, register v = pixel (row MT*wave + m, column acc_row(v, h))
     const bool cok = co < g.cout;
     double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int oy = oy0 + 2 * wave + m;
+    for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + MT * wave + m;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int ox = ox0 + acc_row(v, h);
@@ -191,25 +193,36 @@ bool lds_gather_ok(const GatherGeom& g) {
     // stride 1, "same" padding, 16-channel passes, maps at least one tile wide
     if (g.stride != 1 || g.cin % CH != 0) return false;
     if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hout != g.hin || g.wout != g.win) return false;
-    if (g.wout < TW || g.hout < TH) return false;
-    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    if (g.wout < TW || g.hout < 4) return false;
+    const size_t bytes = (size_t)(8 + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
     return bytes <= 150 * 1024 && (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
+}
+
+template <bool TG, int MT>
+static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
+                              const float* mask, double* stats, hipStream_t st) {
+    constexpr int TH = 4 * MT;
+    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    static bool attr_set = false;
+    if (bytes > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
+        attr_set = true;
+    }
+    dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT>), grid, dim3(256), bytes, st, g, in, wp, out, in_relu, mask, stats);
+    return launch_status("conv_lds");
 }
 
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st) {
-    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (bytes > 64 * 1024 && !attr_set[TG ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
-        attr_set[TG ? 1 : 0] = true;
-    }
-    dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG>), grid, dim3(256), bytes, st, g, in, wp, out, in_relu, mask, stats);
-    return launch_status("conv_lds");
+    // 8x32 tiles when they still give every CU two blocks; otherwise 4x32 tiles: twice the blocks and half
+    // the serial tap loop per block (small maps are critical-path-bound, not throughput-bound)
+    const long blocks8 = (long)((g.wout + TW - 1) / TW) * ((g.hout + 7) / 8) * g.n * ((g.cout + 31) / 32);
+    if (blocks8 >= 512 && g.hout >= 8) return launch_lds_variant<TG, 2>(g, in, wp, out, in_relu, mask, stats, st);
+    return launch_lds_variant<TG, 1>(g, in, wp, out, in_relu, mask, stats, st);
 }
 
 template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);

@@ -58,17 +58,10 @@ struct GFrag {
     float4 b[4];
 };
 
-template <bool TG, int MT>
-struct GatherState {
-    // walks the (valid) taps and, inside a tap, chunks of 4 channel groups
-    int ky, kx, chunk;
-    __device__ __forceinline__ bool tap_ok(const GatherGeom& g, bool s2, int py, int px) const {
-        if (!s2) return true;
-        return !(((py + g.pad - ky * g.dil) & 1) | ((px + g.pad - kx * g.dil) & 1));
-    }
-};
-
-template <bool TG, int MT>
+// KS = 4: the four waves of a block share ONE 32-pixel sub-tile and split the (tap, chunk) steps between
+// them (partial accumulators are summed through LDS) -- for tiny maps, where the serial K loop of a wave is
+// the whole launch time.  KS = 1: every wave owns MT sub-tiles and runs all steps.
+template <bool TG, int MT, int KS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const float* __restrict__ in,
                                                         const float* __restrict__ wp, float* __restrict__ out,
                                                         int in_relu, const float* __restrict__ mask,
@@ -82,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
     const int HP = s2 ? g.hout >> 1 : g.hout, WP = s2 ? g.wout >> 1 : g.wout;
     const int QP = HP * WP;
     const long total = (long)g.n * QP;
-    const long base = ((long)tile * 4 + wave) * (MT * 32);
+    const long base = KS == 4 ? (long)tile * 32 : ((long)tile * 4 + wave) * (MT * 32);
 
     int pn[MT], poy[MT], pox[MT];
     bool live[MT];
@@ -160,12 +153,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
         return !(((py + g.pad - ky * g.dil) | (px + g.pad - kx * g.dil)) & 1);
     };
     // advance (ky, kx, chunk) to the next valid step; returns false at the end
-    auto advance = [&](int& ky, int& kx, int& chunk) -> bool {
+    auto advance1 = [&](int& ky, int& kx, int& chunk) -> bool {
         if (++chunk < nchunks) return true;
         chunk = 0;
         for (;;) {
             if (++kx >= g.kw) { kx = 0; if (++ky >= g.kh) return false; }
             if (tap_valid(ky, kx)) return true;
+        }
+    };
+    int sidx = -1;                                                    // running index of valid steps
+    auto advance = [&](int& ky, int& kx, int& chunk) -> bool {
+        for (;;) {
+            if (!advance1(ky, kx, chunk)) return false;
+            ++sidx;
+            if (KS == 1 || (sidx & 3) == wave) return true;           // this wave's share of the steps
         }
     };
     int ky = 0, kx = -1, chunk = nchunks - 1;                         // "before the first step"
@@ -182,6 +183,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
         have = more;
     }
 
+    if (KS == 4) {                                                    // sum the four partial tiles through LDS
+        __shared__ float red[3][16][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[wave - 1][v][lane] = acc[0][v];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[0][v] += red[0][v][lane] + red[1][v][lane] + red[2][v][lane];
+    }
     // ---- epilogue: lane = output channel, registers = pixels
     const bool cok = co < g.cout;
     // per-pixel output offset and image index travel by shuffle from the lane that decoded the pixel
@@ -451,10 +463,13 @@ int launch_mfma_gather(const GatherGeom& g, const float* in, const float* wp, fl
     // small maps take 1 sub-tile so that more CUs get work
     if (per_phase * phases >= 256L * 512) {
         const int tiles = (int)((per_phase + 255) / 256);
-        hipLaunchKernelGGL((conv_mfma_kernel<TG, 2>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<TG, 2, 1>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
+    } else if (per_phase * phases <= 32L * 1024) {                    // tiny maps: one sub-tile per block, taps split over its waves
+        const int tiles = (int)((per_phase + 31) / 32);
+        hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 4>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
     } else {
         const int tiles = (int)((per_phase + 127) / 128);
-        hipLaunchKernelGGL((conv_mfma_kernel<TG, 1>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 1>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
     }
     return launch_status("conv_mfma");
 }
@@ -479,11 +494,13 @@ bool mfma_wgrad_ok(const WgradGeom& g) {
 }
 
 int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, float* ws, int i_relu, int g_relu,
-                      hipStream_t st) {
+                      int ws_is_zero, hipStream_t st) {
     const int taps = g.kh * g.kw;
     const long total = (long)g.n * g.hg * g.wg;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)taps * g.A * 32 * sizeof(float), st);
-    if (e != hipSuccess) { set_error("memset wgrad ws", e); return SENAS_ELAUNCH; }
+    if (!ws_is_zero) {
+        hipError_t e = hipMemsetAsync(ws, 0, (size_t)taps * g.A * 32 * sizeof(float), st);
+        if (e != hipSuccess) { set_error("memset wgrad ws", e); return SENAS_ELAUNCH; }
+    }
     // pixel chunks: ~512 blocks on the big maps, never below 128 pixels per block
     long chunk = (total + 511) / 512;
     if (chunk < 128) chunk = 128;

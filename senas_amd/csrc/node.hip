@@ -38,9 +38,11 @@ struct ZTable {
 struct DzTable {
     float* p[SENAS_MAX_TERMS];
 };
-struct SeGradTable {
+struct SeGradTable {            // per-term gradient destinations (each its own tensor on the host side)
     float* w1[SENAS_MAX_TERMS];
     float* w2[SENAS_MAX_TERMS];
+    float* dgamma[SENAS_MAX_TERMS];
+    float* dbeta[SENAS_MAX_TERMS];
 };
 
 // ------------------------------------------------------------------------------------------ forward prepare
@@ -224,8 +226,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
                                                                const double* __restrict__ p2, const float* __restrict__ coefs,
                                                                const float* __restrict__ gate, const float* __restrict__ se_m,
-                                                               const float* __restrict__ se_a1, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float* __restrict__ dmix,
+                                                               const float* __restrict__ se_a1, float* __restrict__ dmix,
                                                                float* __restrict__ A, float* __restrict__ B, float* __restrict__ K,
                                                                SeGradTable seg) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];     // da2[n][c], da1[n][kMaxMid]
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
         s2 += u1 * p2[tb + (size_t)i * c + ch] + e * Z;
     }
     const double kk = s2 - mean * s1;
-    dbeta[(size_t)t * c + ch] = (float)s1;
-    dgamma[(size_t)t * c + ch] = (float)(invstd * kk);
+    seg.dbeta[t][ch] = (float)s1;
+    seg.dgamma[t][ch] = (float)(invstd * kk);
     const double bcoef = d.training ? -scale * invstd * invstd * kk / M : 0.0;
     const double kconst = d.training ? (-scale * s1 / M + scale * invstd * invstd * mean * kk / M) : 0.0;
     for (int i = 0; i < n; ++i) {
@@ -418,7 +419,7 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
 
 extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
                               const float* coefs, const float* gate, const float* se_m, const float* se_a1,
-                              double* p1, double* p2, float* dgamma, float* dbeta, float* dmix, float* const* dse_w1,
+                              double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                               float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
@@ -430,6 +431,9 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     for (int t = 0; t < d.nterms; ++t) {
         zt.p[t] = z[t];
         dzt.p[t] = dz[t];
+        SENAS_REQUIRE(dgamma[t] && dbeta[t], "node_bwd: null batch-norm gradient destination");
+        seg.dgamma[t] = dgamma[t];
+        seg.dbeta[t] = dbeta[t];
         SENAS_REQUIRE(z[t] || !dz[t], "node_bwd: dz without z");
         any_dz = any_dz || dz[t] != nullptr;
         if (d.w1[t]) {
@@ -455,7 +459,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     } while (t0 < d.nterms);
     const size_t tnc = (size_t)d.nterms * d.n * d.c;
     const size_t lds = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(double) : 0;
-    hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds, st, d, p1, p2, coefs, gate, se_m, se_a1, dgamma, dbeta,
+    hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds, st, d, p1, p2, coefs, gate, se_m, se_a1,
                        dmix, abk, abk + tnc, abk + 2 * tnc, seg);
     if (any_dz || ds_out) {
         const int V = (d.c % 4 == 0) ? 4 : 1;

@@ -192,7 +192,11 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
 
 // ws: zeroed float[taps][A][32]; the caller unpacks it into the torch layout afterwards
 int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, hipStream_t st) {
-    const int th = wgrad_lds_bytes(g, 8) <= 150 * 1024 ? 8 : 4;
+    // tallest tile that fits in LDS; on small maps shrink it until every CU has a tile (the kernel is
+    // critical-path-bound there: a shorter tile is a shorter serial K loop per block)
+    int th = wgrad_lds_bytes(g, 8) <= 150 * 1024 ? 8 : 4;
+    const int tiles_x = (g.wg + TW - 1) / TW;
+    while (th > 2 && (long)g.n * tiles_x * ((g.hg + th - 1) / th) < 256) th >>= 1;
     const int units = g.kh * g.kw * (g.A / 32);
     const int uw = (units + 7) / 8;
 #define SENAS_WG(AA)                                                                      \

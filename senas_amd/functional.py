@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import ConvGeom, SenasHipError
-from .arena import zeros64
+from .arena import zeros32, zeros64
 
 CL = torch.channels_last
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -163,9 +163,10 @@ class _Conv2d(torch.autograd.Function):
                                                    x.data_ptr(), ws.data_ptr(), _stream()), 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
+            wsz = zeros32(ws.numel() // 4, x.device)          # pre-zeroed split-K image: no memset launch per conv
             with _span('conv_wgrad', g, x, w, dy):
                 _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dw.data_ptr(),
-                                                     ws.data_ptr(), _stream()), 'senas_conv2d_bwd_weight')
+                                                     wsz.data_ptr(), 1, _stream()), 'senas_conv2d_bwd_weight')
         return dx, dw, None, None, None, None, None, None, None, None
 
 

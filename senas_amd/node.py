@@ -121,7 +121,8 @@ class _Node(torch.autograd.Function):
                 dzs[t] = torch.empty_like(zs[k], memory_format=CL)
         ds_out = torch.empty_like(y, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
-        dgb = torch.empty((2, T, c), device=dev, dtype=torch.float32)
+        dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # own tensors: autograd adopts them
+        dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # as .grad without cloning a view
         dmix = torch.empty(T, device=dev, dtype=torch.float32) if ctx.has_mix else None
         abk = torch.empty((3, T, n, c), device=dev, dtype=torch.float32)
         dw1s = [torch.empty_like(wt) for wt in w1s]
@@ -133,11 +134,12 @@ class _Node(torch.autograd.Function):
         dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
         se_m, se_a1 = ctx.se_buf
         _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
-                                    F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(), dgb[0].data_ptr(),
-                                    dgb[1].data_ptr(), F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),
+                                    F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
+                                    _arr([t_.data_ptr() for t_ in dgs]), _arr([t_.data_ptr() for t_ in dbs]),
+                                    F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),
                                     F._stream()), 'senas_node_bwd')
         grads = [dzs[t] for t in real]
-        grads += [dgb[0, t] for t in range(T)] + [dgb[1, t] for t in range(T)]
+        grads += dgs + dbs
         grads += dw1s + dw2s
         grads += [torch.zeros_like(q) for q in meta['passengers']]
         assert len(grads) == ctx.nflat

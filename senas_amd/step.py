@@ -60,6 +60,38 @@ class GraphedForwardBackward(object):
         return self.loss
 
 
+class SearchStep(object):
+    """One search step as experiments/search_arc.py:252-299 runs it after ``alpha_begin``:
+    ``Architecture.step`` on a validation batch (first-order: forward/backward, Adam on alpha/beta/gamma),
+    then the weight step on a training batch (SGD over ALL parameters -- architecture included -- after
+    clip_grad_norm_).  Both passes replay the same captured forward+backward on static input buffers."""
+
+    def __init__(self, model, criterion, weight_optimizer, arch_optimizer, x, y, world_size=1, grad_clip=5.0,
+                 use_graph=True):
+        self.params = [p for p in model.parameters()]
+        self.reducer = GradAllReducer(self.params, world_size=world_size)
+        self.opt_w, self.opt_a, self.grad_clip = weight_optimizer, arch_optimizer, grad_clip
+        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
+        self.graphed = self.fb.graph is not None
+
+    def __call__(self, x_train, y_train, x_valid=None, y_valid=None):
+        fb = self.fb
+        if x_valid is not None:                    # architecture step (skipped before alpha_begin)
+            fb.x.copy_(x_valid, non_blocking=True)
+            fb.y.copy_(y_valid, non_blocking=True)
+            fb()
+            self.reducer.finish()
+            self.opt_a.step()
+        fb.x.copy_(x_train, non_blocking=True)
+        fb.y.copy_(y_train, non_blocking=True)
+        loss = fb()
+        self.reducer.finish()
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        self.opt_w.step()
+        return loss
+
+
 class TrainStep(object):
     """One optimisation step of the derived network: graph(fwd+loss+bwd) -> all-reduce -> clip -> SGD."""
 

@@ -120,17 +120,24 @@ def main():
     ap.add_argument('--search-steps', type=int, default=2, help='timed supernet search steps (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run forward+backward eagerly instead of replaying a HIP graph')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
+    ap.add_argument('--one-device', action='store_true',
+                    help='rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    dev_index = 0 if args.one_device else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
 
     from senas_amd import _lib, functional as F

@@ -56,11 +56,26 @@ typedef struct senas_conv_geom {
 /* ws: device scratch of at least senas_conv2d_ws_bytes(g) bytes (repacked weights / partial sums),
  * private to the call until the stream has passed it.                                          */
 int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);
+/* packed (optional, may be NULL): the MFMA fragment image of w for this direction, kept up to date by
+ * the caller with senas_pack_batched (layout from senas_conv2d_pack_layout).  NULL: the launcher
+ * repacks w into ws itself.  Ignored by the non-MFMA fallback kernels.                            */
 int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y,
-                     int in_relu, double* stats, void* ws, void* stream);
+                     int in_relu, double* stats, void* ws, const float* packed, void* stream);
 /* dx = d loss / d x.  If in_relu != 0, x must be given and dx is masked by (x > 0).            */
 int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx,
-                          int in_relu, const float* x, void* ws, void* stream);
+                          int in_relu, const float* x, void* ws, const float* packed, void* stream);
+/* Packed-weight cache.  direction 0 = forward image, 1 = data-gradient image.  *elems == 0: this
+ * convolution has no MFMA image (depthwise, or reduction channels not a multiple of 8).          */
+typedef struct senas_pack_item {
+    const float* src;            /* weights, torch layout [d0][d1][taps]                          */
+    float* dst;                  /* float[elems]                                                   */
+    int32_t d0, d1, taps, swap;
+    int64_t elems;
+} senas_pack_item;
+int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d0, int32_t* d1, int32_t* swap,
+                             int64_t* elems);
+/* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
+int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
 /* dw (same layout as w) is OVERWRITTEN.  ws_is_zero != 0: the caller guarantees that ws is zero-filled
  * (lets the launcher skip its own memset of the split-K accumulation image).                    */
 int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,

@@ -389,7 +389,7 @@ extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
 
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
 extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
-                                double* stats, void* ws, void* stream) {
+                                double* stats, void* ws, const float* packed, void* stream) {
     SENAS_REQUIRE(geom_ok(g), "conv2d_fwd: inconsistent geometry");
     SENAS_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     hipStream_t st = as_stream(stream);
@@ -410,14 +410,19 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
-    if (!g->transposed && lds_gather_ok(gg)) {
-        launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st);
-        return launch_lds_gather<false>(gg, x, wp, y, in_relu, nullptr, stats, st);
-    }
-    if (mfma_gather_ok(gg, g->transposed != 0)) {
-        if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st); return launch_mfma_gather<false>(gg, x, wp, y, in_relu, nullptr, stats, st); }
-        launch_pack_mfma(w, wp, g->ci, g->co, taps, 0, st);
-        return launch_mfma_gather<true>(gg, x, wp, y, in_relu, nullptr, stats, st);
+    // MFMA paths read the fragment image; `packed` (if given) is that image, refreshed by the caller
+    // once per step (senas_pack_batched) instead of once per launch
+    const bool use_lds = !g->transposed && lds_gather_ok(gg);
+    if (use_lds || mfma_gather_ok(gg, g->transposed != 0)) {
+        const float* img = packed;
+        if (img == nullptr) {
+            if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st);
+            else launch_pack_mfma(w, wp, g->ci, g->co, taps, 0, st);
+            img = wp;
+        }
+        if (use_lds) return launch_lds_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
+        if (!g->transposed) return launch_mfma_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
+        return launch_mfma_gather<true>(gg, x, img, y, in_relu, nullptr, stats, st);
     }
     // Conv2d w[co][ci][tap] -> wp[tap][ci][co] (swap); ConvTranspose2d w[ci][co][tap] -> wp[tap][ci][co]
     if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 1);
@@ -428,7 +433,7 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
 
 // data gradient: Conv2d -> transposed gather over dy; ConvTranspose2d -> plain gather over dy
 extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx, int in_relu,
-                                     const float* x, void* ws, void* stream) {
+                                     const float* x, void* ws, const float* packed, void* stream) {
     SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_data: inconsistent geometry");
     SENAS_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
     SENAS_REQUIRE(!in_relu || x, "conv2d_bwd_data: in_relu needs x");
@@ -451,14 +456,17 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     SENAS_REQUIRE(ws, "conv2d_bwd_data: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
-    if (!g->transposed && lds_gather_ok(gg)) {
-        launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st);
-        return launch_lds_gather<true>(gg, dy, wp, dx, 0, mask, nullptr, st);
-    }
-    if (mfma_gather_ok(gg, g->transposed == 0)) {
-        if (!g->transposed) { launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st); return launch_mfma_gather<true>(gg, dy, wp, dx, 0, mask, nullptr, st); }
-        launch_pack_mfma(w, wp, g->ci, g->co, taps, 1, st);
-        return launch_mfma_gather<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
+    const bool use_lds = !g->transposed && lds_gather_ok(gg);
+    if (use_lds || mfma_gather_ok(gg, g->transposed == 0)) {
+        const float* img = packed;
+        if (img == nullptr) {
+            if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st);
+            else launch_pack_mfma(w, wp, g->ci, g->co, taps, 1, st);
+            img = wp;
+        }
+        if (use_lds) return launch_lds_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
+        if (!g->transposed) return launch_mfma_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
+        return launch_mfma_gather<false>(gg, dy, img, dx, 0, mask, nullptr, st);
     }
     // wp[tap][a = co][b = ci]
     if (!g->transposed) hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->co, g->ci, taps, 0);

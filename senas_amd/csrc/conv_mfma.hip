@@ -501,9 +501,10 @@ int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, fl
         hipError_t e = hipMemsetAsync(ws, 0, (size_t)taps * g.A * 32 * sizeof(float), st);
         if (e != hipSuccess) { set_error("memset wgrad ws", e); return SENAS_ELAUNCH; }
     }
-    // pixel chunks: ~512 blocks on the big maps, never below 128 pixels per block
+    // pixel chunks: ~512 blocks on the big maps; small maps are bound by the serial K loop of one wave,
+    // so they get short chunks (32 pixels = 16 MFMA steps) and more blocks
     long chunk = (total + 511) / 512;
-    if (chunk < 128) chunk = 128;
+    if (chunk < 32) chunk = 32;
     chunk = (chunk + 7) & ~7L;
     g.chunk = (int)chunk;
     const unsigned gx = (unsigned)((total + chunk - 1) / chunk);
@@ -525,3 +526,58 @@ int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, fl
 }
 
 }  // namespace senas
+
+// ---------------------------------------------------------------------------------------------
+// Batched weight packing: one launch refreshes the fragment images of every convolution of a model
+// (weights change once per optimizer step, not once per launch).  items: device array.
+namespace senas {
+
+struct PackItem {                // = senas_pack_item
+    const float* src;
+    float* dst;
+    int d0, d1, taps, swap;
+    long elems;
+};
+
+__global__ void pack_weights_batched_kernel(const PackItem* __restrict__ items) {
+    const PackItem it = items[blockIdx.y];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= it.elems) return;
+    const int A = it.swap ? it.d1 : it.d0, B = it.swap ? it.d0 : it.d1;
+    const int s = i & 3, jj = (i >> 2) & 31, h = (i >> 7) & 1;
+    const int cg = (int)((i >> 8) % (A / 8));
+    const int t = (int)(((i >> 8) / (A / 8)) % it.taps), nt = (int)((i >> 8) / ((long)(A / 8) * it.taps));
+    const int a = cg * 8 + 4 * h + s, j = nt * 32 + jj;
+    float v = 0.f;
+    if (j < B) {
+        const int s0 = it.swap ? j : a, s1 = it.swap ? a : j;
+        v = it.src[((size_t)s0 * it.d1 + s1) * it.taps + t];
+    }
+    it.dst[i] = v;
+}
+
+}  // namespace senas
+
+static_assert(sizeof(senas_pack_item) == sizeof(senas::PackItem), "senas_pack_item layout");
+
+extern "C" int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d0, int32_t* d1, int32_t* swap,
+                                        int64_t* elems) {
+    SENAS_REQUIRE(g && d0 && d1 && swap && elems && (direction == 0 || direction == 1), "conv2d_pack_layout: bad argument");
+    // torch layouts: Conv2d w[co][ci][taps], ConvTranspose2d w[ci][co][taps]; the reduction channel of the
+    // forward pass is ci, of the data gradient co
+    *d0 = g->transposed ? g->ci : g->co;
+    *d1 = g->transposed ? g->co : g->ci;
+    const int reduce_is_d1 = g->transposed ? (direction == 1) : (direction == 0);
+    *swap = reduce_is_d1;
+    const int A = reduce_is_d1 ? *d1 : *d0, B = reduce_is_d1 ? *d0 : *d1;
+    *elems = (g->groups == 1 && A % 8 == 0) ? (int64_t)((B + 31) / 32) * g->kh * g->kw * A * 32 : 0;   // 0: no MFMA image
+    return SENAS_OK;
+}
+
+extern "C" int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream) {
+    SENAS_REQUIRE(items_dev && n > 0 && max_elems > 0, "pack_batched: bad argument");
+    dim3 grid((unsigned)((max_elems + 255) / 256), n);
+    hipLaunchKernelGGL(senas::pack_weights_batched_kernel, grid, dim3(256), 0, senas::as_stream(stream),
+                       reinterpret_cast<const senas::PackItem*>(items_dev));
+    return senas::launch_status("pack_batched");
+}

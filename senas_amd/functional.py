@@ -96,6 +96,15 @@ class _NoSpan(object):
 TIMER = None
 _NOSPAN = _NoSpan()
 
+# (weight data_ptr, direction) -> packed fragment image kept fresh by senas_amd.packing.WeightPacker;
+# empty: every convolution call repacks its own weights
+PACKED = {}
+
+
+def _packed(w, direction):
+    img = PACKED.get((w.data_ptr(), direction))
+    return None if img is None else img.data_ptr()
+
 
 def _span(kind, g, x, w, y):
     if TIMER is None:
@@ -139,7 +148,7 @@ class _Conv2d(torch.autograd.Function):
         ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
         with _span('conv_fwd', g, x, w, y):
             _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
-                                          ws.data_ptr(), _stream()), 'senas_conv2d_fwd')
+                                          ws.data_ptr(), _packed(w, 0), _stream()), 'senas_conv2d_fwd')
         ctx.save_for_backward(x, w)
         ctx.g, ctx.in_relu = g, int(in_relu)
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
@@ -160,7 +169,7 @@ class _Conv2d(torch.autograd.Function):
             dx = torch.empty_like(x, memory_format=CL)
             with _span('conv_dgrad', g, x, w, dy):
                 _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
-                                                   x.data_ptr(), ws.data_ptr(), _stream()), 'senas_conv2d_bwd_data')
+                                                   x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             wsz = zeros32(ws.numel() // 4, x.device)          # pre-zeroed split-K image: no memset launch per conv

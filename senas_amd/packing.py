@@ -1,0 +1,66 @@
+"""Packed-weight cache: the MFMA kernels read convolution weights from a fragment image
+(`conv_mfma.hip`); weights change once per optimizer step, so the images of ALL dense convolutions of a
+model are refreshed by ONE launch at the start of a forward pass (`senas_pack_batched`) instead of one
+repack launch per convolution call (~200 per derived step, ~1 500 per supernet pass).
+
+Without a packer every `senas_conv2d_*` call repacks its own weights -- same results, more launches.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import functional as F
+
+
+class _Item(C.Structure):
+    """senas_pack_item (include/senas_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('d0', C.c_int32), ('d1', C.c_int32), ('taps', C.c_int32),
+                ('swap', C.c_int32), ('elems', C.c_int64)]
+
+
+class WeightPacker(object):
+    def __init__(self, model):
+        L = _lib.lib()
+        self.entries = []            # (weight parameter, direction, image tensor)
+        items = []
+        seen = set()
+        for m in model.modules():
+            if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) or m.groups != 1 or id(m.weight) in seen:
+                continue
+            seen.add(id(m.weight))
+            w = m.weight
+            tr = isinstance(m, nn.ConvTranspose2d)
+            ci, co = (w.shape[0], w.shape[1]) if tr else (w.shape[1], w.shape[0])
+            g = F.ConvGeom(1, 8, 8, ci, 8, 8, co, w.shape[2], w.shape[3], 1, 0, 1, int(tr), 1)   # only channel/tap fields matter
+            for direction in (0, 1):
+                d0, d1, swap, elems = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+                _lib.check(L.senas_conv2d_pack_layout(C.byref(g), direction, C.byref(d0), C.byref(d1), C.byref(swap),
+                                                      C.byref(elems)), 'senas_conv2d_pack_layout')
+                if elems.value == 0:
+                    continue
+                img = torch.empty(elems.value, device=w.device, dtype=torch.float32)
+                self.entries.append((w, direction, img))
+                items.append(_Item(w.data_ptr(), img.data_ptr(), d0.value, d1.value, w.shape[2] * w.shape[3], swap.value,
+                                   elems.value))
+        self.n = len(items)
+        self.max_elems = max((it.elems for it in items), default=0)
+        if self.n:
+            raw = bytes((_Item * self.n)(*items))
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.entries[0][0].device)
+        self.images = {(w.data_ptr(), d): img for w, d, img in self.entries}
+
+    def refresh(self):
+        """Repack every weight (one launch).  Call after the optimizer changed the weights, before the
+        next forward; it is part of the captured graph when the step is graphed."""
+        if self.n:
+            _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
+                       'senas_pack_batched')
+
+    def install(self):
+        F.PACKED = self.images
+
+    def uninstall(self):
+        if F.PACKED is self.images:
+            F.PACKED = {}

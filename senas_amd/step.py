@@ -10,6 +10,7 @@ capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
 import torch
 
 from .arena import reset_arena
+from .packing import WeightPacker
 from .parallel import GradAllReducer
 
 
@@ -22,11 +23,14 @@ class GraphedForwardBackward(object):
         self.loss = None
         self.graph = None
         self.graph_grads = None
+        self.packer = WeightPacker(model)          # one launch per step refreshes every conv's weight image
+        self.packer.install()
         if use_graph:
             self._capture(warmup)
 
     def _eager(self):
         self.reducer.zero_grad()
+        self.packer.refresh()
         loss = self.criterion(self.model(self.x), self.y)
         loss.backward()
         return loss.detach()

@@ -376,3 +376,48 @@ def test_conv_kernels_vs_oracle(case):
     ref64 = ref.detach().double()
     exp = torch.stack([ref64.sum((2, 3)), (ref64 ** 2).sum((2, 3))], -1)
     close(st.float(), exp.float().numpy(), 'stats', rel=2e-5)
+
+
+def test_weight_packer_and_graph_step_match_eager():
+    """The cached weight images (one batched repack per step) and the HIP-graph replay must give the same
+    step as plain eager calls that repack per launch: same loss trajectory, same weights after 3 steps."""
+    import copy
+    from senas_amd import functional as F
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.step import TrainStep
+    torch.manual_seed(0)
+    base = SenasModel(2, 1, c=16, depth=4, genotype=senas_node_4)
+    _randomize(base, 5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 64, 64, generator=g).to(dev())
+    y = torch.randint(0, 2, (2, 64, 64), generator=g).to(dev())
+    crit = SegmentationLosses('dice_ce')
+    results = []
+    for mode in ('eager', 'graph'):
+        net = copy.deepcopy(base).to(dev()).train()
+        opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)
+        losses = []
+        if mode == 'eager':
+            assert not F.PACKED
+            for _ in range(3):
+                opt.zero_grad()
+                loss = crit(net(x), y)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 5)
+                opt.step()
+                losses.append(float(loss))
+        else:
+            step = TrainStep(net, crit, opt, x, y, use_graph=True)
+            assert step.graphed and F.PACKED
+            # the capture warm-up ran forward/backward (BN running stats moved) but never stepped the optimizer
+            for _ in range(3):
+                losses.append(float(step()))
+            step.fb.packer.uninstall()
+        results.append((losses, {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if 'running' not in k and 'num_batches' not in k}))
+    (l0, w0), (l1, w1) = results
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
+    for k in w0:
+        close(w1[k], w0[k], 'weights after 3 steps ' + k, rel=2e-4)

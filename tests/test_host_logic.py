@@ -30,7 +30,7 @@ def test_abi_header_matches_binding_and_library():
     lib = _lib.lib()                      # raises if libsenas_hip.so is missing or lacks a symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.senas_abi_version() == 2
+    assert lib.senas_abi_version() == 3
     # argument counts of the binding agree with the header
     for name, (_, args) in _lib.SIGNATURES.items():
         m = re.search(r'\b%s\s*\(([^;]*?)\)\s*;' % name, hdr, flags=re.S)
@@ -46,7 +46,7 @@ def test_invalid_arguments_are_reported_not_executed():
     from senas_amd import _lib
     lib = _lib.lib()
     g = _lib.ConvGeom(1, 8, 8, 4, 9, 9, 4, 3, 3, 1, 1, 1, 0, 1)      # ho/wo inconsistent with the rest
-    assert lib.senas_conv2d_fwd(C.byref(g), None, None, None, 0, None, None, None) == -1
+    assert lib.senas_conv2d_fwd(C.byref(g), None, None, None, 0, None, None, None, None) == -1
     assert b'geometry' in lib.senas_last_error()
     assert lib.senas_relu_fwd(16, None, None, None) == -1
     assert lib.senas_chan_stats(1, 16, 300, None, None, None) == -1

@@ -196,8 +196,20 @@ def main():
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         per_launch_ms = a['ms'] / a['launches']
         tflops = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this
+        # very command, averaged per kernel symbol, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+        # gfx950; committed as profiles/r1_pmc_traffic.json by tools/pmc_traffic.py (null if not collected)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))
+            rec = pmc['kernels'].get(name)
+            if rec:
+                traffic = int((2 * rec['fetch_kb_avg'] + rec['write_kb_avg']) * 1024)
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(tflops, 3), 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': None, 'launches': a['launches'],
+                'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'launches': a['launches'],
+                'algorithmic_bytes_per_launch': int(a['bytes'] / a['launches']),
                 'avg_launch_ms': round(per_launch_ms, 4),
                 'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 3),
                 'share_of_step': round((a['ms'] / probe_steps) / (1e3 * elapsed / args.steps), 3),

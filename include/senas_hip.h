@@ -183,6 +183,11 @@ int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const flo
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 
+/* Name of the kernel a convolution call dispatches to, as rocprofv3 prints the symbol (without the
+ * `senas::` prefix and argument list).  which: 0 forward, 1 data gradient, 2 weight gradient.
+ * For attributing measured time to profile rows; the string is owned by the library.              */
+const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int which);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 const char* senas_last_error(void);
 int senas_abi_version(void);

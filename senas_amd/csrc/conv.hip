@@ -543,3 +543,54 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
     return launch_status("conv_wgrad");
 }
+
+// Which kernel a convolution call dispatches to (same predicates as the launchers above), as the readable
+// symbol rocprofv3 prints -- lets bench.py attribute HIP-event time to the kernel the profile shows.
+// which: 0 forward, 1 data gradient, 2 weight gradient.
+extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int which) {
+    if (!geom_ok(g) || which < 0 || which > 2) return "invalid";
+    const bool tr = g->transposed != 0;
+    if (which == 2) {
+        if (g->groups != 1) {
+            const int c4 = g->ci / 4;
+            const bool two_stage = g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64;
+            if (two_stage) return g->kh == 3 ? "dwconv_wgrad_part_kernel<3>" : "dwconv_wgrad_part_kernel<5>";
+            return g->kh == 3 ? "dwconv_wgrad_kernel<3>" : "dwconv_wgrad_kernel<5>";
+        }
+        WgradGeom wg = !tr ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
+                           : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        if (!tr && lds_wgrad_ok(wg)) {
+            const int uw = (g->kh * g->kw * (wg.A / 32) + 7) / 8;
+            const int u = uw <= 2 ? 2 : (uw <= 4 ? 4 : 5);
+            static char buf[8][48];
+            static int slot = 0;
+            char* b = buf[slot++ & 7];
+            snprintf(b, 48, "wgrad_lds_kernel<%d, %d>", wg.A, u);
+            return b;
+        }
+        if (mfma_wgrad_ok(wg)) return wg.A % 8 != 0 ? "wgrad_smallc_mfma_kernel<5>" : "wgrad_mfma_kernel<7>";
+        return "conv_wgrad_kernel";
+    }
+    if (g->groups != 1) {
+        const bool tg = (which == 0) == tr;
+        const bool v4 = (which == 0 ? g->co : g->ci) % 4 == 0;
+        return tg ? (v4 ? "dwconv_kernel<true, 4>" : "dwconv_kernel<true, 1>") : (v4 ? "dwconv_kernel<false, 4>" : "dwconv_kernel<false, 1>");
+    }
+    GatherGeom gg = which == 0 ? GatherGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil}
+                               : GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    const bool tg = (which == 0) == tr;                 // transposed gather: ConvTranspose2d forward, Conv2d data gradient
+    if (!tr && lds_gather_ok(gg)) {
+        const long blocks8 = (long)((gg.wout + 31) / 32) * ((gg.hout + 7) / 8) * gg.n * ((gg.cout + 31) / 32);
+        const bool big = blocks8 >= 512 && gg.hout >= 8;
+        return tg ? (big ? "conv_lds_kernel<true, 2>" : "conv_lds_kernel<true, 1>") : (big ? "conv_lds_kernel<false, 2>" : "conv_lds_kernel<false, 1>");
+    }
+    if (mfma_gather_ok(gg, tg)) {
+        const bool s2 = tg && gg.stride == 2;
+        const long per_phase = (long)gg.n * (s2 ? (gg.hout / 2) * (gg.wout / 2) : gg.hout * gg.wout);
+        const long px = per_phase * (s2 ? 4 : 1);
+        if (px >= 256L * 512) return tg ? "conv_mfma_kernel<true, 2, 1>" : "conv_mfma_kernel<false, 2, 1>";
+        if (px <= 32L * 1024) return tg ? "conv_mfma_kernel<true, 1, 4>" : "conv_mfma_kernel<false, 1, 4>";
+        return tg ? "conv_mfma_kernel<true, 1, 1>" : "conv_mfma_kernel<false, 1, 1>";
+    }
+    return tg ? "conv_direct_kernel<TG>" : "conv_direct_kernel";
+}

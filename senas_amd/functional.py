@@ -109,10 +109,10 @@ def _packed(w, direction):
 def _span(kind, g, x, w, y):
     if TIMER is None:
         return _NOSPAN
-    dense = g.groups == 1
     macs = (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
-    shape = '%s%dx%d d%d s%d %s%d->%d' % ('T' if g.transposed else '', g.kh, g.kw, g.dil, g.stride, '' if dense else 'dw ', g.ci, g.co)
-    return TIMER.span('%s[%s]' % (kind, shape), 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()))
+    which = {'conv_fwd': 0, 'conv_dgrad': 1, 'conv_wgrad': 2}[kind]
+    name = _lib.lib().senas_conv2d_kernel_name(C.byref(g), which).decode()      # the symbol rocprofv3 reports
+    return TIMER.span(name, 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()))
 
 
 # ------------------------------------------------------------------------------------------ convolution

@@ -75,6 +75,7 @@ int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, fl
 // wgrad_lds.hip (stride-1 "same" weight gradient, persistent, both operands in LDS); ws zeroed by the caller
 bool lds_wgrad_ok(const WgradGeom& g);
 int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, hipStream_t st);
+void lds_wgrad_name(const WgradGeom& g, char* buf, int len);
 void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st);
 
 // conv_lds.hip (stride-1 "same" convolutions with the input window staged in LDS)
@@ -82,6 +83,19 @@ bool lds_gather_ok(const GatherGeom& g);
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st);
+
+// conv_thin.hip (one side of the GEMM view has <= 4 channels: HBM-bound single-pass kernels; weights in torch layout)
+bool thin_k_ok(const GatherGeom& g);
+template <bool TG>
+int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
+                  const float* mask, double* stats, hipStream_t st);
+bool thin_n_ok(const GatherGeom& g);
+int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
+                  double* stats, hipStream_t st);
+bool thin_n_wgrad_ok(const WgradGeom& g);
+int64_t thin_n_wgrad_ws_bytes(const WgradGeom& g);
+int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part, int i_relu, int g_relu, int* nblk_out,
+                        hipStream_t st);
 
 // V consecutive floats (V == 4: one 16-byte access; the caller guarantees 16-byte alignment)
 template <int V>

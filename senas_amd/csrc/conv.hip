@@ -384,7 +384,12 @@ extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
     const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
     const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
-    return (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
+    int64_t bytes = (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
+    if (small <= 4) {                                    // thin weight gradient: per-block partials
+        const int64_t part = (int64_t)512 * g->ci * g->co * g->kh * g->kw * sizeof(float) + 256;
+        if (part > bytes) bytes = part;
+    }
+    return bytes;
 }
 
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
@@ -407,6 +412,12 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
         }
         return launch_status("dwconv_fwd");
     }
+    // thin shapes (stem, head): single-pass HBM-bound kernels that read the torch-layout weights directly
+    if (thin_k_ok(gg)) {
+        if (!g->transposed) return launch_thin_k<false>(gg, x, w, g->ci, 1, y, in_relu, nullptr, stats, st);
+        return launch_thin_k<true>(gg, x, w, g->co, 0, y, in_relu, nullptr, stats, st);
+    }
+    if (!g->transposed && thin_n_ok(gg)) return launch_thin_n(gg, x, w, g->ci, 1, y, in_relu, stats, st);
     SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
@@ -452,6 +463,10 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
             else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
         }
         return launch_status("dwconv_bwd_data");
+    }
+    if (thin_k_ok(gg)) {
+        if (!g->transposed) return launch_thin_k<true>(gg, dy, w, g->ci, 0, dx, 0, mask, nullptr, st);
+        return launch_thin_k<false>(gg, dy, w, g->co, 1, dx, 0, mask, nullptr, st);
     }
     SENAS_REQUIRE(ws, "conv2d_bwd_data: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
@@ -519,6 +534,16 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         else hipLaunchKernelGGL((dwconv_wgrad_kernel<5>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
         return launch_status("dwconv_wgrad");
     }
+    if (thin_n_wgrad_ok(wg)) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        int nblk = 0;
+        const int rc = launch_thin_n_wgrad(wg, I, G, reinterpret_cast<float*>(ws), i_relu, g_relu, &nblk, st);
+        if (rc != SENAS_OK) return rc;
+        const int n_elem = g->ci * g->co * taps;
+        hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw,
+                           n_elem, nblk);
+        return launch_status("wgrad_thin_n sum");
+    }
     if (!g->transposed && lds_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         float* wsp = reinterpret_cast<float*>(ws);
@@ -559,13 +584,15 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         }
         WgradGeom wg = !tr ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
                            : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        if (thin_n_wgrad_ok(wg)) {
+            if (g->kh == 3) return wg.B <= 2 ? "wgrad_thin_n_kernel<3, 2>" : "wgrad_thin_n_kernel<3, 4>";
+            return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";
+        }
         if (!tr && lds_wgrad_ok(wg)) {
-            const int uw = (g->kh * g->kw * (wg.A / 32) + 7) / 8;
-            const int u = uw <= 2 ? 2 : (uw <= 4 ? 4 : 5);
             static char buf[8][48];
             static int slot = 0;
             char* b = buf[slot++ & 7];
-            snprintf(b, 48, "wgrad_lds_kernel<%d, %d>", wg.A, u);
+            lds_wgrad_name(wg, b, 48);
             return b;
         }
         if (mfma_wgrad_ok(wg)) return wg.A % 8 != 0 ? "wgrad_smallc_mfma_kernel<5>" : "wgrad_mfma_kernel<7>";
@@ -579,6 +606,8 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
     GatherGeom gg = which == 0 ? GatherGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil}
                                : GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
     const bool tg = (which == 0) == tr;                 // transposed gather: ConvTranspose2d forward, Conv2d data gradient
+    if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
+    if (which == 0 && !tr && thin_n_ok(gg)) return gg.cout <= 2 ? "conv_thin_n_kernel<2>" : "conv_thin_n_kernel<4>";
     if (!tr && lds_gather_ok(gg)) {
         const long blocks8 = (long)((gg.wout + 31) / 32) * ((gg.hout + 7) / 8) * gg.n * ((gg.cout + 31) / 32);
         const bool big = blocks8 >= 512 && gg.hout >= 8;

@@ -1,0 +1,330 @@
+// "Thin" convolutions, NHWC fp32, gfx950: one side of the GEMM view is a handful of channels, so the
+// launch is bound by HBM (one pass over the fat tensor), not by the matrix cores.  On the path:
+//   stem   Conv2d(1 -> c, 7x7)      forward            -> thin-K gather   (K = taps x 1)
+//   head   Conv2d(c -> n_class, 3x3) data gradient     -> thin-K transposed gather (K = taps x n_class)
+//   head   forward                                     -> thin-N gather   (n_class outputs per pixel)
+//   head   weight gradient                             -> thin-N wgrad
+// Lane mapping everywhere: the fat tensor's channel axis is split in 16-byte pieces over Q consecutive
+// lanes, so a wave touches whole pixels (Q x 16 contiguous bytes each) with every load/store instruction.
+// Weights are read in the torch layout and transposed while they are copied into LDS (no repack launch).
+#include "common.h"
+
+namespace senas {
+
+namespace {
+
+// torch weight src[d0][d1][taps] viewed as [tap][A][B] (swap == 0: A = d0, B = d1; swap == 1: A = d1, B = d0)
+__device__ __forceinline__ float weight_at(const float* __restrict__ src, int d1, int taps, int swap, int t, int a, int b) {
+    const int s0 = swap ? b : a, s1 = swap ? a : b;
+    return src[((size_t)s0 * d1 + s1) * taps + t];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// thin-K gather: cin <= 4, cout = 4*Q (Q a power of two <= 16).  thread = (pixel lane, 4 output channels).
+// grid = (pixel chunks of one image, n); block 256; dynamic LDS = weights [taps*cin][cout] + fp64 [cout][2].
+template <bool TG>
+__global__ __launch_bounds__(256) void conv_thin_k_kernel(GatherGeom g, const float* __restrict__ in,
+                                                          const float* __restrict__ w, int d1, int swap,
+                                                          float* __restrict__ out, int in_relu,
+                                                          const float* __restrict__ mask, double* __restrict__ stats,
+                                                          int passes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int taps = g.kh * g.kw;
+    const int wfloats = taps * g.cin * g.cout;
+    for (int i = threadIdx.x; i < wfloats; i += 256) {
+        const int b = i % g.cout, a = (i / g.cout) % g.cin, t = i / (g.cout * g.cin);
+        lds[i] = weight_at(w, d1, taps, swap, t, a, b);
+    }
+    double* sred = reinterpret_cast<double*>(lds + ((wfloats + 3) & ~3));
+    if (stats != nullptr && threadIdx.x < 2 * g.cout) sred[threadIdx.x] = 0.0;
+    __syncthreads();
+
+    const int Q = g.cout >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, ppb = 256 / Q;
+    const int n = blockIdx.y, hw = g.hout * g.wout;
+    const int p0 = blockIdx.x * ppb * passes;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < passes; ++it) {
+        const int pix = p0 + it * ppb + pl;
+        if (pix >= hw) break;
+        const int oy = pix / g.wout, ox = pix - oy * g.wout;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < g.kh; ++ky) {
+            int iy;
+            if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                int ix;
+                if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
+                const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin;
+                const float* wt = lds + (ky * g.kw + kx) * g.cin * g.cout + q * 4;
+                for (int ci = 0; ci < g.cin; ++ci) {
+                    float v = ip[ci];
+                    if (in_relu) v = fmaxf(v, 0.f);
+                    const float4 w4 = *reinterpret_cast<const float4*>(wt + ci * g.cout);
+                    acc[0] = fmaf(v, w4.x, acc[0]);
+                    acc[1] = fmaf(v, w4.y, acc[1]);
+                    acc[2] = fmaf(v, w4.z, acc[2]);
+                    acc[3] = fmaf(v, w4.w, acc[3]);
+                }
+            }
+        }
+        const size_t o = ((size_t)n * hw + pix) * g.cout + q * 4;
+        if (mask != nullptr) {
+            const float4 m = *reinterpret_cast<const float4*>(mask + o);
+            if (!(m.x > 0.f)) acc[0] = 0.f;
+            if (!(m.y > 0.f)) acc[1] = 0.f;
+            if (!(m.z > 0.f)) acc[2] = 0.f;
+            if (!(m.w > 0.f)) acc[3] = 0.f;
+        }
+        *reinterpret_cast<float4*>(out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += (double)acc[j];
+            ss[j] += (double)acc[j] * (double)acc[j];
+        }
+    }
+    if (stats != nullptr) {           // lanes that share q (stride Q inside the wave) -> LDS -> one atomic per channel per block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int o = Q; o < 64; o <<= 1) {
+                s[j] += __shfl_xor(s[j], o, 64);
+                ss[j] += __shfl_xor(ss[j], o, 64);
+            }
+        }
+        if ((threadIdx.x & 63) < Q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&sred[(q * 4 + j) * 2], s[j]);
+                atomicAdd(&sred[(q * 4 + j) * 2 + 1], ss[j]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * g.cout) atomicAdd(stats + (size_t)n * g.cout * 2 + threadIdx.x, sred[threadIdx.x]);
+    }
+}
+
+bool thin_k_ok(const GatherGeom& g) {
+    const int q = g.cout >> 2;
+    return g.cin <= 4 && g.cout % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin * g.cout <= 8192 &&
+           (long)g.n * g.hout * g.wout * g.cout < 0x7fffffffL && g.n <= 65535;
+}
+
+template <bool TG>
+int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
+                  const float* mask, double* stats, hipStream_t st) {
+    const int ppb = 256 / (g.cout >> 2), hw = g.hout * g.wout;
+    int passes = 8;
+    while (passes > 1 && (long)g.n * ((hw + ppb * passes - 1) / (ppb * passes)) < 1024) passes >>= 1;
+    dim3 grid((hw + ppb * passes - 1) / (ppb * passes), g.n);
+    const size_t bytes = (size_t)((g.kh * g.kw * g.cin * g.cout + 3) & ~3) * sizeof(float) + (size_t)2 * g.cout * sizeof(double);
+    hipLaunchKernelGGL((conv_thin_k_kernel<TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, mask, stats, passes);
+    return launch_status("conv_thin_k");
+}
+template int launch_thin_k<false>(const GatherGeom&, const float*, const float*, int, int, float*, int, const float*, double*, hipStream_t);
+template int launch_thin_k<true>(const GatherGeom&, const float*, const float*, int, int, float*, int, const float*, double*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// thin-N gather (plain): cout <= CO (2 or 4), cin = 4*Q (Q a power of two <= 16).
+// thread = (pixel lane, 4 input channels); the Q partial sums of a pixel are folded by shuffles.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const float* __restrict__ in,
+                                                          const float* __restrict__ w, int d1, int swap,
+                                                          float* __restrict__ out, int in_relu, double* __restrict__ stats,
+                                                          int passes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [taps*cin][CO] (zero-padded columns), then fp64 [CO][2]
+    const int taps = g.kh * g.kw;
+    const int rows = taps * g.cin;
+    for (int i = threadIdx.x; i < rows * CO; i += 256) {
+        const int b = i % CO, a = (i / CO) % g.cin, t = i / (CO * g.cin);
+        lds[i] = b < g.cout ? weight_at(w, d1, taps, swap, t, a, b) : 0.f;
+    }
+    double* sred = reinterpret_cast<double*>(lds + ((rows * CO + 3) & ~3));
+    if (threadIdx.x < 2 * CO) sred[threadIdx.x] = 0.0;
+    __syncthreads();
+
+    const int Q = g.cin >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, ppb = 256 / Q;
+    const int n = blockIdx.y, hw = g.hout * g.wout;
+    const int p0 = blockIdx.x * ppb * passes;
+    double s[CO], ss[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) s[j] = ss[j] = 0.0;
+    for (int it = 0; it < passes; ++it) {
+        const int pix = p0 + it * ppb + pl;
+        const bool live = pix < hw;                       // dead lanes keep shuffling with the live ones
+        const int pc = live ? pix : 0;
+        const int oy = pc / g.wout, ox = pc - oy * g.wout;
+        float acc[CO];
+#pragma unroll
+        for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            int iy;
+            if (!tap_src<false>(g, oy, ky, g.hin, iy)) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                int ix;
+                if (!tap_src<false>(g, ox, kx, g.win, ix)) continue;
+                float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + q * 4);
+                if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                const float* wt = lds + ((ky * g.kw + kx) * g.cin + q * 4) * CO;
+#pragma unroll
+                for (int j = 0; j < CO; ++j) {
+                    acc[j] = fmaf(v.x, wt[j], acc[j]);
+                    acc[j] = fmaf(v.y, wt[CO + j], acc[j]);
+                    acc[j] = fmaf(v.z, wt[2 * CO + j], acc[j]);
+                    acc[j] = fmaf(v.w, wt[3 * CO + j], acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CO; ++j)
+            for (int o = 1; o < Q; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (live && q == 0) {
+            float* op = out + ((size_t)n * hw + pix) * g.cout;
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                if (j < g.cout) {
+                    op[j] = acc[j];
+                    s[j] += (double)acc[j];
+                    ss[j] += (double)acc[j] * (double)acc[j];
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+            s[j] = wave_sum(s[j]);              // lanes with q != 0 hold zeros
+            ss[j] = wave_sum(ss[j]);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                atomicAdd(&sred[j * 2], s[j]);
+                atomicAdd(&sred[j * 2 + 1], ss[j]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * g.cout) atomicAdd(stats + (size_t)n * g.cout * 2 + threadIdx.x, sred[threadIdx.x]);
+    }
+}
+
+bool thin_n_ok(const GatherGeom& g) {
+    const int q = g.cin >> 2;
+    return g.cout <= 4 && g.cin % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin <= 2048 &&
+           (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL && g.n <= 65535;
+}
+
+int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
+                  double* stats, hipStream_t st) {
+    const int ppb = 256 / (g.cin >> 2), hw = g.hout * g.wout;
+    int passes = 8;
+    while (passes > 1 && (long)g.n * ((hw + ppb * passes - 1) / (ppb * passes)) < 1024) passes >>= 1;
+    dim3 grid((hw + ppb * passes - 1) / (ppb * passes), g.n);
+    const int co = g.cout <= 2 ? 2 : 4;
+    const size_t bytes = (size_t)((g.kh * g.kw * g.cin * co + 3) & ~3) * sizeof(float) + (size_t)2 * co * sizeof(double);
+    if (co == 2) hipLaunchKernelGGL((conv_thin_n_kernel<2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+    else hipLaunchKernelGGL((conv_thin_n_kernel<4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+    return launch_status("conv_thin_n");
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin-N weight gradient: B <= BB (2 or 4) gradient channels, A = 4*Q fat channels, KS x KS taps.
+//   part[block][(b*A + a)*taps + t] = sum over the block's pixels of I[p*s - pad + k*d][a] * G[p][b]
+// thread = (pixel lane, 4 channels of I) with taps*4*BB partial sums in registers; folded over the pixel
+// lanes by shuffles and over the 4 waves through LDS.  A second launch (dwconv_wgrad_sum_kernel) adds the
+// blocks' partials in a fixed order: no atomics, bitwise reproducible.
+template <int KS, int BB>
+__global__ __launch_bounds__(256) void wgrad_thin_n_kernel(WgradGeom g, const float* __restrict__ I,
+                                                           const float* __restrict__ G, float* __restrict__ part,
+                                                           int i_relu, int g_relu) {
+    constexpr int TAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][Q][PER]
+    const int Q = g.A >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
+    const int per_img = g.hg * g.wg;
+    const long total = (long)g.n * per_img;
+    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    if (p1 > total) p1 = total;
+    float acc[TAPS][4][BB];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < BB; ++j) acc[t][i][j] = 0.f;
+    for (long p = p0 + pl; p < p1; p += lanes) {
+        const int n = (int)(p / per_img), r = (int)(p - (long)n * per_img);
+        const int gy = r / g.wg, gx = r - gy * g.wg;
+        float gv[BB];
+#pragma unroll
+        for (int j = 0; j < BB; ++j) {
+            gv[j] = j < g.B ? G[(size_t)p * g.B + j] : 0.f;
+            if (g_relu) gv[j] = fmaxf(gv[j], 0.f);
+        }
+        const float* In = I + (size_t)n * g.hi * g.wi * g.A + q * 4;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = gy * g.stride - g.pad + ky * g.dil;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int ix = gx * g.stride - g.pad + kx * g.dil;
+                const bool ok = iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+                float iv[4];
+                ldv<4>(In + (ok ? (size_t)(iy * g.wi + ix) * g.A : 0), iv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = ok ? iv[i] : 0.f;
+                    if (i_relu) v = fmaxf(v, 0.f);
+#pragma unroll
+                    for (int j = 0; j < BB; ++j) acc[ky * KS + kx][i][j] = fmaf(v, gv[j], acc[ky * KS + kx][i][j]);
+                }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < BB; ++j) {
+                float v = acc[t][i][j];
+                for (int o = Q; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < Q) red[((wave * Q + lane) * TAPS + t) * 4 * BB + i * BB + j] = v;
+            }
+    __syncthreads();
+    const int n_elem = g.B * g.A * TAPS;
+    for (int e = threadIdx.x; e < n_elem; e += 256) {           // e = (b*A + a)*TAPS + t
+        const int t = e % TAPS, a = (e / TAPS) % g.A, b = e / (TAPS * g.A);
+        const int qq = a >> 2, i = a & 3;
+        float v = 0.f;
+        for (int wv = 0; wv < 4; ++wv) v += red[((wv * Q + qq) * TAPS + t) * 4 * BB + i * BB + b];
+        part[(size_t)blockIdx.x * n_elem + e] = v;
+    }
+}
+
+bool thin_n_wgrad_ok(const WgradGeom& g) {
+    const int q = g.A >> 2;
+    return g.B <= 4 && g.A % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh == g.kw && (g.kh == 1 || g.kh == 3);
+}
+
+int64_t thin_n_wgrad_ws_bytes(const WgradGeom& g) { return (int64_t)512 * g.B * g.A * g.kh * g.kw * sizeof(float); }
+
+// part: >= thin_n_wgrad_ws_bytes(g); returns the number of partial rows (blocks) written
+int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part, int i_relu, int g_relu, int* nblk_out,
+                        hipStream_t st) {
+    const long total = (long)g.n * g.hg * g.wg;
+    long nblk = (total + 255) / 256;
+    if (nblk > 512) nblk = 512;
+    g.chunk = (int)((total + nblk - 1) / nblk);
+    nblk = (total + g.chunk - 1) / g.chunk;
+    const int bb = g.B <= 2 ? 2 : 4;
+    const size_t bytes = (size_t)4 * (g.A >> 2) * g.kh * g.kw * 4 * bb * sizeof(float);
+#define SENAS_TW(KS, BB) hipLaunchKernelGGL((wgrad_thin_n_kernel<KS, BB>), dim3((unsigned)nblk), dim3(256), bytes, st, g, I, G, part, i_relu, g_relu)
+    if (g.kh == 3) { if (bb == 2) SENAS_TW(3, 2); else SENAS_TW(3, 4); }
+    else { if (bb == 2) SENAS_TW(1, 2); else SENAS_TW(1, 4); }
+#undef SENAS_TW
+    *nblk_out = (int)nblk;
+    return launch_status("wgrad_thin_n");
+}
+
+}  // namespace senas

@@ -28,32 +28,42 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 
 }  // namespace
 
-// A: in-channels (multiple of 32, <= 128); UW: accumulators per wave; grid = persistent blocks of 512 threads.
+// A: in-channels (multiple of 32, <= 128); UW: accumulators per wave; RS: row split -- the 8 waves form
+// 8/RS unit groups x RS row lanes: wave (ug, rs) owns units ug, ug + 8/RS, ... and the tile rows rs, rs + RS, ...
+// (few taps -> large RS, so a 1x1 or 3x3 kernel still keeps all 8 waves on the matrix cores; the row lanes'
+// partial sums meet in LDS before the one atomic pass).  grid = persistent blocks of 512 threads.
+// PFX: 16-byte pieces of the NEXT tile's X window each thread requests before the K loop of the current tile
+// and parks in registers until the loop is done (the G tile always travels that way), so the HBM/L2 latency
+// of staging hides behind the MFMAs; pieces beyond PFX*512 are fetched after the loop.
 // dynamic LDS: X window [(th + 2*halo) * (32 + 2*halo)][A] floats, then G tile [th * 32][32] floats.
-template <int A, int UW>
+template <int A, int UW, int RS, int PFX>
 __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ G, float* __restrict__ dwp,
                                                         int x_relu, int th, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int UG = 8 / RS;
+    constexpr int PP = A / 4;                    // 16-byte pieces per pixel of X
+    constexpr int XL = 512 / PP;                 // pixels of the window covered by one slot
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: unit tests below are scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+    const int rs = wave % RS, ug = wave / RS;
     const int r = lane & 31, h = lane >> 5;
     const int halo = g.pad;
     const int tile_w = TW + 2 * halo, tile_h = th + 2 * halo;
     float* xs = lds;
     float* gs = lds + tile_h * tile_w * A;
+    float4* xs4 = reinterpret_cast<float4*>(xs);
+    float4* gs4 = reinterpret_cast<float4*>(gs);
     constexpr int a_tiles = A / 32;
     const int taps = g.kh * g.kw;
     const int units = taps * a_tiles;
 
-    // this wave's units: u = wave + 8*t
+    // this wave's units: u = ug + UG*t; slots past the last unit reuse unit 0's operands
     int uoff[UW];                 // LDS float offset of the unit's tap shift + channel slice
-    bool uok[UW];
 #pragma unroll
     for (int t = 0; t < UW; ++t) {
-        const int u = wave + 8 * t;
-        uok[t] = u < units;
-        const int uc = uok[t] ? u : 0;
+        const int u = ug + UG * t;
+        const int uc = u < units ? u : 0;
         const int tap = uc / a_tiles, at = uc - tap * a_tiles;
         const int ky = tap / g.kw, kx = tap - ky * g.kw;
         uoff[t] = ((ky * g.dil) * tile_w + kx * g.dil) * A + at * 32 + r;
@@ -64,97 +74,190 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
+    // staging geometry of this thread (tile-independent): slot k holds window pixel k*XL + xpl, piece xq
+    const int xq = threadIdx.x % PP, xpl = threadIdx.x / PP;       // threads with xpl >= XL idle while X is staged (A = 96)
+    const int xslot = xpl * PP + xq;
+    const int ty0 = xpl / tile_w, tx0 = xpl - ty0 * tile_w;
+    const int wpix = tile_h * tile_w;            // pixels in the X window
+    const int gpix = th * TW;                    // pixels in the G tile
+    const int gq = threadIdx.x & 7, gpl = threadIdx.x >> 3;      // G: 8 pieces per pixel, 64 pixels per slot
     const int per_img = tiles_x * tiles_y;
     const int ntiles = g.n * per_img;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float4 px[PFX > 0 ? PFX : 1], pg[4];
+
+    // request the first PFX slots of X and the whole G tile of `tile` (loads only; borders resolved in commit)
+    auto issue = [&](int tile) {
         const int n = tile / per_img, tr = tile - n * per_img;
         const int oy0 = (tr / tiles_x) * th, ox0 = (tr % tiles_x) * TW;
-        __syncthreads();                                  // previous tile's readers are done
-        // ---- stage X window (A/4 16-byte pieces per pixel) and G tile (8 pieces per pixel, B padded to 32)
-        {
-            const float* src = X + (size_t)n * g.hi * g.wi * A;
-            constexpr int PP = A / 4;
-            const int pieces = tile_h * tile_w * PP;
-            float4* xs4 = reinterpret_cast<float4*>(xs);
-            for (int base = 0; base < pieces; base += 512 * 4) {
-                float4 v[4];
-                int dst[4];
+        const float* src = X + (size_t)n * g.hi * g.wi * A + xq * 4;
+        int ty = ty0, tx = tx0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = base + u * 512 + threadIdx.x;
-                    const int pix = idx / PP, q = idx - pix * PP;
-                    const int ty = pix / tile_w, tx = pix - ty * tile_w;
-                    const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
-                    const bool inb = idx < pieces && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
-                    dst[u] = idx < pieces ? idx : -1;
-                    v[u] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.wi + ix) * A + q * 4 : 0));
-                    if (!inb) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+        for (int k = 0; k < PFX; ++k) {
+            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const bool inb = xpl < XL && k * XL + xpl < wpix && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+            px[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.wi + ix) * A : 0));
+            tx += XL;
+            { const int w1 = tx >= tile_w; tx -= w1 ? tile_w : 0; ty += w1; const int w2 = tx >= tile_w; tx -= w2 ? tile_w : 0; ty += w2; }   // XL <= 64 <= 2*tile_w
+        }
+        if (g.B == 32) {
+            const float* gsrc = G + (size_t)n * g.hg * g.wg * 32 + gq * 4;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (x_relu) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
-                    if (dst[u] >= 0) xs4[dst[u]] = v[u];
-                }
-            }
-            const float* gsrc = G + (size_t)n * g.hg * g.wg * g.B;
-            if (g.B == 32) {                               // full rows: 8 16-byte pieces per pixel, 4 in flight
-                float4* gs4 = reinterpret_cast<float4*>(gs);
-                const int gpieces = th * TW * 8;
-                for (int base = 0; base < gpieces; base += 512 * 4) {
-                    float4 v[4];
-                    int dst[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int idx = base + u * 512 + threadIdx.x;
-                        const int pix = idx >> 3, q = idx & 7;
-                        const int py = pix / TW, px = pix - py * TW;
-                        const int gy = oy0 + py, gx = ox0 + px;
-                        const bool inb = idx < gpieces && gy < g.hg && gx < g.wg;
-                        dst[u] = idx < gpieces ? idx : -1;
-                        v[u] = *reinterpret_cast<const float4*>(gsrc + (inb ? ((size_t)gy * g.wg + gx) * 32 + q * 4 : 0));
-                        if (!inb) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (dst[u] >= 0) gs4[dst[u]] = v[u];
-                }
-            } else {
-                for (int idx = threadIdx.x; idx < th * TW * 32; idx += 512) {   // B < 32: zero-pad the columns
-                    const int pix = idx >> 5, b = idx & 31;
-                    const int py = pix / TW, px = pix - py * TW;
-                    const int gy = oy0 + py, gx = ox0 + px;
-                    float v = 0.f;
-                    if (b < g.B && gy < g.hg && gx < g.wg) v = gsrc[((size_t)gy * g.wg + gx) * g.B + b];
-                    gs[idx] = v;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int pix = k * 64 + gpl;
+                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                const bool inb = pix < gpix && gy < g.hg && gx < g.wg;
+                pg[k] = *reinterpret_cast<const float4*>(gsrc + (inb ? ((size_t)gy * g.wg + gx) * 32 : 0));
             }
         }
+    };
+    // registers -> LDS (ReLU, zero borders), then whatever did not fit in the prefetch slots
+    auto commit = [&](int tile) {
+        const int n = tile / per_img, tr = tile - n * per_img;
+        const int oy0 = (tr / tiles_x) * th, ox0 = (tr % tiles_x) * TW;
+        int ty = ty0, tx = tx0;
+#pragma unroll
+        for (int k = 0; k < PFX; ++k) {
+            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const bool live = xpl < XL && k * XL + xpl < wpix;
+            const bool inb = live && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+            float4 v = px[k];
+            if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) xs4[k * XL * PP + xslot] = v;
+            tx += XL;
+            { const int w1 = tx >= tile_w; tx -= w1 ? tile_w : 0; ty += w1; const int w2 = tx >= tile_w; tx -= w2 ? tile_w : 0; ty += w2; }   // XL <= 64 <= 2*tile_w
+        }
+        const float* src = X + (size_t)n * g.hi * g.wi * A + xq * 4;
+        for (int k0 = PFX; k0 * XL < wpix; k0 += 4) {           // remainder, 4 loads in flight
+            float4 v[4];
+            bool ok[4], lv[4];
+            int tyy = ty, txx = tx;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iy = oy0 - halo + tyy, ix = ox0 - halo + txx;
+                lv[u] = xpl < XL && (k0 + u) * XL + xpl < wpix;
+                ok[u] = lv[u] && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
+                v[u] = *reinterpret_cast<const float4*>(src + (ok[u] ? ((size_t)iy * g.wi + ix) * A : 0));
+                txx += XL;
+                { const int w1 = txx >= tile_w; txx -= w1 ? tile_w : 0; tyy += w1; const int w2 = txx >= tile_w; txx -= w2 ? tile_w : 0; tyy += w2; }
+            }
+            ty = tyy; tx = txx;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (x_relu) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
+                if (!ok[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lv[u]) xs4[(k0 + u) * XL * PP + xslot] = v[u];
+            }
+        }
+        if (g.B == 32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pix = k * 64 + gpl;
+                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                float4 v = pg[k];
+                if (!(gy < g.hg && gx < g.wg)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pix < gpix) gs4[k * 512 + threadIdx.x] = v;
+            }
+        } else {
+            const float* gsrc = G + (size_t)n * g.hg * g.wg * g.B;
+            for (int idx = threadIdx.x; idx < gpix * 32; idx += 512) {   // B < 32: zero-pad the columns
+                const int pix = idx >> 5, b = idx & 31;
+                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                float v = 0.f;
+                if (b < g.B && gy < g.hg && gx < g.wg) v = gsrc[((size_t)gy * g.wg + gx) * g.B + b];
+                gs[idx] = v;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                  // previous tile's readers are done
+        commit(tile);
         __syncthreads();
-        // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15)
-        for (int row = 0; row < th; ++row) {
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);     // in flight during the K loop
+        // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15).
+        // Straight-line code: slots past the last unit compute on unit 0's operands and are dropped in the
+        // epilogue (they sit in the shadow of the waves that own a real unit there), and the operands of step
+        // s+1 are requested before the MFMAs of step s are issued.
+        for (int row = rs; row < th; row += RS) {
             const float* gp = gs + (row * TW + 16 * h) * 32 + r;
             const float* xp = xs + (row * tile_w + 16 * h) * A;
+            float b = gp[0], a[UW];
+#pragma unroll
+            for (int t = 0; t < UW; ++t) a[t] = xp[uoff[t]];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float b = gp[s * 32];
+                float bn = 0.f, an[UW];
+                if (s < 15) {
+                    bn = gp[(s + 1) * 32];
 #pragma unroll
-                for (int t = 0; t < UW; ++t) {
-                    const float a = xp[uoff[t] + s * A];
-                    if (uok[t]) acc[t] = mfma32(a, b, acc[t]);           // wave-uniform
+                    for (int t = 0; t < UW; ++t) an[t] = xp[uoff[t] + (s + 1) * A];
+                }
+#pragma unroll
+                for (int t = 0; t < UW; ++t) acc[t] = mfma32(a[t], b, acc[t]);
+                if (s < 15) {
+                    b = bn;
+#pragma unroll
+                    for (int t = 0; t < UW; ++t) a[t] = an[t];
                 }
             }
         }
     }
     // ---- one atomic pass per block: dwp[tap][a][32]
-    if (r < g.B) {
+    if (RS == 1) {
+        if (r < g.B) {
 #pragma unroll
-        for (int t = 0; t < UW; ++t) {
-            const int u = wave + 8 * t;
-            if (u < units) {
-                const int tap = u / a_tiles, abase = (u - tap * a_tiles) * 32;
+            for (int t = 0; t < UW; ++t) {
+                const int u = ug + UG * t;
+                if (u < units) {
+                    const int tap = u / a_tiles, abase = (u - tap * a_tiles) * 32;
 #pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    atomicAdd(&dwp[((size_t)tap * A + abase + acc_row(v, h)) * 32 + r], acc[t][v]);
+                    for (int v = 0; v < 16; ++v)
+                        atomicAdd(&dwp[((size_t)tap * A + abase + acc_row(v, h)) * 32 + r], acc[t][v]);
+                }
+            }
+        }
+    } else {
+        // the RS row lanes of a unit group fold their accumulators pairwise through LDS (the staging buffers are
+        // free now): log2(RS) rounds of "upper half stores, lower half adds", 16-byte conflict-free accesses
+        // ([slot][quad][lane] float4), then row lane 0 issues the atomics from registers.
+        float4* fold = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int step = RS / 2; step >= 1; step >>= 1) {
+            __syncthreads();
+            if (rs >= step && rs < 2 * step) {
+                const int slot = ug * step + (rs - step);
+#pragma unroll
+                for (int t = 0; t < UW; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fold[((slot * UW + t) * 4 + q) * 64 + lane] =
+                            make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+            }
+            __syncthreads();
+            if (rs < step) {
+                const int slot = ug * step + rs;
+#pragma unroll
+                for (int t = 0; t < UW; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 p = fold[((slot * UW + t) * 4 + q) * 64 + lane];
+                        acc[t][4 * q] += p.x; acc[t][4 * q + 1] += p.y; acc[t][4 * q + 2] += p.z; acc[t][4 * q + 3] += p.w;
+                    }
+            }
+        }
+        if (rs == 0 && r < g.B) {
+#pragma unroll
+            for (int t = 0; t < UW; ++t) {
+                const int u = ug + UG * t;
+                if (u < units) {
+                    const int tap = u / a_tiles, abase = (u - tap * a_tiles) * 32;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        atomicAdd(&dwp[((size_t)tap * A + abase + acc_row(v, h)) * 32 + r], acc[t][v]);
+                }
             }
         }
     }
@@ -164,21 +267,37 @@ static size_t wgrad_lds_bytes(const WgradGeom& g, int th) {
     return ((size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * g.A + (size_t)th * TW * 32) * sizeof(float);
 }
 
+// (accumulators per wave, row split) for a unit count; 0 = not covered
+static void wgrad_lds_shape(int units, int& uw, int& rs) {
+    if (units <= 1) { uw = 1; rs = 8; }
+    else if (units <= 2) { uw = 2; rs = 8; }
+    else if (units <= 4) { uw = 4; rs = 8; }
+    else if (units <= 10) { uw = 5; rs = 4; }
+    else if (units <= 20) { uw = 5; rs = 2; }
+    else if (units <= 28) { uw = 7; rs = 2; }
+    else if (units <= 36) { uw = 9; rs = 2; }
+    else { uw = 0; rs = 0; }
+}
+
 bool lds_wgrad_ok(const WgradGeom& g) {
     if (g.stride != 1 || g.B > 32 || g.A % 32 != 0 || g.A > 128) return false;
     if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hg != g.hi || g.wg != g.wi) return false;
     if (g.wg < TW || g.hg < 8) return false;
     const int units = g.kh * g.kw * (g.A / 32);
-    if (units > 40) return false;
+    int uw, rs;
+    wgrad_lds_shape(units, uw, rs);
+    if (uw == 0) return false;
     return wgrad_lds_bytes(g, 4) <= 150 * 1024 && (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
 }
 
-template <int A, int UW>
+template <int A, int UW, int RS, int PFX>
 static int launch_one(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, int th, hipStream_t st) {
-    const size_t bytes = wgrad_lds_bytes(g, th);
+    size_t bytes = wgrad_lds_bytes(g, th);
+    const size_t fold = RS > 1 ? (size_t)4 * UW * 4096 : 0;      // epilogue: 4 storing waves x UW accumulators x 4 KiB
+    if (fold > bytes) bytes = fold;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, UW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, UW, RS, PFX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
@@ -186,9 +305,22 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
     const int tiles_x = (g.wg + TW - 1) / TW, tiles_y = (g.hg + th - 1) / th;
     const int ntiles = g.n * tiles_x * tiles_y;
     const int blocks = ntiles < 256 ? ntiles : 256;            // one persistent block per CU
-    hipLaunchKernelGGL((wgrad_lds_kernel<A, UW>), dim3(blocks), dim3(512), bytes, st, g, X, G, ws, x_relu, th, tiles_x, tiles_y);
+    hipLaunchKernelGGL((wgrad_lds_kernel<A, UW, RS, PFX>), dim3(blocks), dim3(512), bytes, st, g, X, G, ws, x_relu, th, tiles_x, tiles_y);
     return launch_status("wgrad_lds");
 }
+
+// the instantiations: (A, units) pairs that exist are A in {32, 64, 96, 128} x odd square kernels 1, 3, 5 with
+// <= 36 units; PFX is what the register budget of the shape leaves (256 VGPRs at 2 waves per SIMD)
+#define SENAS_WGRAD_LDS_SHAPES(X_)   \
+    X_(32, 1, 8, 4)                  \
+    X_(32, 5, 4, 6)                  \
+    X_(32, 7, 2, 10)                 \
+    X_(64, 2, 8, 8)                  \
+    X_(64, 5, 2, 11)                 \
+    X_(96, 4, 8, 12)                 \
+    X_(96, 7, 2, 10)                 \
+    X_(128, 4, 8, 16)                \
+    X_(128, 9, 2, 4)
 
 // ws: zeroed float[taps][A][32]; the caller unpacks it into the torch layout afterwards
 int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, hipStream_t st) {
@@ -198,20 +330,25 @@ int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* 
     const int tiles_x = (g.wg + TW - 1) / TW;
     while (th > 2 && (long)g.n * tiles_x * ((g.hg + th - 1) / th) < 256) th >>= 1;
     const int units = g.kh * g.kw * (g.A / 32);
-    const int uw = (units + 7) / 8;
-#define SENAS_WG(AA)                                                                      \
-    do {                                                                                  \
-        if (uw <= 2) return launch_one<AA, 2>(g, X, G, ws, x_relu, th, st);               \
-        if (uw <= 4) return launch_one<AA, 4>(g, X, G, ws, x_relu, th, st);               \
-        return launch_one<AA, 5>(g, X, G, ws, x_relu, th, st);                            \
-    } while (0)
-    switch (g.A) {
-        case 32: SENAS_WG(32);
-        case 64: SENAS_WG(64);
-        case 96: SENAS_WG(96);
-        default: SENAS_WG(128);
-    }
-#undef SENAS_WG
+    int uw, rs;
+    wgrad_lds_shape(units, uw, rs);
+#define SENAS_CASE(A_, UW_, RS_, PF_) \
+    if (g.A == A_ && uw == UW_ && rs == RS_) return launch_one<A_, UW_, RS_, PF_>(g, X, G, ws, x_relu, th, st);
+    SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
+#undef SENAS_CASE
+    set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair");
+    return SENAS_EINVAL;
+}
+
+// the kernel symbol launch_lds_wgrad picks (for senas_conv2d_kernel_name)
+void lds_wgrad_name(const WgradGeom& g, char* buf, int len) {
+    int uw, rs;
+    wgrad_lds_shape(g.kh * g.kw * (g.A / 32), uw, rs);
+    int pf = 0;
+#define SENAS_CASE(A_, UW_, RS_, PF_) if (g.A == A_ && uw == UW_ && rs == RS_) pf = PF_;
+    SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
+#undef SENAS_CASE
+    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d>", g.A, uw, rs, pf);
 }
 
 }  // namespace senas

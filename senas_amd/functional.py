@@ -57,13 +57,13 @@ class KernelTimer(object):
     def __init__(self):
         self.records = []
 
-    def span(self, name, flops, nbytes):
-        return _Span(self, name, flops, nbytes)
+    def span(self, name, flops, nbytes, tag=None):
+        return _Span(self, name, flops, nbytes, tag)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, flops, nbytes, e0, e1 in self.records:
+        for name, flops, nbytes, e0, e1, _ in self.records:
             a = agg.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             a['launches'] += 1
             a['ms'] += e0.elapsed_time(e1)
@@ -73,8 +73,8 @@ class KernelTimer(object):
 
 
 class _Span(object):
-    def __init__(self, timer, name, flops, nbytes):
-        self.t, self.name, self.flops, self.nbytes = timer, name, flops, nbytes
+    def __init__(self, timer, name, flops, nbytes, tag=None):
+        self.t, self.name, self.flops, self.nbytes, self.tag = timer, name, flops, nbytes, tag
 
     def __enter__(self):
         self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,7 +82,7 @@ class _Span(object):
 
     def __exit__(self, *exc):
         self.e1.record()
-        self.t.records.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
+        self.t.records.append((self.name, self.flops, self.nbytes, self.e0, self.e1, self.tag))
 
 
 class _NoSpan(object):
@@ -112,7 +112,8 @@ def _span(kind, g, x, w, y):
     macs = (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
     which = {'conv_fwd': 0, 'conv_dgrad': 1, 'conv_wgrad': 2}[kind]
     name = _lib.lib().senas_conv2d_kernel_name(C.byref(g), which).decode()      # the symbol rocprofv3 reports
-    return TIMER.span(name, 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()))
+    tag = (kind,) + tuple(getattr(g, f) for f, _ in g._fields_)
+    return TIMER.span(name, 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()), tag)
 
 
 # ------------------------------------------------------------------------------------------ convolution

@@ -348,6 +348,18 @@ _CONV_CASES = [
     (3, 1, 32, 40, 40, 7, 1, 1, False, False),      # stem: small-c_in weight gradient
     (2, 32, 2, 24, 24, 3, 1, 1, False, True),       # segmentation head (2 classes)
     (2, 8, 8, 20, 20, 5, 1, 3, False, False),       # inner supernet edge
+    (2, 3, 16, 20, 28, 3, 2, 1, False, False),      # thin-K gather: RGB stem, stride 2
+    (2, 32, 4, 18, 30, 1, 1, 1, False, False),      # thin-N: 1x1 head, 4 classes
+    (2, 16, 3, 24, 24, 3, 1, 1, False, True),       # thin-N with 3 classes (padded to 4), thin-K dgrad with c_in = 3 + ReLU mask
+    (2, 2, 16, 12, 12, 3, 2, 1, True, False),       # thin-K transposed gather forward (ConvTranspose2d from 2 channels)
+    (9, 1, 32, 64, 64, 7, 1, 1, False, False),      # stem at a size that takes 8 pixel passes per thread
+    (2, 32, 32, 24, 64, 3, 1, 1, False, True),      # LDS weight gradient, 9 units: 8 row lanes x 9 accumulators
+    (2, 32, 32, 16, 32, 1, 1, 1, False, False),     # 1x1: one unit, rows dealt to the 8 waves
+    (2, 64, 32, 16, 40, 3, 1, 1, False, False),     # 18 units: 4 unit groups x 2 row lanes
+    (2, 64, 32, 16, 32, 1, 1, 1, False, True),      # 2 units
+    (1, 96, 32, 16, 32, 3, 1, 1, False, False),     # 27 units
+    (1, 96, 16, 8, 32, 1, 1, 1, False, False),      # 3 units, 16 output channels (padded columns)
+    (1, 128, 32, 8, 32, 1, 1, 1, False, True),      # 4 units
 ]
 
 

@@ -170,16 +170,20 @@ typedef struct senas_node_desc {
 /* y = act(sum_t mix_t * gate_t * BN_t(z_t) + residual).  Saved for backward (caller-allocated):
  *   coefs  float[nterms][4][c]  (mean, invstd, scale, shift)      gate   float[nterms][n][c]
  *   coef   float[nterms][n][c]  shiftc float[nterms][n][c]        (scratch of the forward pass)
- *   se_m   float[nterms][n][c], se_a1 float[nterms][n][16]        (only touched for SE terms; may be NULL without) */
+ *   se_m   float[nterms][n][c], se_a1 float[nterms][n][16]        (only touched for SE terms; may be NULL without)
+ *   mask8  uint8[n*hw*c/4] or NULL: with relu and c % 4 == 0, byte k holds (y > 0) of the 4 floats of 16-byte
+ *          piece k in bits 0..3 -- lets the backward pass read 1 byte where it would read 16 of y          */
 int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
-                   float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, void* stream);
+                   float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, uint8_t* mask8,
+                   void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
  *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
  *   dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
  *   abk: float[3][nterms][n][c] scratch; dz[t]: gradient of z_t or NULL (skipped); ds_out: gradient of
- *   the residual input or NULL.                                                                    */
+ *   the residual input or NULL.  With relu, the mask comes from mask8 (as written by senas_node_fwd) if
+ *   given, else from y; one of the two must be non-NULL.                                           */
 int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
-                   const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+                   const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 

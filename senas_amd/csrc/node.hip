@@ -46,45 +46,82 @@ struct SeGradTable {            // per-term gradient destinations (each its own 
 };
 
 // ------------------------------------------------------------------------------------------ forward prepare
-// grid = nterms blocks of 256 threads; c <= 256.
+// grid = nterms blocks of 256 threads; c <= 256.  thread = (image row, channel): 256/c images are handled
+// side by side, every global operand is requested before the first dependent instruction, and everything
+// after that runs out of LDS -- the kernel is one memory round trip long.
+// dynamic LDS: part[R][c][2] doubles | zsum[n][c] doubles | m[n][c] | a1[n][kMaxMid] | w1[mid][c] | w2[c][mid] floats
 __global__ __launch_bounds__(256) void node_prepare_fwd_kernel(NodeDesc d, float* __restrict__ coefs, float* __restrict__ gate,
                                                                float* __restrict__ coef, float* __restrict__ shiftc,
                                                                float* __restrict__ se_m, float* __restrict__ se_a1) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // m[n][c] then a1[n][kMaxMid]
-    const int t = blockIdx.x, ch = threadIdx.x, n = d.n, c = d.c;
-    const bool act = ch < c;
-    float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int t = blockIdx.x, n = d.n, c = d.c;
+    const int R = 256 / c, ch = threadIdx.x % c, row = threadIdx.x / c;
+    const bool act = row < R;
     const double* st = d.stats[t];
-    if (act) {
+    const bool se = d.w1[t] != nullptr;
+    const int mid = se ? d.mid[t] : 0;
+    double* part = ldsd;                                            // [R][c][2]
+    double* zsum_s = part + (size_t)R * c * 2;                      // [n][c]: per-image channel sums (SE squeeze)
+    float* m_s = reinterpret_cast<float*>(zsum_s + (size_t)n * c);  // [n][c]
+    float* a_s = m_s + (size_t)n * c;                               // [n][kMaxMid]
+    float* w1_s = a_s + (size_t)n * kMaxMid;                        // [mid][c]
+    float* w2_s = w1_s + (size_t)kMaxMid * c;                       // [c][mid]
+
+    // ---- all global reads up front
+    double s = 0.0, q = 0.0;
+    if (act && st != nullptr && (d.training || se))
+        for (int i = row; i < n; i += R) {
+            const double v0 = st[((size_t)i * c + ch) * 2], v1 = st[((size_t)i * c + ch) * 2 + 1];
+            s += v0; q += v1;
+            if (se) zsum_s[i * c + ch] = v0;
+        }
+    float gam = 0.f, bet = 0.f, rm = 0.f, rv = 0.f;
+    if (threadIdx.x < c) {
+        gam = d.gamma[t][ch]; bet = d.beta[t][ch];
+        if (d.rmean[t] != nullptr) { rm = d.rmean[t][ch]; rv = d.rvar[t][ch]; }
+    }
+    const float w = d.mix != nullptr ? d.mix[t] : 1.f;
+    if (se) {
+        for (int i = threadIdx.x; i < mid * c; i += 256) { w1_s[i] = d.w1[t][i]; w2_s[i] = d.w2[t][i]; }
+    }
+    if (act) { part[((size_t)row * c + ch) * 2] = s; part[((size_t)row * c + ch) * 2 + 1] = q; }
+    __syncthreads();
+    // ---- batch statistics -> mean / invstd / scale / shift (threads 0..c-1 own a channel; broadcast through LDS)
+    float* bc = reinterpret_cast<float*>(part);                     // reused after the sums are read: [2][c] scale, shift
+    float mean = 0.f, invstd = 0.f, scale = 0.f, shift = 0.f;
+    if (threadIdx.x < c) {
         if (d.training) {
-            double s = 0.0, q = 0.0;
-            if (st != nullptr)
-                for (int i = 0; i < n; ++i) { s += st[((size_t)i * c + ch) * 2]; q += st[((size_t)i * c + ch) * 2 + 1]; }
-            const double m = (double)n * (double)d.hw, mu = s / m;
-            double var = q / m - mu * mu;
+            double ss = 0.0, qq = 0.0;
+            for (int rr = 0; rr < R; ++rr) { ss += part[((size_t)rr * c + ch) * 2]; qq += part[((size_t)rr * c + ch) * 2 + 1]; }
+            const double mm = (double)n * (double)d.hw, mu = ss / mm;
+            double var = qq / mm - mu * mu;
             if (var < 0.0) var = 0.0;
             mean = (float)mu;
             invstd = (float)(1.0 / sqrt(var + (double)d.eps));
             if (d.rmean[t] != nullptr) {
-                const double unbiased = m > 1.0 ? var * m / (m - 1.0) : var;
-                d.rmean[t][ch] = (1.f - d.momentum) * d.rmean[t][ch] + d.momentum * mean;
-                d.rvar[t][ch] = (1.f - d.momentum) * d.rvar[t][ch] + d.momentum * (float)unbiased;
+                const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
+                d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
+                d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
             }
         } else {
-            mean = d.rmean[t][ch];
-            invstd = 1.f / sqrtf(d.rvar[t][ch] + d.eps);
+            mean = rm;
+            invstd = 1.f / sqrtf(rv + d.eps);
         }
-        scale = d.gamma[t][ch] * invstd;
-        shift = d.beta[t][ch] - mean * scale;
+        scale = gam * invstd;
+        shift = bet - mean * scale;
         float* co = coefs + (size_t)t * 4 * c;
         co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
     }
     if (threadIdx.x == 0 && d.training && d.nbt[t] != nullptr) *d.nbt[t] += 1;
-    const float w = d.mix != nullptr ? d.mix[t] : 1.f;
+    __syncthreads();                                                // everyone is done reading part[]
+    if (threadIdx.x < c) { bc[ch] = scale; bc[c + ch] = shift; }
+    __syncthreads();
+    scale = act ? bc[ch] : 0.f;
+    shift = act ? bc[c + ch] : 0.f;
     const size_t tb = (size_t)t * n * c;
-    if (d.w1[t] == nullptr) {
+    if (!se) {
         if (act)
-            for (int i = 0; i < n; ++i) {
+            for (int i = row; i < n; i += R) {
                 gate[tb + (size_t)i * c + ch] = 1.f;
                 coef[tb + (size_t)i * c + ch] = w * scale;
                 shiftc[tb + (size_t)i * c + ch] = w * shift;
@@ -92,34 +129,37 @@ __global__ __launch_bounds__(256) void node_prepare_fwd_kernel(NodeDesc d, float
         return;
     }
     // ---- squeeze-and-excitation: m = mean_hw(BN(z)) = scale * mean_hw(z) + shift
-    const int mid = d.mid[t];
-    float* m_s = lds;
-    float* a_s = lds + n * c;
     if (act)
-        for (int i = 0; i < n; ++i) {
-            const double zbar = st != nullptr ? st[((size_t)i * c + ch) * 2] / (double)d.hw : 0.0;
+        for (int i = row; i < n; i += R) {
+            const double zbar = st != nullptr ? zsum_s[i * c + ch] / (double)d.hw : 0.0;
             const float mv = (float)((double)scale * zbar + (double)shift);
             m_s[i * c + ch] = mv;
             se_m[tb + (size_t)i * c + ch] = mv;
         }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < n * mid; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < n * mid; idx += 256) {
         const int i = idx / mid, j = idx % mid;
         float a = 0.f;
-        for (int k = 0; k < c; ++k) a = fmaf(m_s[i * c + k], d.w1[t][j * c + k], a);
+        for (int k = 0; k < c; ++k) a = fmaf(m_s[i * c + k], w1_s[j * c + k], a);
         a_s[i * kMaxMid + j] = a;
         se_a1[((size_t)t * n + i) * kMaxMid + j] = a;
     }
     __syncthreads();
     if (act)
-        for (int i = 0; i < n; ++i) {
+        for (int i = row; i < n; i += R) {
             float a = 0.f;
-            for (int j = 0; j < mid; ++j) a = fmaf(fmaxf(a_s[i * kMaxMid + j], 0.f), d.w2[t][ch * mid + j], a);
+            for (int j = 0; j < mid; ++j) a = fmaf(fmaxf(a_s[i * kMaxMid + j], 0.f), w2_s[ch * mid + j], a);
             const float g = 1.f / (1.f + expf(-a));
             gate[tb + (size_t)i * c + ch] = g;
             coef[tb + (size_t)i * c + ch] = w * g * scale;
             shiftc[tb + (size_t)i * c + ch] = w * g * shift;
         }
+}
+
+static size_t prepare_fwd_lds(const NodeDesc& d) {
+    const int R = 256 / d.c;
+    return ((size_t)R * d.c * 2 + (size_t)d.n * d.c) * sizeof(double) +
+           ((size_t)d.n * d.c + (size_t)d.n * kMaxMid + (size_t)2 * kMaxMid * d.c) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------ forward combine
@@ -128,7 +168,7 @@ template <int V>
 __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, int nterms, int nimg, ZTable z,
                                                                const float* __restrict__ coef, const float* __restrict__ shiftc,
                                                                const float* __restrict__ residual, int relu,
-                                                               float* __restrict__ y) {
+                                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
     const int n = blockIdx.y;
     float* bias = lds + nterms * c;
@@ -161,6 +201,11 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
             ldv<V>(z.p[t] + off, tmp);
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
+        }
+        if (V == 4 && mask8 != nullptr) {           // one byte per 16-byte piece: bit j = (y_j > 0), the backward pass's ReLU mask
+            const unsigned bits = (acc[0] > 0.f ? 1u : 0u) | (acc[1 % V] > 0.f ? 2u : 0u) | (acc[2 % V] > 0.f ? 4u : 0u) |
+                                  (acc[3 % V] > 0.f ? 8u : 0u);
+            mask8[off >> 2] = (uint8_t)bits;
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
@@ -211,6 +256,96 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
         if (t < tt && z.p[t0 + t] != nullptr) reduce_to(a2[t], p2 + ((size_t)(t0 + t) * nimg + n) * c + ch);
 }
 
+// Vector form for c = 4*Q, Q a power of two (every width on the path): thread = (pixel lane, 4 channels),
+// 16-byte loads with U pixels in flight per thread, the ReLU mask from the forward pass's byte map (or y),
+// fp64 partials folded over the pixel lanes by shuffles and over the 4 waves through LDS; one fp64 atomic
+// per (n, c) and term per block.  grid = (chunks of `chunk` pixels, n).
+template <int TT, int U>
+__global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
+                                                              const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const uint8_t* __restrict__ mask8, int relu, int do_p1,
+                                                              double* __restrict__ p1, double* __restrict__ p2) {
+    extern __shared__ __attribute__((aligned(16))) double redv[];      // [4 waves][1 + TT][c]
+    const int Q = c >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
+    const int n = blockIdx.y;
+    long q0 = (long)blockIdx.x * chunk, q1 = q0 + chunk;
+    if (q1 > hw) q1 = hw;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[TT][4];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a2[t][j] = 0.0;
+    const size_t img = (size_t)n * hw;
+    for (long p = q0 + pl; p < q1; p += (long)lanes * U) {
+        float4 dv[U], zv[TT][U];
+        unsigned mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pp = p + (long)u * lanes;
+            const bool ok = pp < q1;
+            const size_t o4 = (img + (ok ? pp : q0)) * Q + q;            // index in 16-byte pieces
+            dv[u] = reinterpret_cast<const float4*>(dy)[o4];
+            if (!ok) dv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mk[u] = 15u;
+            if (relu) {
+                if (mask8 != nullptr) mk[u] = mask8[o4];
+                else {
+                    const float4 yv = reinterpret_cast<const float4*>(y)[o4];
+                    mk[u] = (yv.x > 0.f ? 1u : 0u) | (yv.y > 0.f ? 2u : 0u) | (yv.z > 0.f ? 4u : 0u) | (yv.w > 0.f ? 8u : 0u);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                if (t < tt && z.p[t0 + t] != nullptr) zv[t][u] = reinterpret_cast<const float4*>(z.p[t0 + t])[o4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float ds[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((mk[u] >> j) & 1u)) ds[j] = 0.f;
+                a1[j] += (double)ds[j];
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                if (t < tt && z.p[t0 + t] != nullptr) {
+                    const float zz[4] = {zv[t][u].x, zv[t][u].y, zv[t][u].z, zv[t][u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a2[t][j] += (double)ds[j] * (double)zz[j];
+                }
+        }
+    }
+    // fold: pixel lanes of the wave (stride Q), then the 4 waves
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        for (int o = Q; o < 64; o <<= 1) a1[j] += __shfl_xor(a1[j], o, 64);
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            for (int o = Q; o < 64; o <<= 1) a2[t][j] += __shfl_xor(a2[t][j], o, 64);
+    }
+    const int wl = Q < 64 ? Q : 64;                 // lanes of a wave that hold distinct channel groups
+    if (lane < wl) {
+        const int qq = q;                           // lane < Q: q == lane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            redv[((size_t)wave * (1 + TT)) * c + qq * 4 + j] = a1[j];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) redv[((size_t)wave * (1 + TT) + 1 + t) * c + qq * 4 + j] = a2[t][j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 + TT) * c; i += 256) {
+        const int k = i / c, ch = i - k * c;
+        if (k == 0 && !do_p1) continue;
+        if (k > 0 && !(k - 1 < tt && z.p[t0 + k - 1] != nullptr)) continue;
+        double v = 0.0;
+        for (int wv = 0; wv < 4; ++wv) v += redv[((size_t)wv * (1 + TT) + k) * c + ch];
+        if (k == 0) atomicAdd(p1 + (size_t)n * c + ch, v);
+        else atomicAdd(p2 + ((size_t)(t0 + k - 1) * nimg + n) * c + ch, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward prepare
 __device__ __forceinline__ double block_sum(double v, double* red) {
     __syncthreads();
@@ -223,7 +358,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return red[0];
 }
 
-__global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
+__global__ __launch_bounds__(256) void node_prepare_bwd_generic_kernel(NodeDesc d, const double* __restrict__ p1,
                                                                const double* __restrict__ p2, const float* __restrict__ coefs,
                                                                const float* __restrict__ gate, const float* __restrict__ se_m,
                                                                const float* __restrict__ se_a1, float* __restrict__ dmix,
@@ -313,10 +448,155 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
     }
 }
 
+// Fast form of the above for n <= 8 * (256 / c) (every batch on the path): thread = (image row, channel) with up
+// to kImgs images per thread in registers; every global operand is requested up front, the SE weights and
+// activations live in LDS, reductions over the images go through LDS -- one memory round trip instead of ~10.
+constexpr int kImgs = 8;
+
+__global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
+                                                               const double* __restrict__ p2, const float* __restrict__ coefs,
+                                                               const float* __restrict__ gate, const float* __restrict__ se_m,
+                                                               const float* __restrict__ se_a1, float* __restrict__ dmix,
+                                                               float* __restrict__ A, float* __restrict__ B, float* __restrict__ K,
+                                                               SeGradTable seg) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int t = blockIdx.x, n = d.n, c = d.c;
+    const int R = 256 / c, ch = threadIdx.x % c, row = threadIdx.x / c;
+    const bool act = row < R;
+    const size_t tb = (size_t)t * n * c;
+    const double hw = (double)d.hw, M = (double)n * hw;
+    const bool se = d.w1[t] != nullptr;
+    const int mid = se ? d.mid[t] : 0;
+    // LDS: doubles da2[n][c] | da1[n][kMaxMid] | part[R][c][2] | red[4]; floats a1[n][kMaxMid] | m[n][c] | w1[mid][c] | w2[c][mid]
+    double* da2 = ldsd;
+    double* da1 = da2 + (size_t)n * c;
+    double* part = da1 + (size_t)n * kMaxMid;
+    double* red = part + (size_t)R * c * 2;
+    float* a1_s = reinterpret_cast<float*>(red + 4);
+    float* m_s = a1_s + (size_t)n * kMaxMid;
+    float* w1_s = m_s + (size_t)n * c;
+    float* w2_s = w1_s + (size_t)kMaxMid * c;
+
+    // ---- all global reads up front
+    const float* co = coefs + (size_t)t * 4 * c;
+    const double mean = act ? co[ch] : 0.0, invstd = act ? co[c + ch] : 0.0, scale = act ? co[2 * c + ch] : 0.0,
+                 shift = act ? co[3 * c + ch] : 0.0;
+    const double w = d.mix != nullptr ? (double)d.mix[t] : 1.0;
+    const double* st = d.stats[t];
+    double P1[kImgs], P2[kImgs], Gt[kImgs], Zs[kImgs];
+#pragma unroll
+    for (int k = 0; k < kImgs; ++k) {
+        const int i = row + k * R;
+        const bool ok = act && i < n;
+        const size_t o = (size_t)(ok ? i : 0) * c + ch;
+        P1[k] = ok ? p1[o] : 0.0;
+        P2[k] = ok ? p2[tb + o] : 0.0;
+        Gt[k] = ok ? (double)gate[tb + o] : 0.0;
+        Zs[k] = ok && st != nullptr ? st[o * 2] : 0.0;
+    }
+    if (se) {
+        for (int i = threadIdx.x; i < mid * c; i += 256) { w1_s[i] = d.w1[t][i]; w2_s[i] = d.w2[t][i]; }
+        for (int i = threadIdx.x; i < n * kMaxMid; i += 256) a1_s[i] = se_a1[(size_t)t * n * kMaxMid + i];
+        for (int i = threadIdx.x; i < n * c; i += 256) m_s[i] = se_m[tb + i];
+    }
+    // ---- d loss / d(mix_t * gate) per (n, c): full-tensor dot product of ds with BN_t(z_t)
+    double dmix_part = 0.0;
+#pragma unroll
+    for (int k = 0; k < kImgs; ++k) {
+        const int i = row + k * R;
+        if (act && i < n) {
+            const double dot = scale * P2[k] + shift * P1[k];
+            dmix_part += Gt[k] * dot;
+            if (se) da2[i * c + ch] = w * dot * Gt[k] * (1.0 - Gt[k]);
+        }
+    }
+    dmix_part = wave_sum(dmix_part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmix_part;
+    __syncthreads();                                             // red[], da2[], SE operands visible
+    if (threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)(red[0] + red[1] + red[2] + red[3]);
+
+    double e[kImgs];
+#pragma unroll
+    for (int k = 0; k < kImgs; ++k) e[k] = 0.0;
+    if (se) {
+        // dW2[c][j] = sum_n da2[n][c] * relu(a1[n][j])
+        for (int idx = threadIdx.x; idx < c * mid; idx += 256) {
+            const int cc = idx / mid, j = idx - cc * mid;
+            double sacc = 0.0;
+            for (int i = 0; i < n; ++i) sacc += da2[i * c + cc] * fmaxf(a1_s[i * kMaxMid + j], 0.f);
+            seg.w2[t][idx] = (float)sacc;
+        }
+        // da1[n][j] = (a1 > 0) * sum_c da2[n][c] * W2[c][j]
+        for (int idx = threadIdx.x; idx < n * mid; idx += 256) {
+            const int i = idx / mid, j = idx - i * mid;
+            double sacc = 0.0;
+            for (int k = 0; k < c; ++k) sacc += da2[i * c + k] * w2_s[k * mid + j];
+            da1[i * kMaxMid + j] = a1_s[i * kMaxMid + j] > 0.f ? sacc : 0.0;
+        }
+        __syncthreads();
+        // dW1[j][c] = sum_n da1[n][j] * m[n][c]
+        for (int idx = threadIdx.x; idx < mid * c; idx += 256) {
+            const int j = idx / c, cc = idx - j * c;
+            double sacc = 0.0;
+            for (int i = 0; i < n; ++i) sacc += da1[i * kMaxMid + j] * m_s[i * c + cc];
+            seg.w1[t][idx] = (float)sacc;
+        }
+#pragma unroll
+        for (int k = 0; k < kImgs; ++k) {
+            const int i = row + k * R;
+            if (act && i < n) {
+                double ev = 0.0;
+                for (int j = 0; j < mid; ++j) ev += da1[i * kMaxMid + j] * w1_s[j * c + ch];
+                e[k] = ev / hw;
+            }
+        }
+    }
+    // ---- sums over the images
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kImgs; ++k) {
+        const int i = row + k * R;
+        if (act && i < n) {
+            const double u1 = w * Gt[k];
+            s1 += u1 * P1[k] + hw * e[k];
+            s2 += u1 * P2[k] + e[k] * Zs[k];
+        }
+    }
+    if (act) { part[((size_t)row * c + ch) * 2] = s1; part[((size_t)row * c + ch) * 2 + 1] = s2; }
+    __syncthreads();
+    if (!act) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int rr = 0; rr < R; ++rr) { s1 += part[((size_t)rr * c + ch) * 2]; s2 += part[((size_t)rr * c + ch) * 2 + 1]; }
+    const double kk = s2 - mean * s1;
+    if (row == 0) {
+        seg.dbeta[t][ch] = (float)s1;
+        seg.dgamma[t][ch] = (float)(invstd * kk);
+    }
+    const double bcoef = d.training ? -scale * invstd * invstd * kk / M : 0.0;
+    const double kconst = d.training ? (-scale * s1 / M + scale * invstd * invstd * mean * kk / M) : 0.0;
+#pragma unroll
+    for (int k = 0; k < kImgs; ++k) {
+        const int i = row + k * R;
+        if (i < n) {
+            const size_t o = tb + (size_t)i * c + ch;
+            A[o] = (float)(scale * w * Gt[k]);
+            B[o] = (float)bcoef;
+            K[o] = (float)(scale * e[k] + kconst);
+        }
+    }
+}
+
+static size_t prepare_bwd_lds(const NodeDesc& d) {
+    const int R = 256 / d.c;
+    return ((size_t)d.n * d.c + (size_t)d.n * kMaxMid + (size_t)R * d.c * 2 + 4) * sizeof(double) +
+           ((size_t)d.n * kMaxMid + (size_t)d.n * d.c + (size_t)2 * kMaxMid * d.c) * sizeof(float);
+}
+
 // ------------------------------------------------------------------------------------------ backward apply
 template <int V>
 __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nterms, int nimg, ZTable z,
-                                                         const float* __restrict__ dy, const float* __restrict__ y, int relu,
+                                                         const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ mask8, int relu,
                                                          const float* __restrict__ A, const float* __restrict__ B,
                                                          const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
     const int cv = c / V;
@@ -329,9 +609,15 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
         float ds[V], yv[V], zv[V], av[V], bv[V], kv[V];
         ldv<V>(dy + off, ds);
         if (relu) {
-            ldv<V>(y + off, yv);
+            if (V == 4 && mask8 != nullptr) {
+                const unsigned mk = mask8[off >> 2];
 #pragma unroll
-            for (int j = 0; j < V; ++j) if (!(yv[j] > 0.f)) ds[j] = 0.f;
+                for (int j = 0; j < V; ++j) if (!((mk >> j) & 1u)) ds[j] = 0.f;
+            } else {
+                ldv<V>(y + off, yv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) if (!(yv[j] > 0.f)) ds[j] = 0.f;
+            }
         }
         if (ds_out != nullptr) stv<V>(ds_out + off, ds);
         for (int t = 0; t < nterms; ++t) {
@@ -394,7 +680,7 @@ using namespace senas;
 
 extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
                               float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1,
-                              void* stream) {
+                              uint8_t* mask8, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_fwd: bad descriptor");
     SENAS_REQUIRE(z && y && coefs && gate && coef && shiftc, "node_fwd: null pointer");
@@ -407,23 +693,25 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     }
     SENAS_REQUIRE(!any_se || (se_m && se_a1), "node_fwd: SE scratch missing");
     hipStream_t st = as_stream(stream);
-    const size_t lds1 = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(float) : 0;
+    const size_t lds1 = prepare_fwd_lds(d);
+    SENAS_REQUIRE(lds1 <= 64 * 1024, "node_fwd: batch x channels too large for the prepare kernel");
     hipLaunchKernelGGL(node_prepare_fwd_kernel, dim3(d.nterms), dim3(256), lds1, st, d, coefs, gate, coef, shiftc, se_m, se_a1);
     const int V = (d.c % 4 == 0) ? 4 : 1;
     dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
     const size_t lds2 = ((size_t)d.nterms * d.c + d.c) * sizeof(float);
-    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y);
-    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y);
+    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr);
+    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr);
     return launch_status("node_fwd");
 }
 
 extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
-                              const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+                              const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                               double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                               float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
-    SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y), "node_bwd: null pointer");
+    SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y || mask8), "node_bwd: null pointer");
+    if (d.c % 4 != 0) { SENAS_REQUIRE(!d.relu || y, "node_bwd: the byte mask needs c % 4 == 0"); mask8 = nullptr; }
     ZTable zt{};
     DzTable dzt{};
     SeGradTable seg{};
@@ -444,28 +732,54 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
         }
     }
     hipStream_t st = as_stream(stream);
-    const long chunk = node_chunk(d.hw, d.n);
-    dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
+    const int Q = d.c >> 2;
+    const bool vec = d.c % 4 == 0 && Q >= 1 && Q <= 64 && (Q & (Q - 1)) == 0;
     int t0 = 0, first = 1;
     do {
         const int left = d.nterms - t0;
         const int tt = left >= 8 ? 8 : left;
-        if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-        else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-        else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-        else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        if (vec) {
+            // pixels per block: a few U-deep iterations of the 256/Q pixel lanes; <= 64 blocks per image so that
+            // at most 64 blocks contend for one (n, c) accumulator
+            const int U = tt <= 2 ? 4 : (tt <= 4 ? 2 : 1);
+            const long per_iter = (long)(256 / Q) * U;
+            const int iters = d.hw <= 4096 ? 2 : (d.hw <= 16384 ? 4 : 8);
+            long chunk = per_iter * iters;
+            if ((d.hw + chunk - 1) / chunk > 64) chunk = ((d.hw + 63) / 64 + per_iter - 1) / per_iter * per_iter;
+            dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
+#define SENAS_RV(TT, UU) hipLaunchKernelGGL((node_reduce_vec_kernel<TT, UU>), rgrid, dim3(256), (size_t)4 * (1 + TT) * d.c * sizeof(double), st, \
+                                             d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, mask8, d.relu, first, p1, p2)
+            if (tt > 4) SENAS_RV(8, 1);
+            else if (tt > 2) SENAS_RV(4, 2);
+            else if (tt == 2) SENAS_RV(2, 4);
+            else SENAS_RV(1, 4);
+#undef SENAS_RV
+        } else {
+            const long chunk = node_chunk(d.hw, d.n);
+            dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
+            if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+            else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+            else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+            else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+        }
         t0 += tt;
         first = 0;
     } while (t0 < d.nterms);
     const size_t tnc = (size_t)d.nterms * d.n * d.c;
-    const size_t lds = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(double) : 0;
-    hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds, st, d, p1, p2, coefs, gate, se_m, se_a1,
-                       dmix, abk, abk + tnc, abk + 2 * tnc, seg);
+    const size_t lds_fast = prepare_bwd_lds(d);
+    if (d.n <= kImgs * (256 / d.c) && lds_fast <= 64 * 1024) {
+        hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds_fast, st, d, p1, p2, coefs, gate, se_m, se_a1,
+                           dmix, abk, abk + tnc, abk + 2 * tnc, seg);
+    } else {
+        const size_t lds = any_se ? ((size_t)d.n * d.c + (size_t)d.n * kMaxMid) * sizeof(double) : 0;
+        hipLaunchKernelGGL(node_prepare_bwd_generic_kernel, dim3(d.nterms), dim3(256), lds, st, d, p1, p2, coefs, gate, se_m, se_a1,
+                           dmix, abk, abk + tnc, abk + 2 * tnc, seg);
+    }
     if (any_dz || ds_out) {
         const int V = (d.c % 4 == 0) ? 4 : 1;
         dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
-        if (V == 4) hipLaunchKernelGGL((node_apply_kernel<4>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
-        else hipLaunchKernelGGL((node_apply_kernel<1>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+        if (V == 4) hipLaunchKernelGGL((node_apply_kernel<4>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+        else hipLaunchKernelGGL((node_apply_kernel<1>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
     }
     return launch_status("node_bwd");
 }

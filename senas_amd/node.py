@@ -82,16 +82,23 @@ class _Node(torch.autograd.Function):
         se_m = torch.empty((T, n, c), device=dev, dtype=torch.float32) if ns else None
         se_a1 = torch.empty((T, n, SE_MID_MAX), device=dev, dtype=torch.float32) if ns else None
         y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL)
+        # ReLU mask for the backward pass: one byte per 16-byte piece of y instead of y itself
+        mask8 = torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if (meta['relu'] and c % 4 == 0) else None
         res = F.nhwc(residual) if residual is not None else None
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         _lib.check(L.senas_node_fwd(C.byref(d), zp, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
-                                    scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._stream()),
+                                    scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._p(mask8),
+                                    F._stream()),
                    'senas_node_fwd')
         ctx.meta = meta
         ctx.has_mix, ctx.has_res, ctx.nflat = mix is not None, residual is not None, len(flat)
         ctx.stats = stats
         ctx.se_buf = (se_m, se_a1)
-        ctx.save_for_backward(y, coefs, gate, mixc if mixc is not None else coefs, *zs, *gammas, *betas, *w1s, *w2s)
+        ctx.mask8 = mask8
+        ctx.out_shape = (n, c, h, w)
+        # y itself is only needed for the mask when there is no byte map
+        ysave = y if (meta['relu'] and mask8 is None) else coefs
+        ctx.save_for_backward(ysave, coefs, gate, mixc if mixc is not None else coefs, *zs, *gammas, *betas, *w1s, *w2s)
         return y
 
     @staticmethod
@@ -107,8 +114,10 @@ class _Node(torch.autograd.Function):
         gammas, betas = saved[4 + nr:4 + nr + T], saved[4 + nr + T:4 + nr + 2 * T]
         w1s = saved[4 + nr + 2 * T:4 + nr + 2 * T + ns]
         w2s = saved[4 + nr + 2 * T + ns:4 + nr + 2 * T + 2 * ns]
-        dev = y.device
+        dev = coefs.device
         dy = F.nhwc(dy)
+        mask8 = ctx.mask8
+        yptr = y.data_ptr() if (meta['relu'] and mask8 is None) else None
         mix = mixc if ctx.has_mix else None
         d = _desc(meta, gammas, betas, w1s, w2s, ctx.stats, mix)
         zfull = [None] * T
@@ -119,7 +128,7 @@ class _Node(torch.autograd.Function):
         for k, t in enumerate(real):
             if need[3 + k]:
                 dzs[t] = torch.empty_like(zs[k], memory_format=CL)
-        ds_out = torch.empty_like(y, memory_format=CL) if (ctx.has_res and need[2]) else None
+        ds_out = torch.empty_like(dy, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
         dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # own tensors: autograd adopts them
         dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # as .grad without cloning a view
@@ -133,7 +142,7 @@ class _Node(torch.autograd.Function):
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
         se_m, se_a1 = ctx.se_buf
-        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
+        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
                                     F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
                                     _arr([t_.data_ptr() for t_ in dgs]), _arr([t_.data_ptr() for t_ in dbs]),
                                     F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),

@@ -187,6 +187,23 @@ int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const flo
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 
+/* ---- optimizer step -------------------------------------------------------------------------
+ * nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.SGD.step() (momentum, dampening,
+ * weight decay, nesterov; experiments/train_model.py:284-289, search_arc.py:280-285) over n tensors in two
+ * launches.  items_dev: DEVICE array; grad == NULL: the tensor is skipped (like a parameter without .grad);
+ * buf: momentum buffer (ignored when momentum == 0).  partial64: double[64] scratch.  max_norm <= 0: no
+ * clipping.  first_step != 0: buffers are initialised with the gradient (torch's first step).  Gradients are
+ * left scaled by the clip coefficient, as clip_grad_norm_ leaves them.  total_norm_out: float[1] or NULL.   */
+typedef struct senas_sgd_item {
+    float* param;
+    float* grad;
+    float* buf;
+    int64_t numel;
+} senas_sgd_item;
+int senas_sgd_clip_step(const senas_sgd_item* items_dev, int n, int64_t max_numel, double* partial64,
+                        float max_norm, float lr, float momentum, float dampening, float weight_decay,
+                        int nesterov, int first_step, float* total_norm_out, void* stream);
+
 /* Name of the kernel a convolution call dispatches to, as rocprofv3 prints the symbol (without the
  * `senas::` prefix and argument list).  which: 0 forward, 1 data gradient, 2 weight gradient.
  * For attributing measured time to profile rows; the string is owned by the library.              */

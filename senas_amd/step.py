@@ -9,6 +9,7 @@ capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
 """
 import torch
 
+from . import optim
 from .arena import reset_arena
 from .packing import WeightPacker
 from .parallel import GradAllReducer
@@ -77,6 +78,8 @@ class SearchStep(object):
         self.opt_w, self.opt_a, self.grad_clip = weight_optimizer, arch_optimizer, grad_clip
         self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
         self.graphed = self.fb.graph is not None
+        # static gradient addresses (graph replays) -> clip + SGD in two launches instead of ~110
+        self.fused = optim.FusedClipSGD(weight_optimizer, grad_clip) if (self.graphed and optim.supported(weight_optimizer)) else None
 
     def __call__(self, x_train, y_train, x_valid=None, y_valid=None):
         fb = self.fb
@@ -90,6 +93,9 @@ class SearchStep(object):
         fb.y.copy_(y_train, non_blocking=True)
         loss = fb()
         self.reducer.finish()
+        if self.fused is not None:
+            self.fused.step()
+            return loss
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.opt_w.step()
@@ -105,10 +111,14 @@ class TrainStep(object):
         self.optimizer, self.grad_clip, self.world = optimizer, grad_clip, world_size
         self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
         self.graphed = self.fb.graph is not None
+        self.fused = optim.FusedClipSGD(optimizer, grad_clip) if (self.graphed and optim.supported(optimizer)) else None
 
     def __call__(self):
         loss = self.fb()
         self.reducer.finish()
+        if self.fused is not None:
+            self.fused.step()
+            return loss
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
         self.optimizer.step()

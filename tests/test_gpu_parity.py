@@ -433,3 +433,36 @@ def test_weight_packer_and_graph_step_match_eager():
         assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
     for k in w0:
         close(w1[k], w0[k], 'weights after 3 steps ' + k, rel=2e-4)
+
+
+@pytest.mark.parametrize('cfg', [dict(momentum=0.9, weight_decay=5e-4), dict(momentum=0.9, weight_decay=3e-4, nesterov=True),
+                                 dict(momentum=0.0, weight_decay=0.0), dict(momentum=0.5, dampening=0.1, weight_decay=1e-2)],
+                         ids=['momentum_wd', 'nesterov', 'plain', 'dampening'])
+def test_fused_clip_sgd_matches_torch(cfg):
+    """senas_sgd_clip_step == nn.utils.clip_grad_norm_ + torch.optim.SGD.step (train_model.py:284-289), 3 steps,
+    one tensor larger than a block, one parameter that never gets a gradient, clipping active and inactive."""
+    from senas_amd.optim import FusedClipSGD
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 32, 5, 5), (7,), (2, 32, 3, 3), (128,), (1,), (32, 128, 3, 3)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * sc for s in shapes] for sc in (3.0, 0.01, 1.0)]     # norm >> 5, << 5, ~
+    ref = [torch.nn.Parameter(b.clone().to(dev())) for b in base] + [torch.nn.Parameter(torch.ones(3, device=dev()))]
+    got = [torch.nn.Parameter(b.clone().to(dev())) for b in base] + [torch.nn.Parameter(torch.ones(3, device=dev()))]
+    opt_r = torch.optim.SGD(ref, lr=0.05, **cfg)
+    opt_g = torch.optim.SGD(got, lr=0.05, **cfg)
+    for p in got[:-1]:
+        p.grad = torch.zeros_like(p)                  # static gradient storage, as under graph replay
+    fused = FusedClipSGD(opt_g, 5.0)
+    for step in range(3):
+        for p, q, gr in zip(ref, got, grads[step]):
+            p.grad = gr.clone().to(dev())
+            q.grad.copy_(gr)
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt_r.step()
+        n_got = fused.step()
+        close(n_got, n_ref.reshape(1).cpu().numpy(), 'total_norm', rel=1e-5)
+        for k, (p, q) in enumerate(zip(ref, got)):
+            close(q.detach(), p.detach().cpu().numpy(), 'param %d step %d' % (k, step), rel=2e-6)
+            if p.grad is not None:
+                close(q.grad, p.grad.cpu().numpy(), 'clipped grad %d step %d' % (k, step), rel=2e-6)
+    assert set(opt_g.state_dict()['state'].keys()) == set(opt_r.state_dict()['state'].keys())

@@ -187,6 +187,24 @@ int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const flo
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 
+/* ---- loss and metric ------------------------------------------------
+ * DiceCrossEntropyLoss (utils/loss/loss.py:45-70,124-228): w_ce * CrossEntropy(mean over pixels) +
+ * w_dice * (1 - mean over classes [1:] (or [0:] with do_bg) of (2 tp + smooth) / (2 tp + fp + fn + smooth + 1e-8))
+ * with soft tp/fp/fn over batch and space.  logits: float [npix][c] (NHWC), c <= 8; target: int64 [npix].
+ *   acc : double[1 + 3c], ZEROED by the caller (sum of -log p[t], sum p_c, sum p_c [t=c], sum [t=c])
+ *   loss: float[1];  coef: float[3c + 1], saved for senas_dice_ce_bwd
+ * bwd: dlogits = dloss[0] (1 if NULL) * d loss / d logits.                                                     */
+int senas_dice_ce_fwd(int64_t npix, int c, const float* logits, const int64_t* target, float w_ce, float w_dice,
+                      float smooth, int do_bg, double* acc, float* loss, float* coef, void* stream);
+int senas_dice_ce_bwd(int64_t npix, int c, const float* logits, const int64_t* target, const float* coef,
+                      const float* dloss, float* dlogits, void* stream);
+/* SegmentationMetric.update (utils/metrics.py:127-173) without host syncs: arg-max over c, then
+ *   counts[c-1][3] (int64: tp, fp, fn of classes 1..c-1) += this batch
+ *   acc_sum[0] += mean over images of (correct_i + eps) / (labelled_i + eps)      (mean_pix_accuracy, :127-142)
+ * part_zeroed: (2n + 3(c-1)) x 8 bytes of zeroed scratch.                                                    */
+int senas_seg_metric_update(int n, int64_t hw, int c, const float* logits, const int64_t* target, float eps,
+                            void* part_zeroed, int64_t* counts, double* acc_sum, void* stream);
+
 /* ---- optimizer step -------------------------------------------------------------------------
  * nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.SGD.step() (momentum, dampening,
  * weight decay, nesterov; experiments/train_model.py:284-289, search_arc.py:280-285) over n tensors in two

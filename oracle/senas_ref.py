@@ -376,8 +376,8 @@ def derive_genotype(sd, depth=5, nodes=3) -> Genotype:
 
 
 # ----------------------------------------------------------------------------- loss and metric
-def dice_ce_loss(logits, target, smooth=1e-5):
-    """DiceCrossEntropyLoss (weights 1/1, do_bg False) -- utils/loss/loss.py:45-70,124-159,173-228."""
+def soft_dice_loss(logits, target, smooth=1e-5):
+    """SoftDiceLoss (batch_dice True, do_bg False, softmax applied inside) -- utils/loss/loss.py:45-70,173-228."""
     prob = F.softmax(logits, 1)
     onehot = torch.zeros_like(prob).scatter_(1, target.long().unsqueeze(1), 1)
     axes = [0] + list(range(2, logits.dim()))
@@ -385,7 +385,12 @@ def dice_ce_loss(logits, target, smooth=1e-5):
     fp = (prob * (1 - onehot)).sum(axes)
     fn = ((1 - prob) * onehot).sum(axes)
     dc = (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8)
-    return F.cross_entropy(logits, target.long()) + (1 - dc[1:].mean())
+    return 1 - dc[1:].mean()
+
+
+def dice_ce_loss(logits, target, smooth=1e-5):
+    """DiceCrossEntropyLoss (weights 1/1) = nn.CrossEntropyLoss + SoftDiceLoss -- utils/loss/loss.py:124-159."""
+    return F.cross_entropy(logits, target.long()) + soft_dice_loss(logits, target, smooth)
 
 
 def hard_counts(logits, label):

@@ -5,26 +5,57 @@ list the models return and the loss is taken on ``outputs[-1]`` (loss.py:26-27).
 dice_ce = SoftDiceLoss (soft TP/FP/FN over batch+space, background class dropped, smooth 1e-5,
 denominator + 1e-8; loss.py:45-70,173-228) + nn.CrossEntropyLoss (loss.py:124-159).
 
-Round-1 note: expressed with torch tensor ops on the device (no host round trip, unlike the
-reference's CPU one-hot at loss.py:199-203); a fused HIP softmax+CE+Dice kernel is the next row of
-the scope table.
+dice_ce / dice_loss run as ``senas_dice_ce_fwd`` / ``senas_dice_ce_bwd``: one pass over
+the logits per direction, no one-hot tensor, no host round trip (the reference builds the one-hot on the CPU
+and copies it over, loss.py:199-203).  Like every op of this package there is no CPU path.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
-import torch.nn.functional as tf
+
+from . import _lib
+from . import functional as F
+from .arena import zeros64
+
+MAX_CLASSES = 8
+
+
+class _DiceCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, w_ce, w_dice, smooth, do_bg):
+        x = F.nhwc(logits)
+        n, c, h, w = x.shape
+        if c > MAX_CLASSES:
+            raise _lib.SenasHipError('dice_ce: %d classes (supported: 1..%d)' % (c, MAX_CLASSES))
+        if not target.is_cuda or tuple(target.shape) != (n, h, w):
+            raise _lib.SenasHipError('dice_ce: target must be a CUDA tensor of shape %s' % ((n, h, w),))
+        t = target.long().contiguous()
+        acc = zeros64((1 + 3 * c,), x.device)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        coef = torch.empty(3 * c + 1, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().senas_dice_ce_fwd(n * h * w, c, x.data_ptr(), t.data_ptr(), w_ce, w_dice, smooth, int(do_bg),
+                                                acc.data_ptr(), loss.data_ptr(), coef.data_ptr(), F._stream()), 'senas_dice_ce_fwd')
+        ctx.save_for_backward(x, t, coef)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, t, coef = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x, memory_format=F.CL)
+        dl = dloss.reshape(1).float().contiguous()
+        _lib.check(_lib.lib().senas_dice_ce_bwd(n * h * w, c, x.data_ptr(), t.data_ptr(), coef.data_ptr(), dl.data_ptr(),
+                                                dx.data_ptr(), F._stream()), 'senas_dice_ce_bwd')
+        return dx, None, None, None, None, None
+
+
+def dice_ce_loss(logits, target, weight_ce=1.0, weight_dice=1.0, smooth=1e-5, do_bg=False):
+    return _DiceCE.apply(logits, target, float(weight_ce), float(weight_dice), float(smooth), bool(do_bg))
 
 
 def soft_dice_loss(logits, target, smooth=1e-5, do_bg=False):
-    prob = tf.softmax(logits, 1)
-    onehot = torch.zeros_like(prob).scatter_(1, target.long().unsqueeze(1), 1.0)
-    dims = [0] + list(range(2, logits.dim()))
-    tp = (prob * onehot).sum(dims)
-    fp = (prob * (1 - onehot)).sum(dims)
-    fn = ((1 - prob) * onehot).sum(dims)
-    dc = (2 * tp + smooth) / (2 * tp + fp + fn + smooth + 1e-8)
-    if not do_bg:
-        dc = dc[1:]
-    return 1 - dc.mean()
+    return dice_ce_loss(logits, target, 0.0, 1.0, smooth, do_bg)
 
 
 class DiceCrossEntropyLoss(nn.Module):
@@ -33,8 +64,7 @@ class DiceCrossEntropyLoss(nn.Module):
         self.weight_ce, self.weight_dice = weight_ce, weight_dice
 
     def forward(self, net_output, target):
-        return self.weight_ce * tf.cross_entropy(net_output, target.long()) + \
-            self.weight_dice * soft_dice_loss(net_output, target)
+        return dice_ce_loss(net_output, target, self.weight_ce, self.weight_dice)
 
 
 class SegmentationLosses(nn.Module):

@@ -466,3 +466,37 @@ def test_fused_clip_sgd_matches_torch(cfg):
             if p.grad is not None:
                 close(q.grad, p.grad.cpu().numpy(), 'clipped grad %d step %d' % (k, step), rel=2e-6)
     assert set(opt_g.state_dict()['state'].keys()) == set(opt_r.state_dict()['state'].keys())
+
+
+@pytest.mark.parametrize('tag', gio.index('loss_metric'))
+def test_loss_and_metric_kernels(tag):
+    """senas_dice_ce_fwd/_bwd and senas_seg_metric_update against the reference's own outputs (golden vectors
+    from utils/loss/loss.py and utils/metrics.py) and against the oracle on a non-unit upstream gradient."""
+    from oracle import senas_ref as R
+    from senas_amd.loss import SegmentationLosses, soft_dice_loss
+    from senas_amd.metrics import SegmentationMetric
+    z = gio.load('loss_metric')
+    lg = torch.from_numpy(z[tag + '/logits'])
+    tgt = torch.from_numpy(z[tag + '/target'])
+    logits = lg.to(dev()).requires_grad_(True)
+    loss = SegmentationLosses('dice_ce')([logits], tgt.to(dev()))
+    np.testing.assert_allclose(loss.item(), float(z[tag + '/loss']), rtol=2e-6)
+    loss.backward()
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), z[tag + '/dlogits'], rtol=2e-5, atol=2e-9)
+    # scaled upstream gradient + the dice-only entry point
+    ref_in = lg.clone().requires_grad_(True)
+    (R.soft_dice_loss(ref_in, tgt) * 3.0).backward()
+    got_in = lg.to(dev()).requires_grad_(True)
+    (soft_dice_loss(got_in, tgt.to(dev())) * 3.0).backward()
+    np.testing.assert_allclose(got_in.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=2e-5, atol=2e-9)
+    m = SegmentationMetric(lg.shape[1])
+    m.update(tgt.to(dev()), logits.detach())
+    m.update(tgt.to(dev()), logits.detach() * 0.5 + 0.1)
+    np.testing.assert_allclose(np.array(m.get()), z[tag + '/metric'], atol=2e-3)
+    # hard counts are integers: bit-exact against the oracle
+    cnt = None
+    for t in (lg, lg * 0.5 + 0.1):
+        c = R.hard_counts(t, tgt)
+        cnt = c if cnt is None else tuple(a + b for a, b in zip(cnt, c))
+    tp, fp, fn = m.counts()
+    assert [list(map(int, v)) for v in (tp, fp, fn)] == [[int(q) for q in np.asarray(v).reshape(-1)] for v in cnt]

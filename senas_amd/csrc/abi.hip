@@ -15,3 +15,4 @@ void set_error_msg(const char* what) {
 
 extern "C" const char* senas_last_error(void) { return senas::g_err; }
 extern "C" int senas_abi_version(void) { return 4; }
+

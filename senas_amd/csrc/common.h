@@ -24,6 +24,25 @@ inline int launch_status(const char* what) {
 
 constexpr int kWave = 64;   // gfx950 wavefront
 
+// Phase timestamps for kernel tuning: only in the debug library (`make phases` -> libsenas_hip_phases.so, used by
+// tools/phase_probe.py); the shipped library compiles PHASE() to nothing.  100 MHz wall clock, block 0 / thread 0.
+#ifdef SENAS_PHASES
+static __device__ unsigned long long senas_phase_buf[64];          // one per translation unit
+#define SENAS_PHASE_READER(name)                                                                          \
+    extern "C" int senas_debug_read_phases_##name(unsigned long long* host64) {                           \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                              \
+        return hipMemcpyFromSymbol(host64, HIP_SYMBOL(senas::senas_phase_buf), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; \
+    }
+#define SENAS_PHASE(k)                                                                                   \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)                   \
+            senas_phase_buf[k] = wall_clock64();                                                         \
+    } while (0)
+#else
+#define SENAS_PHASE(k) do { } while (0)
+#define SENAS_PHASE_READER(name)
+#endif
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
@@ -80,6 +99,7 @@ void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hip
 
 // conv_lds.hip (stride-1 "same" convolutions with the input window staged in LDS)
 bool lds_gather_ok(const GatherGeom& g);
+void lds_gather_shape(const GatherGeom& g, int& mt, int& ks);
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st);

@@ -609,9 +609,15 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && !tr && thin_n_ok(gg)) return gg.cout <= 2 ? "conv_thin_n_kernel<2>" : "conv_thin_n_kernel<4>";
     if (!tr && lds_gather_ok(gg)) {
-        const long blocks8 = (long)((gg.wout + 31) / 32) * ((gg.hout + 7) / 8) * gg.n * ((gg.cout + 31) / 32);
-        const bool big = blocks8 >= 512 && gg.hout >= 8;
-        return tg ? (big ? "conv_lds_kernel<true, 2>" : "conv_lds_kernel<true, 1>") : (big ? "conv_lds_kernel<false, 2>" : "conv_lds_kernel<false, 1>");
+        int mt, ks;
+        lds_gather_shape(gg, mt, ks);
+        static char buf[8][48];
+        static int slot = 0;
+        char* b = buf[slot++ & 7];
+        const int taps = g->kh * g->kw;
+        const int maxt = ks == 1 ? 1 : (taps <= 9 ? (9 + ks - 1) / ks : (25 + ks - 1) / ks);
+        snprintf(b, 48, "conv_lds_kernel<%s, %d, %d, %d>", tg ? "true" : "false", mt, ks, maxt);
+        return b;
     }
     if (mfma_gather_ok(gg, tg)) {
         const bool s2 = tg && gg.stride == 2;

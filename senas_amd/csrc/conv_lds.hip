@@ -13,6 +13,10 @@
 // 64 B data + 16 B pad: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots), so the
 // window costs 880 px * 80 B = 69 KiB for 5x5 dilation 3 at MT = 2 -- two blocks per CU, one loading
 // while the other computes.  B fragments (weights) stream from the packed image in L2.
+//
+// KS > 1 (small maps): the block grows to 4*KS waves; wave (rw, kg) works on tile row rw and the taps kg, kg + KS, ...
+// -- the per-block tap loop, which is the whole critical path when a launch has fewer tiles than the chip has CUs,
+// gets KS times shorter; the KS partial accumulators meet in LDS (pairwise fold) before the epilogue.
 #include "common.h"
 
 namespace senas {
@@ -37,15 +41,21 @@ struct Frag {
 
 }  // namespace
 
-// grid = (tiles_x, tiles_y, n * co_tiles); dynamic LDS = tile_h * tile_w * PST floats
-template <bool TG, int MT>
-__global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
+// grid = (tiles_x, tiles_y, n * co_tiles); dynamic LDS = max(tile_h * tile_w * PST floats, fold scratch)
+// MAXT (KS > 1 only): taps per wave group, rounded up -- those variants keep ALL their weight fragments of a channel
+// pass in registers, requested before the window is staged, so the short tap loop of a small-map block never waits
+// for L2 (with 6-7 taps per wave there is not enough MFMA work per tap to hide a weight fetch behind).
+template <bool TG, int MT, int KS, int MAXT>
+__global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
                                                        double* __restrict__ stats) {
     constexpr int TH = 4 * MT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NT = 256 * KS;
+    const int lane = threadIdx.x & 63;
+    const int wave = (threadIdx.x >> 6) & 3;             // tile row group
+    const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // tap group (wave-uniform)
     const int r = lane & 31, h = lane >> 5;
     const int n = blockIdx.z % g.n, cot = blockIdx.z / g.n;
     const int co = cot * 32 + r;
@@ -68,17 +78,30 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
     const int lbase = ((MT * wave) * tile_w + r) * P4 + h;
     const int lrow = tile_w * P4;
 
+    SENAS_PHASE(0);
     for (int pass = 0; pass < npass; ++pass) {
+        float4 bfr[KS > 1 ? MAXT : 1][2];                // KS > 1: this wave's weight fragments of the pass
+        if (KS > 1) {
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) {
+                const int t = kg + KS * i;
+                const float* wt = wp + ((size_t)(t < taps ? t : 0) * ngroups + pass * 2) * 256;
+                bfr[i][0] = *reinterpret_cast<const float4*>(wt);
+                bfr[i][1] = *reinterpret_cast<const float4*>(wt + 256);
+                if (t >= taps) bfr[i][0] = bfr[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);      // padding slot: adds nothing
+            }
+        }
         __syncthreads();                                 // previous pass's readers are done
+        SENAS_PHASE(1 + pass * 4);
         // ---- stage the window: thread = one 16-byte piece; 4 consecutive threads = one pixel's 64 B
         const float* src = in + (size_t)n * g.hin * g.win * g.cin + pass * CH;
         const int pieces = tile_h * tile_w * 4;
-        for (int base = 0; base < pieces; base += 256 * 4) {       // 4 loads in flight per thread
+        for (int base = 0; base < pieces; base += NT * 4) {        // 4 loads in flight per thread
             float4 v[4];
             int dst[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + threadIdx.x;
+                const int idx = base + u * NT + threadIdx.x;
                 const int pix = idx >> 2, q = idx & 3;
                 const int ty = pix / tile_w, tx = pix - ty * tile_w;
                 const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
@@ -93,7 +116,9 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
                 if (dst[u] >= 0) lds4[dst[u]] = v[u];
             }
         }
+        SENAS_PHASE(2 + pass * 4);
         __syncthreads();
+        SENAS_PHASE(3 + pass * 4);
 
         // ---- taps, software-pipelined over two alternating fragment sets (no register copies):
         // while tap t's MFMAs issue, tap t+1's A fragments (LDS) and B fragments (L2) are in flight
@@ -136,24 +161,80 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
                     acc[m] = mfma32(cur.a[c2][m].w, cur.b[c2].w, acc[m]);
                 }
         };
-        Frag<MT> f0, f1;
-        int toff;
-        const float* wt;
-        tap_ptrs(0, toff, wt);
-        load_b(wt, f0);
-        load_a(toff, f0);
-        for (int t = 0;;) {
-            bool more = t + 1 < taps;
-            if (more) tap_ptrs(t + 1, toff, wt);
-            step(f0, f1, more, toff, wt);
-            if (++t >= taps) break;
-            more = t + 1 < taps;
-            if (more) tap_ptrs(t + 1, toff, wt);
-            step(f1, f0, more, toff, wt);
-            if (++t >= taps) break;
+        if (KS == 1) {
+            Frag<MT> f0, f1;
+            int toff;
+            const float* wt;
+            tap_ptrs(0, toff, wt);
+            load_b(wt, f0);
+            load_a(toff, f0);
+            for (int t = 0;;) {
+                bool more = t + 1 < taps;
+                if (more) tap_ptrs(t + 1, toff, wt);
+                step(f0, f1, more, toff, wt);
+                if (++t >= taps) break;
+                more = t + 1 < taps;
+                if (more) tap_ptrs(t + 1, toff, wt);
+                step(f1, f0, more, toff, wt);
+                if (++t >= taps) break;
+            }
+        } else {
+            // straight-line: weights are in registers, A fragments come from LDS with compile-time trip counts
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) {
+                const int t = kg + KS * i;
+                int toff;
+                const float* unused;
+                tap_ptrs(t < taps ? t : 0, toff, unused);
+                float4 fa[2][MT];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) fa[c2][m] = lds4[lbase + m * lrow + toff + c2 * 2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m] = mfma32(fa[c2][m].x, bfr[i][c2].x, acc[m]);
+                        acc[m] = mfma32(fa[c2][m].y, bfr[i][c2].y, acc[m]);
+                        acc[m] = mfma32(fa[c2][m].z, bfr[i][c2].z, acc[m]);
+                        acc[m] = mfma32(fa[c2][m].w, bfr[i][c2].w, acc[m]);
+                    }
+            }
+        }
+        SENAS_PHASE(4 + pass * 4);
+    }
+
+    SENAS_PHASE(40);
+    if (KS > 1) {            // pairwise fold of the tap groups' accumulators: [slot][sub-tile][quad][lane] float4
+        float4* fold = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int sgrp = KS / 2; sgrp >= 1; sgrp >>= 1) {
+            __syncthreads();
+            if (kg >= sgrp && kg < 2 * sgrp) {
+                const int slot = (kg - sgrp) * 4 + wave;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        fold[((slot * MT + m) * 4 + q4) * 64 + lane] =
+                            make_float4(acc[m][4 * q4], acc[m][4 * q4 + 1], acc[m][4 * q4 + 2], acc[m][4 * q4 + 3]);
+            }
+            __syncthreads();
+            if (kg < sgrp) {
+                const int slot = kg * 4 + wave;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 pv = fold[((slot * MT + m) * 4 + q4) * 64 + lane];
+                        acc[m][4 * q4] += pv.x; acc[m][4 * q4 + 1] += pv.y; acc[m][4 * q4 + 2] += pv.z; acc[m][4 * q4 + 3] += pv.w;
+                    }
+            }
         }
     }
 
+    SENAS_PHASE(41);
     // ---- epilogue: lane = output channel, register v = pixel (row MT*wave + m, column acc_row(v, h))
     const bool cok = co < g.cout;
     double s = 0.0, q = 0.0;
@@ -164,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
         for (int v = 0; v < 16; ++v) {
             const int ox = ox0 + acc_row(v, h);
             float val = acc[m][v];
-            if (oy < g.hout && ox < g.wout && cok) {
+            if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
                 const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
                 if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
                 out[o] = val;
@@ -173,21 +254,25 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(GatherGeom g, const float
             }
         }
     }
+    SENAS_PHASE(42);
     if (stats != nullptr) {                              // block-level reduction: 2 atomics per channel per block
         __syncthreads();
         double* red = reinterpret_cast<double*>(lds);    // [4 waves][32 channels][2]
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
-        if (h == 0) { red[(wave * 32 + r) * 2] = s; red[(wave * 32 + r) * 2 + 1] = q; }
+        if (kg == 0 && h == 0) { red[(wave * 32 + r) * 2] = s; red[(wave * 32 + r) * 2 + 1] = q; }
         __syncthreads();
-        if (wave == 0 && h == 0 && cok) {
+        if (kg == 0 && wave == 0 && h == 0 && cok) {
             for (int w = 1; w < 4; ++w) { s += red[(w * 32 + r) * 2]; q += red[(w * 32 + r) * 2 + 1]; }
             double* st = stats + ((size_t)n * g.cout + co) * 2;
             atomicAdd(st, s);
             atomicAdd(st + 1, q);
         }
     }
+    SENAS_PHASE(43);
 }
+
+SENAS_PHASE_READER(conv_lds)
 
 bool lds_gather_ok(const GatherGeom& g) {
     // stride 1, "same" padding, 16-channel passes, maps at least one tile wide
@@ -198,31 +283,54 @@ bool lds_gather_ok(const GatherGeom& g) {
     return bytes <= 150 * 1024 && (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
 }
 
-template <bool TG, int MT>
+static size_t conv_lds_bytes(const GatherGeom& g, int th, int mt, int ks) {
+    size_t bytes = (size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    const size_t fold = ks > 1 ? (size_t)(ks / 2) * 4 * mt * 4096 : 0;
+    if (bytes < 4 * 32 * 2 * sizeof(double)) bytes = 4 * 32 * 2 * sizeof(double);      // statistics scratch
+    return fold > bytes ? fold : bytes;
+}
+
+template <bool TG, int MT, int KS, int MAXT>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                               const float* mask, double* stats, hipStream_t st) {
     constexpr int TH = 4 * MT;
-    const size_t bytes = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
+    const size_t bytes = conv_lds_bytes(g, TH, MT, KS);
     static bool attr_set = false;
     if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
     dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG, MT>), grid, dim3(256), bytes, st, g, in, wp, out, in_relu, mask, stats);
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT>), grid, dim3(256 * KS), bytes, st, g, in, wp, out, in_relu, mask, stats);
     return launch_status("conv_lds");
+}
+
+// (MT, KS) for a geometry: 8x32 tiles when they still give every CU two blocks; otherwise 4x32 tiles, and when even
+// those leave the chip under-filled the taps of a tile are dealt to 2 or 4 groups of waves (small maps are
+// critical-path-bound, not throughput-bound)
+void lds_gather_shape(const GatherGeom& g, int& mt, int& ks) {
+    const long cot = (g.cout + 31) / 32, tx = (g.wout + TW - 1) / TW;
+    const long blocks8 = tx * ((g.hout + 7) / 8) * g.n * cot, blocks4 = tx * ((g.hout + 3) / 4) * g.n * cot;
+    const int taps = g.kh * g.kw;
+    mt = (blocks8 >= 512 && g.hout >= 8) ? 2 : 1;
+    ks = 1;
+    if (mt == 1 && taps >= 9 && taps <= 25) ks = blocks4 <= 256 ? 4 : (blocks4 <= 512 ? 2 : 1);
 }
 
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st) {
-    // 8x32 tiles when they still give every CU two blocks; otherwise 4x32 tiles: twice the blocks and half
-    // the serial tap loop per block (small maps are critical-path-bound, not throughput-bound)
-    const long blocks8 = (long)((g.wout + TW - 1) / TW) * ((g.hout + 7) / 8) * g.n * ((g.cout + 31) / 32);
-    if (blocks8 >= 512 && g.hout >= 8) return launch_lds_variant<TG, 2>(g, in, wp, out, in_relu, mask, stats, st);
-    return launch_lds_variant<TG, 1>(g, in, wp, out, in_relu, mask, stats, st);
+    int mt, ks;
+    lds_gather_shape(g, mt, ks);
+    const int taps = g.kh * g.kw;
+    if (mt == 2) return launch_lds_variant<TG, 2, 1, 1>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 4 && taps <= 9) return launch_lds_variant<TG, 1, 4, 3>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 4 && taps <= 25) return launch_lds_variant<TG, 1, 4, 7>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 2 && taps <= 9) return launch_lds_variant<TG, 1, 2, 5>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 2 && taps <= 25) return launch_lds_variant<TG, 1, 2, 13>(g, in, wp, out, in_relu, mask, stats, st);
+    return launch_lds_variant<TG, 1, 1, 1>(g, in, wp, out, in_relu, mask, stats, st);
 }
 
 template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);

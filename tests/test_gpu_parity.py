@@ -360,6 +360,8 @@ _CONV_CASES = [
     (1, 96, 32, 16, 32, 3, 1, 1, False, False),     # 27 units
     (1, 96, 16, 8, 32, 1, 1, 1, False, False),      # 3 units, 16 output channels (padded columns)
     (1, 128, 32, 8, 32, 1, 1, 1, False, True),      # 4 units
+    (8, 32, 32, 64, 96, 3, 1, 1, False, True),      # LDS window kernel with the taps dealt to 2 wave groups
+    (8, 16, 32, 72, 128, 3, 1, 1, False, False),    # 4x32 tiles, one wave group (between the two regimes)
 ]
 
 

@@ -616,7 +616,8 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         char* b = buf[slot++ & 7];
         const int taps = g->kh * g->kw;
         const int maxt = ks == 1 ? 1 : (taps <= 9 ? (9 + ks - 1) / ks : (25 + ks - 1) / ks);
-        snprintf(b, 48, "conv_lds_kernel<%s, %d, %d, %d>", tg ? "true" : "false", mt, ks, maxt);
+        const int pf = 0;          // next-pass prefetch measured slower than relying on the co-resident block
+        snprintf(b, 48, "conv_lds_kernel<%s, %d, %d, %d, %d>", tg ? "true" : "false", mt, ks, maxt, pf);
         return b;
     }
     if (mfma_gather_ok(gg, tg)) {

@@ -45,7 +45,10 @@ struct Frag {
 // MAXT (KS > 1 only): taps per wave group, rounded up -- those variants keep ALL their weight fragments of a channel
 // pass in registers, requested before the window is staged, so the short tap loop of a small-map block never waits
 // for L2 (with 6-7 taps per wave there is not enough MFMA work per tap to hide a weight fetch behind).
-template <bool TG, int MT, int KS, int MAXT>
+// PF: 16-byte pieces of the NEXT channel pass's window each thread requests before the tap loop of the current pass
+// and parks in registers until the loop is done -- the HBM/L2 latency of staging hides behind the MFMAs (only the
+// first pass of a block is staged in the open; pieces beyond PF per thread are fetched after the loop).
+template <bool TG, int MT, int KS, int MAXT, int PF>
 __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
@@ -78,7 +81,64 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
     const int lbase = ((MT * wave) * tile_w + r) * P4 + h;
     const int lrow = tile_w * P4;
 
+    // staging geometry of this thread (pass-independent): slot k holds window pixel k*(NT/4) + (tid>>2), piece tid&3
+    constexpr int XL = NT / 4;
+    const int sq = threadIdx.x & 3, spl = threadIdx.x >> 2;
+    const int ty0 = spl / tile_w, tx0 = spl - ty0 * tile_w;
+    const int dty = XL / tile_w, dtx = XL - dty * tile_w;             // slot-to-slot step in (row, column)
+    const int wpix = tile_h * tile_w;
+    const float* src0 = in + (size_t)n * g.hin * g.win * g.cin + sq * 4;
+    float4 pf[PF > 0 ? PF : 1];
+    auto issue = [&](int pass) {                                       // loads only; borders resolved in commit
+        const float* src = src0 + pass * CH;
+        int ty = ty0, tx = tx0;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const bool inb = k * XL + spl < wpix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            pf[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.win + ix) * g.cin : 0));
+            ty += dty; tx += dtx;
+            if (tx >= tile_w) { tx -= tile_w; ++ty; }
+        }
+    };
+    auto commit = [&](int pass) {                                      // registers -> LDS, then the remainder
+        const float* src = src0 + pass * CH;
+        int ty = ty0, tx = tx0;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const bool live = k * XL + spl < wpix;
+            const bool inb = live && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            float4 v = pf[k];
+            if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) lds4[(k * XL + spl) * P4 + sq] = v;
+            ty += dty; tx += dtx;
+            if (tx >= tile_w) { tx -= tile_w; ++ty; }
+        }
+        for (int k0 = PF; k0 * XL < wpix; k0 += 4) {                   // 4 loads in flight per thread
+            float4 v[4];
+            bool ok[4], lv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+                lv[u] = (k0 + u) * XL + spl < wpix;
+                ok[u] = lv[u] && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+                v[u] = *reinterpret_cast<const float4*>(src + (ok[u] ? ((size_t)iy * g.win + ix) * g.cin : 0));
+                ty += dty; tx += dtx;
+                if (tx >= tile_w) { tx -= tile_w; ++ty; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in_relu) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
+                if (!ok[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lv[u]) lds4[((k0 + u) * XL + spl) * P4 + sq] = v[u];
+            }
+        }
+    };
+
     SENAS_PHASE(0);
+    issue(0);
     for (int pass = 0; pass < npass; ++pass) {
         float4 bfr[KS > 1 ? MAXT : 1][2];                // KS > 1: this wave's weight fragments of the pass
         if (KS > 1) {
@@ -93,32 +153,11 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
         }
         __syncthreads();                                 // previous pass's readers are done
         SENAS_PHASE(1 + pass * 4);
-        // ---- stage the window: thread = one 16-byte piece; 4 consecutive threads = one pixel's 64 B
-        const float* src = in + (size_t)n * g.hin * g.win * g.cin + pass * CH;
-        const int pieces = tile_h * tile_w * 4;
-        for (int base = 0; base < pieces; base += NT * 4) {        // 4 loads in flight per thread
-            float4 v[4];
-            int dst[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * NT + threadIdx.x;
-                const int pix = idx >> 2, q = idx & 3;
-                const int ty = pix / tile_w, tx = pix - ty * tile_w;
-                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
-                const bool inb = idx < pieces && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                dst[u] = idx < pieces ? pix * P4 + q : -1;
-                v[u] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.win + ix) * g.cin + q * 4 : 0));
-                if (!inb) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (in_relu) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
-                if (dst[u] >= 0) lds4[dst[u]] = v[u];
-            }
-        }
+        commit(pass);
         SENAS_PHASE(2 + pass * 4);
         __syncthreads();
         SENAS_PHASE(3 + pass * 4);
+        if (pass + 1 < npass) issue(pass + 1);           // in flight during the tap loop
 
         // ---- taps, software-pipelined over two alternating fragment sets (no register copies):
         // while tap t's MFMAs issue, tap t+1's A fragments (LDS) and B fragments (L2) are in flight
@@ -290,20 +329,20 @@ static size_t conv_lds_bytes(const GatherGeom& g, int th, int mt, int ks) {
     return fold > bytes ? fold : bytes;
 }
 
-template <bool TG, int MT, int KS, int MAXT>
+template <bool TG, int MT, int KS, int MAXT, int PF>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                               const float* mask, double* stats, hipStream_t st) {
     constexpr int TH = 4 * MT;
     const size_t bytes = conv_lds_bytes(g, TH, MT, KS);
     static bool attr_set = false;
     if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
     dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT>), grid, dim3(256 * KS), bytes, st, g, in, wp, out, in_relu, mask, stats);
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF>), grid, dim3(256 * KS), bytes, st, g, in, wp, out, in_relu, mask, stats);
     return launch_status("conv_lds");
 }
 
@@ -325,12 +364,12 @@ int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, flo
     int mt, ks;
     lds_gather_shape(g, mt, ks);
     const int taps = g.kh * g.kw;
-    if (mt == 2) return launch_lds_variant<TG, 2, 1, 1>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 4 && taps <= 9) return launch_lds_variant<TG, 1, 4, 3>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 4 && taps <= 25) return launch_lds_variant<TG, 1, 4, 7>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 2 && taps <= 9) return launch_lds_variant<TG, 1, 2, 5>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 2 && taps <= 25) return launch_lds_variant<TG, 1, 2, 13>(g, in, wp, out, in_relu, mask, stats, st);
-    return launch_lds_variant<TG, 1, 1, 1>(g, in, wp, out, in_relu, mask, stats, st);
+    if (mt == 2) return launch_lds_variant<TG, 2, 1, 1, 0>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 4 && taps <= 9) return launch_lds_variant<TG, 1, 4, 3, 0>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 4 && taps <= 25) return launch_lds_variant<TG, 1, 4, 7, 0>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 2 && taps <= 9) return launch_lds_variant<TG, 1, 2, 5, 0>(g, in, wp, out, in_relu, mask, stats, st);
+    if (ks == 2 && taps <= 25) return launch_lds_variant<TG, 1, 2, 13, 0>(g, in, wp, out, in_relu, mask, stats, st);
+    return launch_lds_variant<TG, 1, 1, 1, 0>(g, in, wp, out, in_relu, mask, stats, st);
 }
 
 template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);

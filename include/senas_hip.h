@@ -55,7 +55,7 @@ typedef struct senas_conv_geom {
  * sum of squares of y into it (producer-side batch-norm statistics; caller zeroes it).          */
 /* ws: device scratch of at least senas_conv2d_ws_bytes(g) bytes (repacked weights / partial sums),
  * private to the call until the stream has passed it.                                          */
-int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);
+int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);     /* forward and data gradient */
 /* packed (optional, may be NULL): the MFMA fragment image of w for this direction, kept up to date by
  * the caller with senas_pack_batched (layout from senas_conv2d_pack_layout).  NULL: the launcher
  * repacks w into ws itself.  Ignored by the non-MFMA fallback kernels.                            */
@@ -76,6 +76,9 @@ int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d
                              int64_t* elems);
 /* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
 int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
+/* Workspace of the weight gradient: *bytes to allocate and whether it must be zero-filled on entry
+ * (*needs_zero != 0; pass ws_is_zero accordingly, or 0 to let the call clear it itself).            */
+int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* bytes, int32_t* needs_zero);
 /* dw (same layout as w) is OVERWRITTEN.  ws_is_zero != 0: the caller guarantees that ws is zero-filled
  * (lets the launcher skip its own memset of the split-K accumulation image).                    */
 int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,

@@ -384,12 +384,21 @@ extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
     const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
     const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
-    int64_t bytes = (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
-    if (small <= 4) {                                    // thin weight gradient: per-block partials
-        const int64_t part = (int64_t)512 * g->ci * g->co * g->kh * g->kw * sizeof(float) + 256;
-        if (part > bytes) bytes = part;
-    }
-    return bytes;
+    return (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
+}
+
+// Workspace of the weight gradient: which path it takes decides the size and whether it must arrive zero-filled.
+extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* bytes, int32_t* needs_zero) {
+    SENAS_REQUIRE(geom_ok(g) && bytes && needs_zero, "conv2d_bwd_weight_ws: bad argument");
+    *bytes = senas_conv2d_ws_bytes(g);
+    *needs_zero = 0;
+    if (g->groups != 1) return SENAS_OK;                           // per-block partials, overwritten
+    WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
+                                  : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (thin_n_wgrad_ok(wg)) { *bytes = thin_n_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
+    if (!g->transposed && lds_wgrad_ok(wg)) { *bytes = lds_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
+    if (mfma_wgrad_ok(wg)) *needs_zero = 1;                        // split-K image accumulated with atomics
+    return SENAS_OK;
 }
 
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
@@ -546,15 +555,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
     }
     if (!g->transposed && lds_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
-        float* wsp = reinterpret_cast<float*>(ws);
-        if (!ws_is_zero) {
-            hipError_t e0 = hipMemsetAsync(wsp, 0, (size_t)taps * wg.A * 32 * sizeof(float), st);
-            if (e0 != hipSuccess) { set_error("memset wgrad ws", e0); return SENAS_ELAUNCH; }
-        }
-        const int rc = launch_lds_wgrad(wg, I, G, wsp, i_relu, st);
-        if (rc != SENAS_OK) return rc;
-        launch_unpack_wgrad(wsp, dw, wg.A, wg.B, taps, st);
-        return launch_status("wgrad_lds unpack");
+        return launch_lds_wgrad(wg, I, G, reinterpret_cast<float*>(ws), dw, i_relu, st);      // ws need not be zero here
     }
     if (mfma_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");

@@ -28,25 +28,29 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 
 }  // namespace
 
-// A: in-channels (multiple of 32, <= 128); UW: accumulators per wave; RS: row split -- the 8 waves form
-// 8/RS unit groups x RS row lanes: wave (ug, rs) owns units ug, ug + 8/RS, ... and the tile rows rs, rs + RS, ...
-// (few taps -> large RS, so a 1x1 or 3x3 kernel still keeps all 8 waves on the matrix cores; the row lanes'
-// partial sums meet in LDS before the one atomic pass).  grid = persistent blocks of 512 threads.
+// A: in-channels (multiple of 32, <= 128).  The work units (tap, 32-channel slice of a) are dealt to the 8 waves as
+//   Q   "full" units per wave (unit w + 8t, all rows of every tile), and
+//   REM "shared" units (units 8Q .. 8Q+REM-1), whose tile rows are dealt round-robin: wave w takes row r of shared
+//       unit j when (r + j) % 8 == w
+// so every wave issues the same number of MFMAs whatever the unit count is (25 units = 3 full + 1 shared, a 1x1
+// kernel = 1 shared: 8 row lanes).  Accumulators stay in registers ACROSS tiles; at the end the shared units' 8
+// partials meet in LDS and every unit is written ONCE, without atomics, to this block's slice of the partial
+// image part[block][unit][32][32] -- the unpack launch adds the blocks' slices in a fixed order (bitwise
+// reproducible weight gradients) while it transposes to the torch layout.
 // PFX: 16-byte pieces of the NEXT tile's X window each thread requests before the K loop of the current tile
 // and parks in registers until the loop is done (the G tile always travels that way), so the HBM/L2 latency
 // of staging hides behind the MFMAs; pieces beyond PFX*512 are fetched after the loop.
 // dynamic LDS: X window [(th + 2*halo) * (32 + 2*halo)][A] floats, then G tile [th * 32][32] floats.
-template <int A, int UW, int RS, int PFX>
+template <int A, int Q, int REM, int PFX>
 __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float* __restrict__ X,
-                                                        const float* __restrict__ G, float* __restrict__ dwp,
+                                                        const float* __restrict__ G, float* __restrict__ part,
                                                         int x_relu, int th, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int UG = 8 / RS;
+    constexpr int UW = Q + REM;
     constexpr int PP = A / 4;                    // 16-byte pieces per pixel of X
     constexpr int XL = 512 / PP;                 // pixels of the window covered by one slot
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
-    const int rs = wave % RS, ug = wave / RS;
     const int r = lane & 31, h = lane >> 5;
     const int halo = g.pad;
     const int tile_w = TW + 2 * halo, tile_h = th + 2 * halo;
@@ -55,16 +59,13 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
     float4* xs4 = reinterpret_cast<float4*>(xs);
     float4* gs4 = reinterpret_cast<float4*>(gs);
     constexpr int a_tiles = A / 32;
-    const int taps = g.kh * g.kw;
-    const int units = taps * a_tiles;
 
-    // this wave's units: u = ug + UG*t; slots past the last unit reuse unit 0's operands
+    // accumulator t < Q: full unit wave + 8t; t >= Q: shared unit 8Q + (t - Q)
     int uoff[UW];                 // LDS float offset of the unit's tap shift + channel slice
 #pragma unroll
     for (int t = 0; t < UW; ++t) {
-        const int u = ug + UG * t;
-        const int uc = u < units ? u : 0;
-        const int tap = uc / a_tiles, at = uc - tap * a_tiles;
+        const int u = t < Q ? wave + 8 * t : 8 * Q + (t - Q);
+        const int tap = u / a_tiles, at = u - tap * a_tiles;
         const int ky = tap / g.kw, kx = tap - ky * g.kw;
         uoff[t] = ((ky * g.dil) * tile_w + kx * g.dil) * A + at * 32 + r;
     }
@@ -177,89 +178,114 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         commit(tile);
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);     // in flight during the K loop
-        // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15).
-        // Straight-line code: slots past the last unit compute on unit 0's operands and are dropped in the
-        // epilogue (they sit in the shadow of the waves that own a real unit there), and the operands of step
-        // s+1 are requested before the MFMAs of step s are issued.
-        for (int row = rs; row < th; row += RS) {
+        // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15); straight-line
+        // per (row, unit group): the operands of step s+1 are requested before the MFMAs of step s are issued
+        for (int row = 0; row < th; ++row) {
             const float* gp = gs + (row * TW + 16 * h) * 32 + r;
             const float* xp = xs + (row * tile_w + 16 * h) * A;
-            float b = gp[0], a[UW];
+            if (Q > 0) {
+                float b = gp[0], a[Q > 0 ? Q : 1];
 #pragma unroll
-            for (int t = 0; t < UW; ++t) a[t] = xp[uoff[t]];
+                for (int t = 0; t < Q; ++t) a[t] = xp[uoff[t]];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float bn = 0.f, an[UW];
-                if (s < 15) {
-                    bn = gp[(s + 1) * 32];
+                for (int s = 0; s < 16; ++s) {
+                    float bn = 0.f, an[Q > 0 ? Q : 1];
+                    if (s < 15) {
+                        bn = gp[(s + 1) * 32];
 #pragma unroll
-                    for (int t = 0; t < UW; ++t) an[t] = xp[uoff[t] + (s + 1) * A];
+                        for (int t = 0; t < Q; ++t) an[t] = xp[uoff[t] + (s + 1) * A];
+                    }
+#pragma unroll
+                    for (int t = 0; t < Q; ++t) acc[t] = mfma32(a[t], b, acc[t]);
+                    if (s < 15) {
+                        b = bn;
+#pragma unroll
+                        for (int t = 0; t < Q; ++t) a[t] = an[t];
+                    }
                 }
+            }
 #pragma unroll
-                for (int t = 0; t < UW; ++t) acc[t] = mfma32(a[t], b, acc[t]);
-                if (s < 15) {
-                    b = bn;
+            for (int j = 0; j < REM; ++j) {
+                if (((row + j) & 7) == wave) {                    // wave-uniform: this row of shared unit j is mine
+                    float b = gp[0], a = xp[uoff[Q + j]];
 #pragma unroll
-                    for (int t = 0; t < UW; ++t) a[t] = an[t];
+                    for (int s = 0; s < 16; ++s) {
+                        float bn = 0.f, an = 0.f;
+                        if (s < 15) { bn = gp[(s + 1) * 32]; an = xp[uoff[Q + j] + (s + 1) * A]; }
+                        acc[Q + j] = mfma32(a, b, acc[Q + j]);
+                        b = bn; a = an;
+                    }
                 }
             }
         }
     }
-    // ---- one atomic pass per block: dwp[tap][a][32]
-    if (RS == 1) {
-        if (r < g.B) {
-#pragma unroll
-            for (int t = 0; t < UW; ++t) {
-                const int u = ug + UG * t;
-                if (u < units) {
-                    const int tap = u / a_tiles, abase = (u - tap * a_tiles) * 32;
-#pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        atomicAdd(&dwp[((size_t)tap * A + abase + acc_row(v, h)) * 32 + r], acc[t][v]);
-                }
-            }
-        }
-    } else {
-        // the RS row lanes of a unit group fold their accumulators pairwise through LDS (the staging buffers are
-        // free now): log2(RS) rounds of "upper half stores, lower half adds", 16-byte conflict-free accesses
-        // ([slot][quad][lane] float4), then row lane 0 issues the atomics from registers.
+    // ---- shared units: the 8 waves' partial sums fold pairwise through LDS (the staging buffers are free now),
+    // 16-byte conflict-free accesses ([slot][unit][quad][lane] float4); wave 0 ends up with the totals
+    if (REM > 0) {
         float4* fold = reinterpret_cast<float4*>(lds);
 #pragma unroll
-        for (int step = RS / 2; step >= 1; step >>= 1) {
+        for (int step = 4; step >= 1; step >>= 1) {
             __syncthreads();
-            if (rs >= step && rs < 2 * step) {
-                const int slot = ug * step + (rs - step);
+            if (wave >= step && wave < 2 * step) {
+                const int slot = wave - step;
 #pragma unroll
-                for (int t = 0; t < UW; ++t)
+                for (int j = 0; j < REM; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        fold[((slot * UW + t) * 4 + q) * 64 + lane] =
-                            make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                        fold[((slot * REM + j) * 4 + q) * 64 + lane] =
+                            make_float4(acc[Q + j][4 * q], acc[Q + j][4 * q + 1], acc[Q + j][4 * q + 2], acc[Q + j][4 * q + 3]);
             }
             __syncthreads();
-            if (rs < step) {
-                const int slot = ug * step + rs;
+            if (wave < step) {
 #pragma unroll
-                for (int t = 0; t < UW; ++t)
+                for (int j = 0; j < REM; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 p = fold[((slot * UW + t) * 4 + q) * 64 + lane];
-                        acc[t][4 * q] += p.x; acc[t][4 * q + 1] += p.y; acc[t][4 * q + 2] += p.z; acc[t][4 * q + 3] += p.w;
+                        const float4 p = fold[((wave * REM + j) * 4 + q) * 64 + lane];
+                        acc[Q + j][4 * q] += p.x; acc[Q + j][4 * q + 1] += p.y; acc[Q + j][4 * q + 2] += p.z; acc[Q + j][4 * q + 3] += p.w;
                     }
             }
         }
-        if (rs == 0 && r < g.B) {
+    }
+    // ---- this block's slice of the partial image: part[block][unit][a (32)][b (32)], every element written once
+    float* mine = part + (size_t)blockIdx.x * (8 * Q + REM) * 1024;
 #pragma unroll
-            for (int t = 0; t < UW; ++t) {
-                const int u = ug + UG * t;
-                if (u < units) {
-                    const int tap = u / a_tiles, abase = (u - tap * a_tiles) * 32;
+    for (int t = 0; t < UW; ++t) {
+        if (t < Q || wave == 0) {
+            const int u = t < Q ? wave + 8 * t : 8 * Q + (t - Q);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        atomicAdd(&dwp[((size_t)tap * A + abase + acc_row(v, h)) * 32 + r], acc[t][v]);
-                }
-            }
+            for (int v = 0; v < 16; ++v) mine[(size_t)u * 1024 + acc_row(v, h) * 32 + r] = acc[t][v];
         }
+    }
+}
+
+// part[block][unit = tap*a_tiles + at][32 a][32 b] summed over the blocks -> torch layout dw[b][a][tap].
+// grid = units * 32 blocks (one row `a` of one unit each); thread = (b, k): the 8 k-groups each add every 8th block's
+// slice in index order, then meet in LDS in a fixed order -- bitwise reproducible, 128-byte coalesced reads.
+__global__ __launch_bounds__(256) void wgrad_lds_sum_kernel(const float* __restrict__ part, float* __restrict__ dw, int A, int B,
+                                                            int taps, int nblk) {
+    __shared__ float red[8][32];
+    const int b = threadIdx.x & 31, k = threadIdx.x >> 5;
+    const int unit = blockIdx.x >> 5, arow = blockIdx.x & 31;
+    const int a_tiles = A / 32;
+    const size_t per_blk = (size_t)taps * a_tiles * 1024;
+    const float* p = part + ((size_t)unit * 32 + arow) * 32 + b;
+    float s = 0.f;
+    int j = k;
+    for (; j + 24 < nblk; j += 32) {                 // 4 independent loads in flight
+        const float v0 = p[(size_t)j * per_blk], v1 = p[(size_t)(j + 8) * per_blk], v2 = p[(size_t)(j + 16) * per_blk],
+                    v3 = p[(size_t)(j + 24) * per_blk];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; j < nblk; j += 8) s += p[(size_t)j * per_blk];
+    red[k][b] = s;
+    __syncthreads();
+    if (k == 0 && b < B) {
+        float tot = red[0][b];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) tot += red[q][b];
+        const int tap = unit / a_tiles, a = (unit - tap * a_tiles) * 32 + arow;
+        dw[((size_t)b * A + a) * taps + tap] = tot;
     }
 }
 
@@ -267,88 +293,96 @@ static size_t wgrad_lds_bytes(const WgradGeom& g, int th) {
     return ((size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * g.A + (size_t)th * TW * 32) * sizeof(float);
 }
 
-// (accumulators per wave, row split) for a unit count; 0 = not covered
-static void wgrad_lds_shape(int units, int& uw, int& rs) {
-    if (units <= 1) { uw = 1; rs = 8; }
-    else if (units <= 2) { uw = 2; rs = 8; }
-    else if (units <= 4) { uw = 4; rs = 8; }
-    else if (units <= 10) { uw = 5; rs = 4; }
-    else if (units <= 20) { uw = 5; rs = 2; }
-    else if (units <= 28) { uw = 7; rs = 2; }
-    else if (units <= 36) { uw = 9; rs = 2; }
-    else { uw = 0; rs = 0; }
+// the (A, units) pairs that exist: A in {32, 64, 96, 128} x odd square kernels 1, 3, 5 with <= 36 units.
+// X_(A, Q, REM, PFX): units = 8*Q + REM; PFX is what the register budget leaves (256 VGPRs at 2 waves per SIMD)
+#define SENAS_WGRAD_LDS_SHAPES(X_)   \
+    X_(32, 0, 1, 4)                  \
+    X_(32, 1, 1, 6)                  \
+    X_(32, 3, 1, 14)                 \
+    X_(64, 0, 2, 8)                  \
+    X_(64, 2, 2, 11)                 \
+    X_(96, 0, 3, 12)                 \
+    X_(96, 3, 3, 12)                 \
+    X_(128, 0, 4, 16)                \
+    X_(128, 4, 4, 6)
+
+static bool wgrad_lds_has_shape(int A, int units) {
+#define SENAS_CASE(A_, Q_, REM_, PF_) if (A == A_ && units == 8 * Q_ + REM_) return true;
+    SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
+#undef SENAS_CASE
+    return false;
 }
 
 bool lds_wgrad_ok(const WgradGeom& g) {
     if (g.stride != 1 || g.B > 32 || g.A % 32 != 0 || g.A > 128) return false;
     if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hg != g.hi || g.wg != g.wi) return false;
     if (g.wg < TW || g.hg < 8) return false;
-    const int units = g.kh * g.kw * (g.A / 32);
-    int uw, rs;
-    wgrad_lds_shape(units, uw, rs);
-    if (uw == 0) return false;
+    if (!wgrad_lds_has_shape(g.A, g.kh * g.kw * (g.A / 32))) return false;
     return wgrad_lds_bytes(g, 4) <= 150 * 1024 && (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
 }
 
-template <int A, int UW, int RS, int PFX>
-static int launch_one(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, int th, hipStream_t st) {
-    size_t bytes = wgrad_lds_bytes(g, th);
-    const size_t fold = RS > 1 ? (size_t)4 * UW * 4096 : 0;      // epilogue: 4 storing waves x UW accumulators x 4 KiB
-    if (fold > bytes) bytes = fold;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, UW, RS, PFX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
-        attr_set = true;
-    }
-    const int tiles_x = (g.wg + TW - 1) / TW, tiles_y = (g.hg + th - 1) / th;
-    const int ntiles = g.n * tiles_x * tiles_y;
-    const int blocks = ntiles < 256 ? ntiles : 256;            // one persistent block per CU
-    hipLaunchKernelGGL((wgrad_lds_kernel<A, UW, RS, PFX>), dim3(blocks), dim3(512), bytes, st, g, X, G, ws, x_relu, th, tiles_x, tiles_y);
-    return launch_status("wgrad_lds");
-}
-
-// the instantiations: (A, units) pairs that exist are A in {32, 64, 96, 128} x odd square kernels 1, 3, 5 with
-// <= 36 units; PFX is what the register budget of the shape leaves (256 VGPRs at 2 waves per SIMD)
-#define SENAS_WGRAD_LDS_SHAPES(X_)   \
-    X_(32, 1, 8, 4)                  \
-    X_(32, 5, 4, 6)                  \
-    X_(32, 7, 2, 10)                 \
-    X_(64, 2, 8, 8)                  \
-    X_(64, 5, 2, 11)                 \
-    X_(96, 4, 8, 12)                 \
-    X_(96, 7, 2, 10)                 \
-    X_(128, 4, 8, 16)                \
-    X_(128, 9, 2, 4)
-
-// ws: zeroed float[taps][A][32]; the caller unpacks it into the torch layout afterwards
-int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* ws, int x_relu, hipStream_t st) {
+static int wgrad_lds_tile_rows(const WgradGeom& g) {
     // tallest tile that fits in LDS; on small maps shrink it until every CU has a tile (the kernel is
     // critical-path-bound there: a shorter tile is a shorter serial K loop per block)
     int th = wgrad_lds_bytes(g, 8) <= 150 * 1024 ? 8 : 4;
     const int tiles_x = (g.wg + TW - 1) / TW;
     while (th > 2 && (long)g.n * tiles_x * ((g.hg + th - 1) / th) < 256) th >>= 1;
+    return th;
+}
+
+static int wgrad_lds_blocks(const WgradGeom& g) {
+    const int th = wgrad_lds_tile_rows(g);
+    const long ntiles = (long)g.n * ((g.wg + TW - 1) / TW) * ((g.hg + th - 1) / th);
+    return (int)(ntiles < 256 ? ntiles : 256);                 // one persistent block per CU
+}
+
+// bytes of the partial image the launch writes: blocks x units x 32 x 32 floats
+int64_t lds_wgrad_ws_bytes(const WgradGeom& g) {
+    return (int64_t)wgrad_lds_blocks(g) * g.kh * g.kw * (g.A / 32) * 1024 * sizeof(float);
+}
+
+template <int A, int Q, int REM, int PFX>
+static int launch_one(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st) {
+    const int th = wgrad_lds_tile_rows(g);
+    size_t bytes = wgrad_lds_bytes(g, th);
+    const size_t fold = (size_t)4 * REM * 4096;                // epilogue: 4 storing waves x REM accumulators x 4 KiB
+    if (fold > bytes) bytes = fold;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
+        attr_set = true;
+    }
+    const int tiles_x = (g.wg + TW - 1) / TW, tiles_y = (g.hg + th - 1) / th;
+    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
+                       tiles_x, tiles_y);
+    return launch_status("wgrad_lds");
+}
+
+// part: lds_wgrad_ws_bytes(g) of scratch (need not be zeroed); dw: torch layout, overwritten
+int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, hipStream_t st) {
     const int units = g.kh * g.kw * (g.A / 32);
-    int uw, rs;
-    wgrad_lds_shape(units, uw, rs);
-#define SENAS_CASE(A_, UW_, RS_, PF_) \
-    if (g.A == A_ && uw == UW_ && rs == RS_) return launch_one<A_, UW_, RS_, PF_>(g, X, G, ws, x_relu, th, st);
+    int rc = SENAS_EINVAL;
+    bool found = false;
+#define SENAS_CASE(A_, Q_, REM_, PF_) \
+    if (!found && g.A == A_ && units == 8 * Q_ + REM_) { found = true; rc = launch_one<A_, Q_, REM_, PF_>(g, X, G, part, x_relu, st); }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
-    set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair");
-    return SENAS_EINVAL;
+    if (!found) { set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
+    if (rc != SENAS_OK) return rc;
+    hipLaunchKernelGGL(wgrad_lds_sum_kernel, dim3(units * 32), dim3(256), 0, st, part, dw, g.A, g.B, g.kh * g.kw, wgrad_lds_blocks(g));
+    return launch_status("wgrad_lds sum");
 }
 
 // the kernel symbol launch_lds_wgrad picks (for senas_conv2d_kernel_name)
 void lds_wgrad_name(const WgradGeom& g, char* buf, int len) {
-    int uw, rs;
-    wgrad_lds_shape(g.kh * g.kw * (g.A / 32), uw, rs);
-    int pf = 0;
-#define SENAS_CASE(A_, UW_, RS_, PF_) if (g.A == A_ && uw == UW_ && rs == RS_) pf = PF_;
+    const int units = g.kh * g.kw * (g.A / 32);
+    int q = 0, rem = 0, pf = 0;
+#define SENAS_CASE(A_, Q_, REM_, PF_) if (g.A == A_ && units == 8 * Q_ + REM_) { q = Q_; rem = REM_; pf = PF_; }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
-    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d>", g.A, uw, rs, pf);
+    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d>", g.A, q, rem, pf);
 }
 
 }  // namespace senas

@@ -164,19 +164,23 @@ class _Conv2d(torch.autograd.Function):
         if dy is None:
             return (None,) * 10
         dy = nhwc(dy)
-        ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
+            ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
             with _span('conv_dgrad', g, x, w, dy):
                 _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
                                                    x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            wsz = zeros32(ws.numel() // 4, x.device)          # pre-zeroed split-K image: no memset launch per conv
+            nbytes, zero = C.c_int64(), C.c_int32()
+            _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
+            # pre-zeroed arena slice where the path accumulates with atomics (no memset launch per conv); plain
+            # scratch where it writes per-block partials
+            wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
             with _span('conv_wgrad', g, x, w, dy):
                 _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dw.data_ptr(),
-                                                     wsz.data_ptr(), 1, _stream()), 'senas_conv2d_bwd_weight')
+                                                     wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
         return dx, dw, None, None, None, None, None, None, None, None
 
 

@@ -54,6 +54,51 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Producer-side batch-norm statistics for the "thread = 4 channels of one output pixel" kernels (pool, resample,
+// depthwise): stats[n][c][2] += (sum, sum of squares) of this block's outputs.  Every thread of the block must
+// call it (inactive threads pass active = false).  c = 4*cv with cv a power of two <= 64 and a block that lies
+// inside one image take the cheap route -- shuffles over the pixel lanes, LDS over the 4 waves, one fp64 atomic
+// pair per channel and block; anything else falls back to per-element atomics.
+__device__ __forceinline__ void block_add_stats4(double* __restrict__ stats, bool uniform_img, int n, int c, int ch,
+                                                 const float (&v)[4], bool active) {
+    if (stats == nullptr) return;                                   // kernel-uniform
+    const int cv = c >> 2;
+    if (!uniform_img || (cv & (cv - 1)) != 0 || cv > 64) {          // block-uniform
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double* st = stats + ((size_t)n * c + ch + j) * 2;
+                atomicAdd(st, (double)v[j]);
+                atomicAdd(st + 1, (double)v[j] * v[j]);
+            }
+        }
+        return;
+    }
+    __shared__ double red_stats[4][512];                            // [wave][channel][2], c <= 256
+    double s[4], q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] = active ? (double)v[j] : 0.0;
+        q[j] = s[j] * s[j];
+        for (int o = cv; o < 64; o <<= 1) {
+            s[j] += __shfl_xor(s[j], o, 64);
+            q[j] += __shfl_xor(q[j], o, 64);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < cv) {                                                // lane == channel group (threads are laid out c-fastest)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red_stats[wave][(lane * 4 + j) * 2] = s[j]; red_stats[wave][(lane * 4 + j) * 2 + 1] = q[j]; }
+    }
+    __syncthreads();
+    const int nw = cv < 64 ? 4 : 4;                                 // all 4 waves hold every channel group (cv <= 64)
+    for (int i = threadIdx.x; i < 2 * c; i += 256) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red_stats[w][i];
+        atomicAdd(stats + (size_t)n * c * 2 + i, t);
+    }
+}
+
 // Geometry of one "gather" pass: out[n,oy,ox,:] reads in[n, f(oy,ky), f(ox,kx), :].
 //   plain      : iy = oy*stride - pad + ky*dil                       (conv fwd, convT dgrad)
 //   transposed : iy = (oy + pad - ky*dil)/stride when divisible      (convT fwd, conv dgrad)

@@ -174,9 +174,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
                                                      const float* __restrict__ w, float* __restrict__ out,
                                                      int in_relu, const float* __restrict__ mask,
                                                      double* __restrict__ stats, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const long first = (long)blockIdx.x * 256;
+    long idx = first + threadIdx.x;
+    const bool active = idx < total;               // statistics are reduced per block: every thread stays alive
+    if (!active) idx = total - 1;
     const int cv = g.cout / V;
+    const long per_img = (long)g.hout * g.wout * cv;
+    const bool uniform = first / per_img == (first + 255 < total ? first + 255 : total - 1) / per_img;
     const int c = (int)(idx % cv) * V;
     long pix = idx / cv;
     const int ox = (int)(pix % g.wout);
@@ -205,13 +209,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
     const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + c;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        float r = acc[j];
-        if (mask != nullptr && !(mask[o + j] > 0.f)) r = 0.f;
-        out[o + j] = r;
-        if (stats != nullptr) {
-            double* st = stats + ((size_t)n * g.cout + c + j) * 2;
-            atomicAdd(st, (double)r);
-            atomicAdd(st + 1, (double)r * r);
+        if (mask != nullptr && !(mask[o + j] > 0.f)) acc[j] = 0.f;
+    }
+    if (active) stv<V>(out + o, acc);
+    if constexpr (V == 4) {
+        block_add_stats4(stats, uniform, n, g.cout, c, acc, active);
+    } else {
+        if (stats != nullptr && active) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                double* st = stats + ((size_t)n * g.cout + c + j) * 2;
+                atomicAdd(st, (double)acc[j]);
+                atomicAdd(st + 1, (double)acc[j] * acc[j]);
+            }
         }
     }
 }

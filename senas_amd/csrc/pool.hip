@@ -19,6 +19,33 @@ __device__ __forceinline__ void decode(long idx, int cv, int wo, int ho, int& c,
     n = (int)(p / ho);
 }
 
+// forward kernels with statistics: every thread stays alive (block-level reduction); `active` guards the stores
+template <int V>
+__device__ __forceinline__ void fwd_prologue(long total, int cv, int wo, int ho, long& idx, bool& active, bool& uniform) {
+    const long first = (long)blockIdx.x * 256;
+    idx = first + threadIdx.x;
+    active = idx < total;
+    if (!active) idx = total - 1;
+    const long per_img = (long)ho * wo * cv;
+    const long last = first + 255 < total ? first + 255 : total - 1;
+    uniform = first / per_img == last / per_img;
+}
+
+template <int V>
+__device__ __forceinline__ void fwd_stats(double* stats, bool uniform, int n, int c, int ch, const float (&v)[V], bool active) {
+    if constexpr (V == 4) {
+        block_add_stats4(stats, uniform, n, c, ch, v, active);
+    } else {
+        if (stats == nullptr || !active) return;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            double* st = stats + ((size_t)n * c + ch + j) * 2;
+            atomicAdd(st, (double)v[j]);
+            atomicAdd(st + 1, (double)v[j] * v[j]);
+        }
+    }
+}
+
 template <int V>
 __device__ __forceinline__ void add_stats(double* stats, int n, int c, int ch, const float (&v)[V]) {
     if (stats == nullptr) return;
@@ -34,8 +61,9 @@ __device__ __forceinline__ void add_stats(double* stats, int n, int c, int ch, c
 template <int V>
 __global__ __launch_bounds__(256) void avgpool3_fwd_kernel(PoolGeom g, const float* __restrict__ x, int in_relu,
                                                            float* __restrict__ y, double* __restrict__ stats, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    long idx;
+    bool active, uniform;
+    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
     float acc[V];
@@ -58,8 +86,8 @@ __global__ __launch_bounds__(256) void avgpool3_fwd_kernel(PoolGeom g, const flo
     // torch divides the window sum by the number of in-bounds taps
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = acc[j] / (float)cnt;
-    stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, acc);
-    add_stats<V>(stats, n, g.c, ch, acc);
+    if (active) stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, acc);
+    fwd_stats<V>(stats, uniform, n, g.c, ch, acc, active);
 }
 
 __device__ __forceinline__ int window_count(int o, int stride, int lim) {
@@ -114,8 +142,9 @@ template <int V>
 __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(PoolGeom g, const float* __restrict__ x, int in_relu,
                                                            float* __restrict__ y, uint8_t* __restrict__ amax,
                                                            double* __restrict__ stats, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    long idx;
+    bool active, uniform;
+    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
     float best[V];
@@ -138,10 +167,12 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(PoolGeom g, const flo
         }
     }
     const size_t o = ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch;
-    stv<V>(y + o, best);
+    if (active) {
+        stv<V>(y + o, best);
 #pragma unroll
-    for (int j = 0; j < V; ++j) amax[o + j] = (uint8_t)arg[j];
-    add_stats<V>(stats, n, g.c, ch, best);
+        for (int j = 0; j < V; ++j) amax[o + j] = (uint8_t)arg[j];
+    }
+    fwd_stats<V>(stats, uniform, n, g.c, ch, best, active);
 }
 
 template <int V>
@@ -196,8 +227,9 @@ __device__ __forceinline__ void bilinear_src(int d, int lim, int& i0, int& i1, f
 template <int V>
 __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(PoolGeom g, const float* __restrict__ x,
                                                              float* __restrict__ y, double* __restrict__ stats, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    long idx;
+    bool active, uniform;
+    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
     int y0, y1, x0, x1;
@@ -211,8 +243,8 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(PoolGeom g, const f
     ldv<V>(x + ((size_t)(n * g.h + y1) * g.w + x1) * g.c + ch, d);
 #pragma unroll
     for (int j = 0; j < V; ++j) r[j] = ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
-    stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, r);
-    add_stats<V>(stats, n, g.c, ch, r);
+    if (active) stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, r);
+    fwd_stats<V>(stats, uniform, n, g.c, ch, r, active);
 }
 
 // weight with which destination row/col d reads source index i

@@ -192,19 +192,23 @@ def conv2d(x, w, stride=1, pad=0, dil=1, transposed=False, out_pad=0, groups=1, 
 # ------------------------------------------------------------------------------------------ pooling / resampling
 class _AvgPool3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stride, in_relu):
+    def forward(ctx, x, stride, in_relu, want_stats):
         x = nhwc(x)
         n, c, h, w = x.shape
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = new_nhwc(n, c, ho, wo, x)
-        _lib.check(_lib.lib().senas_avgpool3_fwd(n, h, w, c, stride, x.data_ptr(), int(in_relu), y.data_ptr(), None,
+        stats = new_stats(n, c, x) if want_stats else None
+        _lib.check(_lib.lib().senas_avgpool3_fwd(n, h, w, c, stride, x.data_ptr(), int(in_relu), y.data_ptr(), _p(stats),
                                                  _stream()), 'senas_avgpool3_fwd')
         ctx.save_for_backward(x)
         ctx.meta = (stride, int(in_relu))
-        return y
+        ctx.set_materialize_grads(False)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _ds=None):
         (x,) = ctx.saved_tensors
         stride, in_relu = ctx.meta
         n, c, h, w = x.shape
@@ -212,25 +216,29 @@ class _AvgPool3(torch.autograd.Function):
         dx = torch.empty_like(x, memory_format=CL)
         _lib.check(_lib.lib().senas_avgpool3_bwd(n, h, w, c, stride, dy.data_ptr(), in_relu, x.data_ptr(), dx.data_ptr(),
                                                  _stream()), 'senas_avgpool3_bwd')
-        return dx, None, None
+        return dx, None, None, None
 
 
 class _MaxPool3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stride, in_relu):
+    def forward(ctx, x, stride, in_relu, want_stats):
         x = nhwc(x)
         n, c, h, w = x.shape
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = new_nhwc(n, c, ho, wo, x)
         arg = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8)
+        stats = new_stats(n, c, x) if want_stats else None
         _lib.check(_lib.lib().senas_maxpool3_fwd(n, h, w, c, stride, x.data_ptr(), int(in_relu), y.data_ptr(),
-                                                 arg.data_ptr(), None, _stream()), 'senas_maxpool3_fwd')
+                                                 arg.data_ptr(), _p(stats), _stream()), 'senas_maxpool3_fwd')
         ctx.save_for_backward(x, arg)
         ctx.meta = (stride, int(in_relu))
-        return y
+        ctx.set_materialize_grads(False)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _ds=None):
         x, arg = ctx.saved_tensors
         stride, in_relu = ctx.meta
         n, c, h, w = x.shape
@@ -238,28 +246,32 @@ class _MaxPool3(torch.autograd.Function):
         dx = torch.empty_like(x, memory_format=CL)
         _lib.check(_lib.lib().senas_maxpool3_bwd(n, h, w, c, stride, dy.data_ptr(), arg.data_ptr(), in_relu, x.data_ptr(),
                                                  dx.data_ptr(), _stream()), 'senas_maxpool3_bwd')
-        return dx, None, None
+        return dx, None, None, None
 
 
 class _Bilinear2x(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, want_stats):
         x = nhwc(x)
         n, c, h, w = x.shape
         y = new_nhwc(n, c, 2 * h, 2 * w, x)
-        _lib.check(_lib.lib().senas_bilinear2x_fwd(n, h, w, c, x.data_ptr(), y.data_ptr(), None, _stream()),
+        stats = new_stats(n, c, x) if want_stats else None
+        _lib.check(_lib.lib().senas_bilinear2x_fwd(n, h, w, c, x.data_ptr(), y.data_ptr(), _p(stats), _stream()),
                    'senas_bilinear2x_fwd')
         ctx.shape = (n, c, h, w)
-        return y
+        ctx.set_materialize_grads(False)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _ds=None):
         n, c, h, w = ctx.shape
         dy = nhwc(dy)
         dx = new_nhwc(n, c, h, w, dy)
         _lib.check(_lib.lib().senas_bilinear2x_bwd(n, h, w, c, dy.data_ptr(), dx.data_ptr(), _stream()),
                    'senas_bilinear2x_bwd')
-        return dx
+        return dx, None
 
 
 class _ReLU(torch.autograd.Function):
@@ -301,16 +313,20 @@ def zero_feature(x, c_out):
     return _ZeroFeature.apply(_dev(x), c_out)
 
 
-def avg_pool3(x, stride, in_relu=False):
-    return _AvgPool3.apply(x, stride, in_relu)
+def avg_pool3(x, stride, in_relu=False, want_stats=False):
+    """y, or (y, stats) with want_stats: the producer-side per-image channel sums the next BatchNorm needs."""
+    y, st = _AvgPool3.apply(x, stride, in_relu, want_stats)
+    return (y, st) if want_stats else y
 
 
-def max_pool3(x, stride, in_relu=False):
-    return _MaxPool3.apply(x, stride, in_relu)
+def max_pool3(x, stride, in_relu=False, want_stats=False):
+    y, st = _MaxPool3.apply(x, stride, in_relu, want_stats)
+    return (y, st) if want_stats else y
 
 
-def bilinear2x(x):
-    return _Bilinear2x.apply(x)
+def bilinear2x(x, want_stats=False):
+    y, st = _Bilinear2x.apply(x, want_stats)
+    return (y, st) if want_stats else y
 
 
 def relu(x):

@@ -153,8 +153,8 @@ class DepSepConv(_Op):
         super().__init__(*depth, build_norm(c_in, affine), build_activation(), *point, build_norm(c_ot, affine))
 
     def raw(self, x):
-        z1, _ = run_conv(self[0], x, want_stats=False)
-        mid = F.bn_combine([Term(z1, self[1])], relu=True)
+        z1, st1 = run_conv(self[0], x)
+        mid = F.bn_combine([Term(z1, self[1], stats=st1)], relu=True)
         z2, st = run_conv(self[3], mid)
         return Term(z2, self[4], stats=st)
 
@@ -169,22 +169,23 @@ class AdapterBlock(nn.Module):
             self.conv = nn.Conv2d(c_in, c_ot, kernel_size=1, bias=False)
         self.norm = build_norm(c_ot, True)
 
-    def _resample(self, x):
+    def _resample(self, x, want_stats=False):
+        """y, or (y, stats-or-None) with want_stats (the resampling kernels produce the next norm's statistics)."""
         m = self.module
         if isinstance(m, nn.Identity):
-            return x
+            return (x, None) if want_stats else x
         if isinstance(m, nn.AvgPool2d):
             if (m.kernel_size, m.padding, m.count_include_pad) != (3, 1, False):
                 raise NotImplementedError('only AvgPool2d(3, s, 1, count_include_pad=False) is on the path')
-            return F.avg_pool3(x, m.stride)
+            return F.avg_pool3(x, m.stride, want_stats=want_stats)
         if isinstance(m, nn.MaxPool2d):
             if (m.kernel_size, m.padding) != (3, 1):
                 raise NotImplementedError('only MaxPool2d(3, s, 1) is on the path')
-            return F.max_pool3(x, m.stride)
+            return F.max_pool3(x, m.stride, want_stats=want_stats)
         if isinstance(m, nn.Upsample):
             if m.scale_factor != 2 or m.mode != 'bilinear' or m.align_corners:
                 raise NotImplementedError('only Upsample(x2, bilinear, align_corners=False) is on the path')
-            return F.bilinear2x(x)
+            return F.bilinear2x(x, want_stats=want_stats)
         raise NotImplementedError('AdapterBlock around %s' % type(m).__name__)
 
     def raw(self, x):
@@ -193,11 +194,11 @@ class AdapterBlock(nn.Module):
             if self.module.stride != 1:
                 raise NotImplementedError('ZeroOp(stride != 1) is not used by OPS')
             return Term(None, self.norm, passengers=[self.conv.weight] if has_conv else [])
-        y = self._resample(x)
         if has_conv:
-            z, st = run_conv(self.conv, y)
+            z, st = run_conv(self.conv, self._resample(x))
             return Term(z, self.norm, stats=st)
-        return Term(y, self.norm)
+        y, st = self._resample(x, want_stats=True)
+        return Term(y, self.norm, stats=st)
 
     def forward(self, x):
         t = self.raw(x)
@@ -262,8 +263,10 @@ class _Rectify(nn.Sequential):
             z, st = run_conv(op, x, in_relu=True)
             return F.bn_combine([Term(z, self[2], stats=st)])
         if isinstance(op, nn.AvgPool2d):
-            return F.bn_combine([Term(F.avg_pool3(x, op.stride, in_relu=True), self[2])])
-        return F.bn_combine([Term(F.bilinear2x(F.relu(x)), self[2])])
+            z, st = F.avg_pool3(x, op.stride, in_relu=True, want_stats=True)
+            return F.bn_combine([Term(z, self[2], stats=st)])
+        z, st = F.bilinear2x(F.relu(x), want_stats=True)
+        return F.bn_combine([Term(z, self[2], stats=st)])
 
 
 def build_rectify(c_in, c_ot, cell_type):

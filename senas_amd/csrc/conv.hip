@@ -620,15 +620,10 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && !tr && thin_n_ok(gg)) return gg.cout <= 2 ? "conv_thin_n_kernel<2>" : "conv_thin_n_kernel<4>";
     if (!tr && lds_gather_ok(gg)) {
-        int mt, ks;
-        lds_gather_shape(gg, mt, ks);
-        static char buf[8][48];
+        static char buf[8][64];
         static int slot = 0;
         char* b = buf[slot++ & 7];
-        const int taps = g->kh * g->kw;
-        const int maxt = ks == 1 ? 1 : (taps <= 9 ? (9 + ks - 1) / ks : (25 + ks - 1) / ks);
-        const int pf = 0;          // next-pass prefetch measured slower than relying on the co-resident block
-        snprintf(b, 48, "conv_lds_kernel<%s, %d, %d, %d, %d>", tg ? "true" : "false", mt, ks, maxt, pf);
+        lds_gather_name(gg, tg, b, 64);
         return b;
     }
     if (mfma_gather_ok(gg, tg)) {

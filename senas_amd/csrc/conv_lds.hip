@@ -48,23 +48,30 @@ struct Frag {
 // PF: 16-byte pieces of the NEXT channel pass's window each thread requests before the tap loop of the current pass
 // and parks in registers until the loop is done -- the HBM/L2 latency of staging hides behind the MFMAs (only the
 // first pass of a block is staged in the open; pieces beyond PF per thread are fetched after the loop).
-template <bool TG, int MT, int KS, int MAXT, int PF>
-__global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
+// RW: row waves per tap group (4, or 1 for maps so small that even 4-row tiles leave most CUs idle: the block is then
+// ONE 32-pixel MFMA row whose taps are dealt to the 4 waves, one wave per SIMD -- the shortest critical path there is).
+// TWL: tile width in pixels (32, 16, 8): a 32-pixel MFMA row covers 32/TWL image rows, so 16x16 and 8x8 maps use the
+// same kernel.  Block = 64 * RW * KS threads; tile = RW * MT * (32/TWL) image rows x TWL columns.
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL>
+__global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
                                                        double* __restrict__ stats) {
-    constexpr int TH = 4 * MT;
+    constexpr int RPM = 32 / TWL;                        // image rows per MFMA row
+    constexpr int TH = RW * MT * RPM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NT = 256 * KS;
+    constexpr int NT = 64 * RW * KS;
     const int lane = threadIdx.x & 63;
-    const int wave = (threadIdx.x >> 6) & 3;             // tile row group
-    const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // tap group (wave-uniform)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wv % RW;                            // tile row group
+    const int kg = wv / RW;                              // tap group (wave-uniform)
     const int r = lane & 31, h = lane >> 5;
+    const int pr = r / TWL, px = r % TWL;                // this lane's pixel inside its MFMA row
     const int n = blockIdx.z % g.n, cot = blockIdx.z / g.n;
     const int co = cot * 32 + r;
-    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TWL;
     const int halo = g.pad;                              // = dil * (k / 2) on this path
-    const int tile_w = TW + 2 * halo, tile_h = TH + 2 * halo;
+    const int tile_w = TWL + 2 * halo, tile_h = TH + 2 * halo;
     const int ngroups = g.cin >> 3, npass = g.cin / CH;
     const int taps = g.kh * g.kw;
     wp += (size_t)cot * taps * ngroups * 256 + lane * 4;
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
     // LDS offset (in 16-byte units, so the accesses are provably aligned -> ds_read_b128) of this lane's
     // pixel for tap (0,0), channel chunk h, sub-tile 0; sub-tile m is tile_w * P4 * m further
     float4* lds4 = reinterpret_cast<float4*>(lds);
-    const int lbase = ((MT * wave) * tile_w + r) * P4 + h;
-    const int lrow = tile_w * P4;
+    const int lbase = ((MT * wave * RPM + pr) * tile_w + px) * P4 + h;
+    const int lrow = RPM * tile_w * P4;
 
     // staging geometry of this thread (pass-independent): slot k holds window pixel k*(NT/4) + (tid>>2), piece tid&3
     constexpr int XL = NT / 4;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
         for (int sgrp = KS / 2; sgrp >= 1; sgrp >>= 1) {
             __syncthreads();
             if (kg >= sgrp && kg < 2 * sgrp) {
-                const int slot = (kg - sgrp) * 4 + wave;
+                const int slot = (kg - sgrp) * RW + wave;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
             }
             __syncthreads();
             if (kg < sgrp) {
-                const int slot = kg * 4 + wave;
+                const int slot = kg * RW + wave;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -279,10 +286,10 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
     double s = 0.0, q = 0.0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + MT * wave + m;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int ox = ox0 + acc_row(v, h);
+            const int pq = acc_row(v, h);                // pixel of the MFMA row this register holds
+            const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
             float val = acc[m][v];
             if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
                 const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
@@ -296,13 +303,13 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
     SENAS_PHASE(42);
     if (stats != nullptr) {                              // block-level reduction: 2 atomics per channel per block
         __syncthreads();
-        double* red = reinterpret_cast<double*>(lds);    // [4 waves][32 channels][2]
+        double* red = reinterpret_cast<double*>(lds);    // [RW waves][32 channels][2]
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
         if (kg == 0 && h == 0) { red[(wave * 32 + r) * 2] = s; red[(wave * 32 + r) * 2 + 1] = q; }
         __syncthreads();
         if (kg == 0 && wave == 0 && h == 0 && cok) {
-            for (int w = 1; w < 4; ++w) { s += red[(w * 32 + r) * 2]; q += red[(w * 32 + r) * 2 + 1]; }
+            for (int w = 1; w < RW; ++w) { s += red[(w * 32 + r) * 2]; q += red[(w * 32 + r) * 2 + 1]; }
             double* st = stats + ((size_t)n * g.cout + co) * 2;
             atomicAdd(st, s);
             atomicAdd(st + 1, q);
@@ -313,63 +320,94 @@ __global__ __launch_bounds__(256 * KS) void conv_lds_kernel(GatherGeom g, const 
 
 SENAS_PHASE_READER(conv_lds)
 
+static int lds_tile_width(const GatherGeom& g) { return g.wout >= 32 ? 32 : (g.wout >= 16 ? 16 : 8); }
+
 bool lds_gather_ok(const GatherGeom& g) {
-    // stride 1, "same" padding, 16-channel passes, maps at least one tile wide
+    // stride 1, "same" padding, 16-channel passes, maps at least 8 wide and 4 high
     if (g.stride != 1 || g.cin % CH != 0) return false;
     if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hout != g.hin || g.wout != g.win) return false;
-    if (g.wout < TW || g.hout < 4) return false;
+    if (g.wout < 8 || g.hout < 4) return false;
     const size_t bytes = (size_t)(8 + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
     return bytes <= 150 * 1024 && (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
 }
 
-static size_t conv_lds_bytes(const GatherGeom& g, int th, int mt, int ks) {
-    size_t bytes = (size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * PST * sizeof(float);
-    const size_t fold = ks > 1 ? (size_t)(ks / 2) * 4 * mt * 4096 : 0;
+static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int ks, int rw) {
+    size_t bytes = (size_t)(th + 2 * g.pad) * (twl + 2 * g.pad) * PST * sizeof(float);
+    const size_t fold = ks > 1 ? (size_t)(ks / 2) * rw * mt * 4096 : 0;
     if (bytes < 4 * 32 * 2 * sizeof(double)) bytes = 4 * 32 * 2 * sizeof(double);      // statistics scratch
     return fold > bytes ? fold : bytes;
 }
 
-template <bool TG, int MT, int KS, int MAXT, int PF>
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                               const float* mask, double* stats, hipStream_t st) {
-    constexpr int TH = 4 * MT;
-    const size_t bytes = conv_lds_bytes(g, TH, MT, KS);
+    constexpr int TH = RW * MT * (32 / TWL);
+    const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW);
     static bool attr_set = false;
     if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
-    dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF>), grid, dim3(256 * KS), bytes, st, g, in, wp, out, in_relu, mask, stats);
+    dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
+                       mask, stats);
     return launch_status("conv_lds");
 }
 
-// (MT, KS) for a geometry: 8x32 tiles when they still give every CU two blocks; otherwise 4x32 tiles, and when even
-// those leave the chip under-filled the taps of a tile are dealt to 2 or 4 groups of waves (small maps are
-// critical-path-bound, not throughput-bound)
-void lds_gather_shape(const GatherGeom& g, int& mt, int& ks) {
-    const long cot = (g.cout + 31) / 32, tx = (g.wout + TW - 1) / TW;
-    const long blocks8 = tx * ((g.hout + 7) / 8) * g.n * cot, blocks4 = tx * ((g.hout + 3) / 4) * g.n * cot;
+// (MT, KS, RW, TWL) for a geometry.  Maps >= 32 wide: 8x32 tiles when they still give every CU two blocks; otherwise
+// 4x32 tiles, and when even those leave the chip under-filled the taps of a tile are dealt to 2 or 4 groups of waves.
+// When 4-row tiles would not even give half the CUs a block (32x32 maps and below) a block is ONE 32-pixel MFMA row
+// with its taps on 4 waves (RW = 1): small maps are critical-path-bound, not throughput-bound.
+void lds_gather_shape(const GatherGeom& g, int& mt, int& ks, int& rw, int& twl) {
+    twl = lds_tile_width(g);
     const int taps = g.kh * g.kw;
+    const long cot = (g.cout + 31) / 32, tx = (g.wout + twl - 1) / twl;
+    rw = 4;
+    if (twl < 32) {                                      // 16- and 8-wide maps: always the single-row form
+        mt = 1; rw = 1; ks = taps >= 9 && taps <= 25 ? 4 : 1;
+        return;
+    }
+    const long blocks8 = tx * ((g.hout + 7) / 8) * g.n * cot, blocks4 = tx * ((g.hout + 3) / 4) * g.n * cot;
     mt = (blocks8 >= 512 && g.hout >= 8) ? 2 : 1;
     ks = 1;
-    if (mt == 1 && taps >= 9 && taps <= 25) ks = blocks4 <= 256 ? 4 : (blocks4 <= 512 ? 2 : 1);
+    if (mt == 1 && taps >= 9 && taps <= 25) {
+        ks = blocks4 <= 256 ? 4 : (blocks4 <= 512 ? 2 : 1);
+        if (blocks4 <= 128) rw = 1;
+    }
 }
 
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st) {
-    int mt, ks;
-    lds_gather_shape(g, mt, ks);
+    int mt, ks, rw, twl;
+    lds_gather_shape(g, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;
-    if (mt == 2) return launch_lds_variant<TG, 2, 1, 1, 0>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 4 && taps <= 9) return launch_lds_variant<TG, 1, 4, 3, 0>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 4 && taps <= 25) return launch_lds_variant<TG, 1, 4, 7, 0>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 2 && taps <= 9) return launch_lds_variant<TG, 1, 2, 5, 0>(g, in, wp, out, in_relu, mask, stats, st);
-    if (ks == 2 && taps <= 25) return launch_lds_variant<TG, 1, 2, 13, 0>(g, in, wp, out, in_relu, mask, stats, st);
-    return launch_lds_variant<TG, 1, 1, 1, 0>(g, in, wp, out, in_relu, mask, stats, st);
+#define SENAS_LV(MT_, KS_, MAXT_, RW_, TWL_) return launch_lds_variant<TG, MT_, KS_, MAXT_, 0, RW_, TWL_>(g, in, wp, out, in_relu, mask, stats, st)
+    if (rw == 1) {
+        if (twl == 32) { if (taps <= 9) SENAS_LV(1, 4, 3, 1, 32); SENAS_LV(1, 4, 7, 1, 32); }
+        if (twl == 16) { if (ks == 1) SENAS_LV(1, 1, 1, 1, 16); if (taps <= 9) SENAS_LV(1, 4, 3, 1, 16); SENAS_LV(1, 4, 7, 1, 16); }
+        if (ks == 1) SENAS_LV(1, 1, 1, 1, 8);
+        if (taps <= 9) SENAS_LV(1, 4, 3, 1, 8);
+        SENAS_LV(1, 4, 7, 1, 8);
+    }
+    if (mt == 2) SENAS_LV(2, 1, 1, 4, 32);
+    if (ks == 4 && taps <= 9) SENAS_LV(1, 4, 3, 4, 32);
+    if (ks == 4 && taps <= 25) SENAS_LV(1, 4, 7, 4, 32);
+    if (ks == 2 && taps <= 9) SENAS_LV(1, 2, 5, 4, 32);
+    if (ks == 2 && taps <= 25) SENAS_LV(1, 2, 13, 4, 32);
+    SENAS_LV(1, 1, 1, 4, 32);
+#undef SENAS_LV
+}
+
+// the kernel symbol launch_lds_gather picks (for senas_conv2d_kernel_name)
+void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len) {
+    int mt, ks, rw, twl;
+    lds_gather_shape(g, mt, ks, rw, twl);
+    const int taps = g.kh * g.kw;
+    const int maxt = ks == 1 ? 1 : (taps <= 9 ? (ks == 4 ? 3 : 5) : (ks == 4 ? 7 : 13));
+    snprintf(buf, len, "conv_lds_kernel<%s, %d, %d, %d, 0, %d, %d>", tg ? "true" : "false", mt, ks, maxt, rw, twl);
 }
 
 template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);

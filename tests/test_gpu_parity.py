@@ -362,6 +362,12 @@ _CONV_CASES = [
     (1, 128, 32, 8, 32, 1, 1, 1, False, True),      # 4 units
     (8, 32, 32, 64, 96, 3, 1, 1, False, True),      # LDS window kernel with the taps dealt to 2 wave groups
     (8, 16, 32, 72, 128, 3, 1, 1, False, False),    # 4x32 tiles, one wave group (between the two regimes)
+    (2, 32, 32, 32, 32, 3, 1, 1, False, True),      # single-MFMA-row blocks (few tiles): 32 wide
+    (8, 32, 32, 16, 16, 5, 1, 3, False, False),     # 16-wide maps: one MFMA row = 2 image rows
+    (8, 32, 32, 8, 8, 5, 1, 2, False, True),        # 8-wide maps: one MFMA row = 4 image rows
+    (3, 32, 16, 12, 20, 5, 1, 2, False, False),     # 16-wide tiles, ragged in both directions
+    (2, 32, 32, 10, 9, 3, 1, 1, False, False),      # 8-wide tiles, ragged
+    (2, 16, 32, 8, 8, 1, 1, 1, False, False),       # 1x1 on an 8x8 map (one-wave blocks)
 ]
 
 

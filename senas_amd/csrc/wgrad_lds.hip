@@ -19,7 +19,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-constexpr int TW = 32;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -41,19 +40,22 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // and parks in registers until the loop is done (the G tile always travels that way), so the HBM/L2 latency
 // of staging hides behind the MFMAs; pieces beyond PFX*512 are fetched after the loop.
 // dynamic LDS: X window [(th + 2*halo) * (32 + 2*halo)][A] floats, then G tile [th * 32][32] floats.
-template <int A, int Q, int REM, int PFX>
+// TWL: tile width in pixels (32, 16, 8): the 32 K-pixels of an MFMA row are 32/TWL image rows of TWL columns, so
+// 16x16 and 8x8 maps run here too; `th` counts MFMA rows (th * 32/TWL image rows per tile).
+template <int A, int Q, int REM, int PFX, int TWL>
 __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ G, float* __restrict__ part,
                                                         int x_relu, int th, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int UW = Q + REM;
+    constexpr int RPM = 32 / TWL;                // image rows per MFMA row
     constexpr int PP = A / 4;                    // 16-byte pieces per pixel of X
     constexpr int XL = 512 / PP;                 // pixels of the window covered by one slot
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
     const int r = lane & 31, h = lane >> 5;
     const int halo = g.pad;
-    const int tile_w = TW + 2 * halo, tile_h = th + 2 * halo;
+    const int tile_w = TWL + 2 * halo, tile_h = th * RPM + 2 * halo;
     float* xs = lds;
     float* gs = lds + tile_h * tile_w * A;
     float4* xs4 = reinterpret_cast<float4*>(xs);
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
     const int xq = threadIdx.x % PP, xpl = threadIdx.x / PP;       // threads with xpl >= XL idle while X is staged (A = 96)
     const int xslot = xpl * PP + xq;
     const int ty0 = xpl / tile_w, tx0 = xpl - ty0 * tile_w;
+    const int dty = XL / tile_w, dtx = XL - dty * tile_w;        // slot-to-slot step in (row, column)
     const int wpix = tile_h * tile_w;            // pixels in the X window
-    const int gpix = th * TW;                    // pixels in the G tile
+    const int gpix = th * 32;                    // pixels in the G tile (stored linearly: TWL-wide rows back to back)
     const int gq = threadIdx.x & 7, gpl = threadIdx.x >> 3;      // G: 8 pieces per pixel, 64 pixels per slot
     const int per_img = tiles_x * tiles_y;
     const int ntiles = g.n * per_img;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
     // request the first PFX slots of X and the whole G tile of `tile` (loads only; borders resolved in commit)
     auto issue = [&](int tile) {
         const int n = tile / per_img, tr = tile - n * per_img;
-        const int oy0 = (tr / tiles_x) * th, ox0 = (tr % tiles_x) * TW;
+        const int oy0 = (tr / tiles_x) * th * RPM, ox0 = (tr % tiles_x) * TWL;
         const float* src = X + (size_t)n * g.hi * g.wi * A + xq * 4;
         int ty = ty0, tx = tx0;
 #pragma unroll
@@ -97,15 +100,15 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
             const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
             const bool inb = xpl < XL && k * XL + xpl < wpix && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
             px[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.wi + ix) * A : 0));
-            tx += XL;
-            { const int w1 = tx >= tile_w; tx -= w1 ? tile_w : 0; ty += w1; const int w2 = tx >= tile_w; tx -= w2 ? tile_w : 0; ty += w2; }   // XL <= 64 <= 2*tile_w
+            ty += dty; tx += dtx;
+            if (tx >= tile_w) { tx -= tile_w; ++ty; }
         }
         if (g.B == 32) {
             const float* gsrc = G + (size_t)n * g.hg * g.wg * 32 + gq * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pix = k * 64 + gpl;
-                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                const int gy = oy0 + pix / TWL, gx = ox0 + pix % TWL;
                 const bool inb = pix < gpix && gy < g.hg && gx < g.wg;
                 pg[k] = *reinterpret_cast<const float4*>(gsrc + (inb ? ((size_t)gy * g.wg + gx) * 32 : 0));
             }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
     // registers -> LDS (ReLU, zero borders), then whatever did not fit in the prefetch slots
     auto commit = [&](int tile) {
         const int n = tile / per_img, tr = tile - n * per_img;
-        const int oy0 = (tr / tiles_x) * th, ox0 = (tr % tiles_x) * TW;
+        const int oy0 = (tr / tiles_x) * th * RPM, ox0 = (tr % tiles_x) * TWL;
         int ty = ty0, tx = tx0;
 #pragma unroll
         for (int k = 0; k < PFX; ++k) {
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
             if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) xs4[k * XL * PP + xslot] = v;
-            tx += XL;
-            { const int w1 = tx >= tile_w; tx -= w1 ? tile_w : 0; ty += w1; const int w2 = tx >= tile_w; tx -= w2 ? tile_w : 0; ty += w2; }   // XL <= 64 <= 2*tile_w
+            ty += dty; tx += dtx;
+            if (tx >= tile_w) { tx -= tile_w; ++ty; }
         }
         const float* src = X + (size_t)n * g.hi * g.wi * A + xq * 4;
         for (int k0 = PFX; k0 * XL < wpix; k0 += 4) {           // remainder, 4 loads in flight
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
                 lv[u] = xpl < XL && (k0 + u) * XL + xpl < wpix;
                 ok[u] = lv[u] && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
                 v[u] = *reinterpret_cast<const float4*>(src + (ok[u] ? ((size_t)iy * g.wi + ix) * A : 0));
-                txx += XL;
-                { const int w1 = txx >= tile_w; txx -= w1 ? tile_w : 0; tyy += w1; const int w2 = txx >= tile_w; txx -= w2 ? tile_w : 0; tyy += w2; }
+                tyy += dty; txx += dtx;
+                if (txx >= tile_w) { txx -= tile_w; ++tyy; }
             }
             ty = tyy; tx = txx;
 #pragma unroll
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pix = k * 64 + gpl;
-                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                const int gy = oy0 + pix / TWL, gx = ox0 + pix % TWL;
                 float4 v = pg[k];
                 if (!(gy < g.hg && gx < g.wg)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pix < gpix) gs4[k * 512 + threadIdx.x] = v;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
             const float* gsrc = G + (size_t)n * g.hg * g.wg * g.B;
             for (int idx = threadIdx.x; idx < gpix * 32; idx += 512) {   // B < 32: zero-pad the columns
                 const int pix = idx >> 5, b = idx & 31;
-                const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
+                const int gy = oy0 + pix / TWL, gx = ox0 + pix % TWL;
                 float v = 0.f;
                 if (b < g.B && gy < g.hg && gx < g.wg) v = gsrc[((size_t)gy * g.wg + gx) * g.B + b];
                 gs[idx] = v;
@@ -180,9 +183,12 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);     // in flight during the K loop
         // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15); straight-line
         // per (row, unit group): the operands of step s+1 are requested before the MFMAs of step s are issued
+        const int rowstep = tile_w * A;
+        auto koff = [&](int s) { return TWL == 8 ? (s >> 3) * rowstep + (s & 7) * A : s * A; };     // s is a compile-time index
         for (int row = 0; row < th; ++row) {
-            const float* gp = gs + (row * TW + 16 * h) * 32 + r;
-            const float* xp = xs + (row * tile_w + 16 * h) * A;
+            const float* gp = gs + (row * 32 + 16 * h) * 32 + r;
+            // K-pixel k = 16h + s of this MFMA row sits at image row k / TWL, column k % TWL of the tile
+            const float* xp = xs + (TWL == 32 ? (row * tile_w + 16 * h) : (TWL == 16 ? (row * 2 + h) * tile_w : (row * 4 + 2 * h) * tile_w)) * A;
             if (Q > 0) {
                 float b = gp[0], a[Q > 0 ? Q : 1];
 #pragma unroll
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
                     if (s < 15) {
                         bn = gp[(s + 1) * 32];
 #pragma unroll
-                        for (int t = 0; t < Q; ++t) an[t] = xp[uoff[t] + (s + 1) * A];
+                        for (int t = 0; t < Q; ++t) an[t] = xp[uoff[t] + koff(s + 1)];
                     }
 #pragma unroll
                     for (int t = 0; t < Q; ++t) acc[t] = mfma32(a[t], b, acc[t]);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
                         float bn = 0.f, an = 0.f;
-                        if (s < 15) { bn = gp[(s + 1) * 32]; an = xp[uoff[Q + j] + (s + 1) * A]; }
+                        if (s < 15) { bn = gp[(s + 1) * 32]; an = xp[uoff[Q + j] + koff(s + 1)]; }
                         acc[Q + j] = mfma32(a, b, acc[Q + j]);
                         b = bn; a = an;
                     }
@@ -289,8 +295,11 @@ __global__ __launch_bounds__(256) void wgrad_lds_sum_kernel(const float* __restr
     }
 }
 
-static size_t wgrad_lds_bytes(const WgradGeom& g, int th) {
-    return ((size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * g.A + (size_t)th * TW * 32) * sizeof(float);
+static int wgrad_tile_width(const WgradGeom& g) { return g.wg >= 32 ? 32 : (g.wg >= 16 ? 16 : 8); }
+
+// th MFMA rows = th * 32/twl image rows
+static size_t wgrad_lds_bytes(const WgradGeom& g, int th, int twl) {
+    return ((size_t)(th * (32 / twl) + 2 * g.pad) * (twl + 2 * g.pad) * g.A + (size_t)th * 32 * 32) * sizeof(float);
 }
 
 // the (A, units) pairs that exist: A in {32, 64, 96, 128} x odd square kernels 1, 3, 5 with <= 36 units.
@@ -305,6 +314,8 @@ static size_t wgrad_lds_bytes(const WgradGeom& g, int th) {
     X_(96, 3, 3, 12)                 \
     X_(128, 0, 4, 16)                \
     X_(128, 4, 4, 6)
+// narrow maps (16 / 8 pixels wide) exist for the 32- and 128-channel shapes only
+static bool wgrad_lds_narrow_ok(int A) { return A == 32 || A == 128; }
 
 static bool wgrad_lds_has_shape(int A, int units) {
 #define SENAS_CASE(A_, Q_, REM_, PF_) if (A == A_ && units == 8 * Q_ + REM_) return true;
@@ -316,23 +327,26 @@ static bool wgrad_lds_has_shape(int A, int units) {
 bool lds_wgrad_ok(const WgradGeom& g) {
     if (g.stride != 1 || g.B > 32 || g.A % 32 != 0 || g.A > 128) return false;
     if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hg != g.hi || g.wg != g.wi) return false;
-    if (g.wg < TW || g.hg < 8) return false;
+    if (g.wg < 8 || g.hg < 4 || (g.wg < 32 && !wgrad_lds_narrow_ok(g.A))) return false;
+    if (g.wg >= 32 && g.hg < 8) return false;
     if (!wgrad_lds_has_shape(g.A, g.kh * g.kw * (g.A / 32))) return false;
-    return wgrad_lds_bytes(g, 4) <= 150 * 1024 && (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
+    return wgrad_lds_bytes(g, wgrad_tile_width(g) == 32 ? 4 : 2, wgrad_tile_width(g)) <= 150 * 1024 && (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
 }
 
 static int wgrad_lds_tile_rows(const WgradGeom& g) {
     // tallest tile that fits in LDS; on small maps shrink it until every CU has a tile (the kernel is
     // critical-path-bound there: a shorter tile is a shorter serial K loop per block)
-    int th = wgrad_lds_bytes(g, 8) <= 150 * 1024 ? 8 : 4;
-    const int tiles_x = (g.wg + TW - 1) / TW;
-    while (th > 2 && (long)g.n * tiles_x * ((g.hg + th - 1) / th) < 256) th >>= 1;
+    const int twl = wgrad_tile_width(g), rpm = 32 / twl;
+    int th = wgrad_lds_bytes(g, 8, twl) <= 150 * 1024 ? 8 : 4;
+    const int tiles_x = (g.wg + twl - 1) / twl;
+    const int th_min = twl == 32 ? 2 : 1;
+    while (th > th_min && (long)g.n * tiles_x * ((g.hg + th * rpm - 1) / (th * rpm)) < 256) th >>= 1;
     return th;
 }
 
 static int wgrad_lds_blocks(const WgradGeom& g) {
-    const int th = wgrad_lds_tile_rows(g);
-    const long ntiles = (long)g.n * ((g.wg + TW - 1) / TW) * ((g.hg + th - 1) / th);
+    const int th = wgrad_lds_tile_rows(g), twl = wgrad_tile_width(g), rows = th * (32 / twl);
+    const long ntiles = (long)g.n * ((g.wg + twl - 1) / twl) * ((g.hg + rows - 1) / rows);
     return (int)(ntiles < 256 ? ntiles : 256);                 // one persistent block per CU
 }
 
@@ -341,21 +355,22 @@ int64_t lds_wgrad_ws_bytes(const WgradGeom& g) {
     return (int64_t)wgrad_lds_blocks(g) * g.kh * g.kw * (g.A / 32) * 1024 * sizeof(float);
 }
 
-template <int A, int Q, int REM, int PFX>
+template <int A, int Q, int REM, int PFX, int TWL>
 static int launch_one(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st) {
     const int th = wgrad_lds_tile_rows(g);
-    size_t bytes = wgrad_lds_bytes(g, th);
+    size_t bytes = wgrad_lds_bytes(g, th, TWL);
     const size_t fold = (size_t)4 * REM * 4096;                // epilogue: 4 storing waves x REM accumulators x 4 KiB
     if (fold > bytes) bytes = fold;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
-    const int tiles_x = (g.wg + TW - 1) / TW, tiles_y = (g.hg + th - 1) / th;
-    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
+    const int rows = th * (32 / TWL);
+    const int tiles_x = (g.wg + TWL - 1) / TWL, tiles_y = (g.hg + rows - 1) / rows;
+    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
                        tiles_x, tiles_y);
     return launch_status("wgrad_lds");
 }
@@ -363,10 +378,18 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
 // part: lds_wgrad_ws_bytes(g) of scratch (need not be zeroed); dw: torch layout, overwritten
 int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, hipStream_t st) {
     const int units = g.kh * g.kw * (g.A / 32);
+    const int twl = wgrad_tile_width(g);
     int rc = SENAS_EINVAL;
     bool found = false;
 #define SENAS_CASE(A_, Q_, REM_, PF_) \
-    if (!found && g.A == A_ && units == 8 * Q_ + REM_) { found = true; rc = launch_one<A_, Q_, REM_, PF_>(g, X, G, part, x_relu, st); }
+    if (!found && g.A == A_ && units == 8 * Q_ + REM_) {                                                          \
+        found = true;                                                                                             \
+        if (twl == 32) rc = launch_one<A_, Q_, REM_, PF_, 32>(g, X, G, part, x_relu, st);                        \
+        else if constexpr (A_ == 32 || A_ == 128) {                                                               \
+            rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16>(g, X, G, part, x_relu, st)                         \
+                           : launch_one<A_, Q_, REM_, PF_, 8>(g, X, G, part, x_relu, st);                         \
+        }                                                                                                         \
+    }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
     if (!found) { set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
@@ -382,7 +405,7 @@ void lds_wgrad_name(const WgradGeom& g, char* buf, int len) {
 #define SENAS_CASE(A_, Q_, REM_, PF_) if (g.A == A_ && units == 8 * Q_ + REM_) { q = Q_; rem = REM_; pf = PF_; }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
-    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d>", g.A, q, rem, pf);
+    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d, %d>", g.A, q, rem, pf, wgrad_tile_width(g));
 }
 
 }  // namespace senas

@@ -368,6 +368,9 @@ _CONV_CASES = [
     (3, 32, 16, 12, 20, 5, 1, 2, False, False),     # 16-wide tiles, ragged in both directions
     (2, 32, 32, 10, 9, 3, 1, 1, False, False),      # 8-wide tiles, ragged
     (2, 16, 32, 8, 8, 1, 1, 1, False, False),       # 1x1 on an 8x8 map (one-wave blocks)
+    (8, 128, 32, 16, 16, 3, 1, 1, False, True),     # ShrinkBlock shape on a 16x16 map (narrow LDS weight gradient, 36 units)
+    (8, 128, 32, 8, 8, 3, 1, 1, False, False),      # ... and on 8x8
+    (2, 32, 32, 8, 8, 1, 1, 1, False, True),        # narrow 1x1 weight gradient
 ]
 
 

@@ -173,3 +173,61 @@ def test_loss_and_metric_have_no_cpu_path():
         SegmentationMetric(2).update(tgt, logits)
     with pytest.raises(NotImplementedError):
         SegmentationLosses('focal')
+
+
+# ------------------------------------------------------------------ checkpoint interchange (scope row f-3)
+def test_checkpoint_round_trip_in_reference_format(tmp_path):
+    """A search-phase checkpoint in the reference's dictionary layout (search_arc.py:227-238), built around the
+    REFERENCE's own state_dict from the golden file, loads into this package's modules, survives a save/load
+    through the reference's file name, and comes back with identical keys, order and values."""
+    from senas_amd import checkpoint as ck
+    from senas_amd.senas_search import NAS
+    z = gio.load('nets')
+    tag = 'nas.c8.d4'
+    kw = json.loads(str(z[tag + '/kw']))
+    ref_sd = gio.add_missing_counters(gio.torch_sd(gio.unpack(z, tag + '/sd0/'), requires_grad=False))
+    net = NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+    opt_w = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=3e-4)
+    opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt_w, 10)
+    ref_ckpt = {'epoch': 3, 'dur_time': 12.5, 'cur_patience': 0, 'geno_type': 'g', 'model_state': ref_sd,
+                'arch_optimizer': opt_a.state_dict(), 'model_optimizer': opt_w.state_dict(),
+                # the reference writes these keys (alphas_dict(), betas_dict()) ...
+                'alphas_dict': {k: ref_sd[k] + 0.5 for k in ('alphas_dn', 'alphas_dn_nm', 'alphas_up', 'alphas_up_nm')},
+                'betas_dict': {k: ref_sd[k] - 0.25 for k in ('betas_dn', 'betas_up')}, 'scheduler': sched.state_dict()}
+    epoch, dur, geno = ck.load_search_state(ref_ckpt, net, opt_a, opt_w, sched)
+    assert (epoch, dur, geno) == (3, 12.5, 'g')
+    assert torch.equal(net.alphas_dn, ref_sd['alphas_dn'] + 0.5) and torch.equal(net.betas_up, ref_sd['betas_up'] - 0.25)
+    assert net.arch_parameters()[0] is net.alphas_dn            # still the tensors the optimizer holds
+    out = ck.search_state(net, opt_a, opt_w, sched, epoch=3, dur_time=1.0, geno_type=str(net.genotype()))
+    assert list(out.keys()) == ['epoch', 'dur_time', 'cur_patience', 'geno_type', 'model_state', 'arch_optimizer',
+                                'model_optimizer', 'alphas_dict', 'betas_dict', 'scheduler']
+    path = ck.save_checkpoint(out, True, str(tmp_path))
+    assert os.path.basename(path) == 'checkpint.pth.tar' and os.path.exists(os.path.join(str(tmp_path), 'model_best.pth.tar'))
+    back = torch.load(path, map_location='cpu', weights_only=False)
+    assert [k for k in back['model_state'] if not k.endswith('num_batches_tracked')] == \
+        [k for k in ref_sd if not k.endswith('num_batches_tracked')]
+    for k, v in ref_sd.items():
+        if k.startswith(('alphas', 'betas')):
+            continue
+        assert torch.equal(back['model_state'][k], v), k
+    # legacy key names (what the reference's load_params reads) are accepted as well
+    ck.load_search_state({'model_state': back['model_state'], 'alphas_dict': {'alphas_down': ref_sd['alphas_dn']},
+                          'betas_dict': {'betas_down': ref_sd['betas_dn']}}, net)
+    assert torch.equal(net.alphas_dn, ref_sd['alphas_dn'])
+
+
+def test_train_checkpoint_layout(tmp_path):
+    from senas_amd import checkpoint as ck
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.senas_model import SenasModel
+    net = SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+    st = ck.train_state(net, opt, epoch=0, best_dice_coeff=0.5)
+    assert list(st.keys()) == ['epoch', 'dur_time', 'model_state', 'model_optimizer', 'best_pixAcc', 'best_mIoU',
+                               'best_dice_coeff', 'best_loss']
+    other = SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4)
+    assert ck.load_train_state(st, other, torch.optim.SGD(other.parameters(), lr=0.01, momentum=0.9)) == 1
+    assert ck.load_train_state(net.state_dict(), other) == 0            # bare state_dict (testing_model.py)
+    for (ka, va), (kb, vb) in zip(net.state_dict().items(), other.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)

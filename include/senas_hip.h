@@ -184,9 +184,11 @@ int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const flo
  *   dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
  *   abk: float[3][nterms][n][c] scratch; dz[t]: gradient of z_t or NULL (skipped); ds_out: gradient of
  *   the residual input or NULL.  With relu, the mask comes from mask8 (as written by senas_node_fwd) if
- *   given, else from y; one of the two must be non-NULL.                                           */
-int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
-                   const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+ *   given, else from y; one of the two must be non-NULL.
+ *   dy_pixel_stride: floats between consecutive pixels of dy (0 or c: dense NHWC; larger: dy is a channel slice of a
+ *   wider NHWC tensor, e.g. the gradient of a torch.cat along channels -- read in place, no copy).             */
+int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
+                   const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
 // p1[n][c] += sum_p ds ; p2[t][n][c] += sum_p ds * z_t for t in [t0, t0 + TT).  block = rows x c lanes.
 template <int TT>
 __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
-                                                          const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ dy, int dys, const float* __restrict__ y,
                                                           int relu, int do_p1, double* __restrict__ p1,
                                                           double* __restrict__ p2) {
     __shared__ double red[256];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
         const size_t base = (size_t)n * hw * c + ch;
         for (long p = q0 + row; p < q1; p += rows) {
             const size_t o = base + (size_t)p * c;
-            float ds = dy[o];
+            float ds = dy[((size_t)n * hw + p) * dys + ch];
             if (relu && !(y[o] > 0.f)) ds = 0.f;
             a1 += ds;
 #pragma unroll
@@ -262,10 +262,11 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
 // per (n, c) and term per block.  grid = (chunks of `chunk` pixels, n).
 template <int TT, int U>
 __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
-                                                              const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, int dys, const float* __restrict__ y,
                                                               const uint8_t* __restrict__ mask8, int relu, int do_p1,
                                                               double* __restrict__ p1, double* __restrict__ p2) {
     extern __shared__ __attribute__((aligned(16))) double redv[];      // [4 waves][1 + TT][c]
+    const int dq = dys >> 2;                                            // dy's pixel stride in 16-byte pieces (Q when dense)
     const int Q = c >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
     const int n = blockIdx.y;
     long q0 = (long)blockIdx.x * chunk, q1 = q0 + chunk;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
             const long pp = p + (long)u * lanes;
             const bool ok = pp < q1;
             const size_t o4 = (img + (ok ? pp : q0)) * Q + q;            // index in 16-byte pieces
-            dv[u] = reinterpret_cast<const float4*>(dy)[o4];
+            dv[u] = reinterpret_cast<const float4*>(dy)[(img + (ok ? pp : q0)) * dq + q];
             if (!ok) dv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             mk[u] = 15u;
             if (relu) {
@@ -595,7 +596,7 @@ static size_t prepare_bwd_lds(const NodeDesc& d) {
 // ------------------------------------------------------------------------------------------ backward apply
 template <int V>
 __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nterms, int nimg, ZTable z,
-                                                         const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, int dys, const float* __restrict__ y,
                                                          const uint8_t* __restrict__ mask8, int relu,
                                                          const float* __restrict__ A, const float* __restrict__ B,
                                                          const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
         const int ch = (int)(i % cv) * V;
         const size_t off = img_off + (size_t)(i / cv) * c + ch;
         float ds[V], yv[V], zv[V], av[V], bv[V], kv[V];
-        ldv<V>(dy + off, ds);
+        ldv<V>(dy + ((size_t)n * hw + (size_t)(i / cv)) * dys + ch, ds);
         if (relu) {
             if (V == 4 && mask8 != nullptr) {
                 const unsigned mk = mask8[off >> 2];
@@ -704,14 +705,19 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     return launch_status("node_fwd");
 }
 
-extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, const float* y,
-                              const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
+extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
+                              const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                               double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                               float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
     SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y || mask8), "node_bwd: null pointer");
     if (d.c % 4 != 0) { SENAS_REQUIRE(!d.relu || y, "node_bwd: the byte mask needs c % 4 == 0"); mask8 = nullptr; }
+    if (dy_pixel_stride <= 0) dy_pixel_stride = d.c;
+    SENAS_REQUIRE(dy_pixel_stride >= d.c && dy_pixel_stride < (1 << 30), "node_bwd: dy pixel stride smaller than c");
+    SENAS_REQUIRE(d.c % 4 != 0 || dy_pixel_stride == d.c || (dy_pixel_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0),
+                  "node_bwd: a strided dy must keep 16-byte alignment");
+    const int dys = (int)dy_pixel_stride;
     ZTable zt{};
     DzTable dzt{};
     SeGradTable seg{};
@@ -748,7 +754,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
             if ((d.hw + chunk - 1) / chunk > 64) chunk = ((d.hw + 63) / 64 + per_iter - 1) / per_iter * per_iter;
             dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
 #define SENAS_RV(TT, UU) hipLaunchKernelGGL((node_reduce_vec_kernel<TT, UU>), rgrid, dim3(256), (size_t)4 * (1 + TT) * d.c * sizeof(double), st, \
-                                             d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, mask8, d.relu, first, p1, p2)
+                                             d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2)
             if (tt > 4) SENAS_RV(8, 1);
             else if (tt > 2) SENAS_RV(4, 2);
             else if (tt == 2) SENAS_RV(2, 4);
@@ -757,10 +763,10 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
         } else {
             const long chunk = node_chunk(d.hw, d.n);
             dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
-            if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-            else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-            else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
-            else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, y, d.relu, first, p1, p2);
+            if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
+            else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
+            else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
+            else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
         }
         t0 += tt;
         first = 0;
@@ -778,8 +784,8 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     if (any_dz || ds_out) {
         const int V = (d.c % 4 == 0) ? 4 : 1;
         dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
-        if (V == 4) hipLaunchKernelGGL((node_apply_kernel<4>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
-        else hipLaunchKernelGGL((node_apply_kernel<1>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+        if (V == 4) hipLaunchKernelGGL((node_apply_kernel<4>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, dys, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
+        else hipLaunchKernelGGL((node_apply_kernel<1>), grid, dim3(256), 0, st, d.hw, d.c, d.nterms, d.n, zt, dy, dys, y, mask8, d.relu, abk, abk + tnc, abk + 2 * tnc, dzt, ds_out);
     }
     return launch_status("node_bwd");
 }

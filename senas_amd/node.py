@@ -115,7 +115,14 @@ class _Node(torch.autograd.Function):
         w1s = saved[4 + nr + 2 * T:4 + nr + 2 * T + ns]
         w2s = saved[4 + nr + 2 * T + ns:4 + nr + 2 * T + 2 * ns]
         dev = coefs.device
-        dy = F.nhwc(dy)
+        # a channel slice of a wider NHWC tensor (the gradient of torch.cat along channels) is read in place
+        F._dev(dy)
+        ct = dy.stride(3) if dy.dim() == 4 else 0
+        if (dy.dim() == 4 and tuple(dy.shape) == (n, c, h, w) and ct > c and ct % 4 == 0 and c % 4 == 0 and
+                dy.stride() == (h * w * ct, 1, w * ct, ct) and dy.data_ptr() % 16 == 0):
+            dy_stride = ct
+        else:
+            dy, dy_stride = F.nhwc(dy), c
         mask8 = ctx.mask8
         yptr = y.data_ptr() if (meta['relu'] and mask8 is None) else None
         mix = mixc if ctx.has_mix else None
@@ -128,7 +135,7 @@ class _Node(torch.autograd.Function):
         for k, t in enumerate(real):
             if need[3 + k]:
                 dzs[t] = torch.empty_like(zs[k], memory_format=CL)
-        ds_out = torch.empty_like(dy, memory_format=CL) if (ctx.has_res and need[2]) else None
+        ds_out = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
         dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # own tensors: autograd adopts them
         dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # as .grad without cloning a view
@@ -142,7 +149,7 @@ class _Node(torch.autograd.Function):
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
         se_m, se_a1 = ctx.se_buf
-        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
+        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), dy_stride, yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
                                     F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
                                     _arr([t_.data_ptr() for t_ in dgs]), _arr([t_.data_ptr() for t_ in dbs]),
                                     F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),

@@ -55,48 +55,64 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Producer-side batch-norm statistics for the "thread = 4 channels of one output pixel" kernels (pool, resample,
-// depthwise): stats[n][c][2] += (sum, sum of squares) of this block's outputs.  Every thread of the block must
-// call it (inactive threads pass active = false).  c = 4*cv with cv a power of two <= 64 and a block that lies
-// inside one image take the cheap route -- shuffles over the pixel lanes, LDS over the 4 waves, one fp64 atomic
-// pair per channel and block; anything else falls back to per-element atomics.
-__device__ __forceinline__ void block_add_stats4(double* __restrict__ stats, bool uniform_img, int n, int c, int ch,
-                                                 const float (&v)[4], bool active) {
-    if (stats == nullptr) return;                                   // kernel-uniform
-    const int cv = c >> 2;
-    if (!uniform_img || (cv & (cv - 1)) != 0 || cv > 64) {          // block-uniform
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double* st = stats + ((size_t)n * c + ch + j) * 2;
-                atomicAdd(st, (double)v[j]);
-                atomicAdd(st + 1, (double)v[j] * v[j]);
-            }
-        }
-        return;
-    }
-    __shared__ double red_stats[4][512];                            // [wave][channel][2], c <= 256
+// depthwise).  A block owns `per_thread` consecutive chunks of 256 flat elements (same channel group in every chunk,
+// because 256 % (c/4) == 0); each thread adds its values to fp64 registers with stats_accumulate4 and the block
+// flushes ONCE with stats_flush4: shuffles over the pixel lanes of a wave, LDS over the 4 waves, one fp64 atomic
+// pair per channel -- so a 256x256 map costs ~64 atomics per (image, channel), not 2048.
+// `uniform` (block lies inside one image, c = 4*cv with cv a power of two <= 64) is decided on the host side of the
+// launch and checked per block; otherwise every element falls back to its own atomics.
+struct Stats4 {
     double s[4], q[4];
+};
+__device__ __forceinline__ void stats_init4(Stats4& a) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[j] = active ? (double)v[j] : 0.0;
-        q[j] = s[j] * s[j];
-        for (int o = cv; o < 64; o <<= 1) {
-            s[j] += __shfl_xor(s[j], o, 64);
-            q[j] += __shfl_xor(q[j], o, 64);
+    for (int j = 0; j < 4; ++j) a.s[j] = a.q[j] = 0.0;
+}
+__device__ __forceinline__ void stats_accumulate4(Stats4& a, double* __restrict__ stats, bool uniform, int n, int c, int ch,
+                                                  const float (&v)[4], bool active) {
+    if (stats == nullptr || !active) return;
+    if (uniform) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.s[j] += (double)v[j]; a.q[j] += (double)v[j] * (double)v[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double* st = stats + ((size_t)n * c + ch + j) * 2;
+            atomicAdd(st, (double)v[j]);
+            atomicAdd(st + 1, (double)v[j] * v[j]);
         }
     }
+}
+// every thread of the block calls it once, after its last element (n: the block's image, ch: the thread's first channel)
+__device__ __forceinline__ void stats_flush4(Stats4& a, double* __restrict__ stats, bool uniform, int n, int c, int ch) {
+    if (stats == nullptr || !uniform) return;                       // block-uniform
+    __shared__ double red_stats[4][512];                            // [wave][channel][2], c <= 256
+    const int cv = c >> 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int o = cv; o < 64; o <<= 1) {
+            a.s[j] += __shfl_xor(a.s[j], o, 64);
+            a.q[j] += __shfl_xor(a.q[j], o, 64);
+        }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < cv) {                                                // lane == channel group (threads are laid out c-fastest)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red_stats[wave][(lane * 4 + j) * 2] = s[j]; red_stats[wave][(lane * 4 + j) * 2 + 1] = q[j]; }
+        for (int j = 0; j < 4; ++j) { red_stats[wave][(ch + j) * 2] = a.s[j]; red_stats[wave][(ch + j) * 2 + 1] = a.q[j]; }
     }
     __syncthreads();
-    const int nw = cv < 64 ? 4 : 4;                                 // all 4 waves hold every channel group (cv <= 64)
     for (int i = threadIdx.x; i < 2 * c; i += 256) {
         double t = 0.0;
-        for (int w = 0; w < nw; ++w) t += red_stats[w][i];
+        for (int w = 0; w < 4; ++w) t += red_stats[w][i];
         atomicAdd(stats + (size_t)n * c * 2 + i, t);
     }
+}
+// host side: chunks of 256 elements per block such that a block never straddles two images; 0 = no uniform layout
+inline int stats_chunks_per_block(long per_img_elems, int c, long total_elems) {
+    const int cv = c >> 2;
+    if (c % 4 != 0 || (cv & (cv - 1)) != 0 || cv > 64) return 0;
+    for (int p = 8; p >= 1; p >>= 1)          // fat blocks only while >= 2048 of them remain: small maps stay latency-bound
+        if (per_img_elems % (256L * p) == 0 && (p == 1 || total_elems / (256L * p) >= 2048)) return p;
+    return 0;
 }
 
 // Geometry of one "gather" pass: out[n,oy,ox,:] reads in[n, f(oy,ky), f(ox,kx), :].

@@ -173,57 +173,65 @@ template <bool TG, int V>
 __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
                                                      const float* __restrict__ w, float* __restrict__ out,
                                                      int in_relu, const float* __restrict__ mask,
-                                                     double* __restrict__ stats, long total) {
-    const long first = (long)blockIdx.x * 256;
-    long idx = first + threadIdx.x;
-    const bool active = idx < total;               // statistics are reduced per block: every thread stays alive
-    if (!active) idx = total - 1;
+                                                     double* __restrict__ stats, long total, int P) {
+    // block b owns P chunks of 256 flat elements; P > 0 means the launcher guarantees the block lies inside one image,
+    // so the batch-norm statistics are kept in registers and flushed once per block (common.h)
+    Stats4 acc_st;
+    stats_init4(acc_st);
+    const bool uniform = P > 0;
+    const int chunks = uniform ? P : 1;
     const int cv = g.cout / V;
-    const long per_img = (long)g.hout * g.wout * cv;
-    const bool uniform = first / per_img == (first + 255 < total ? first + 255 : total - 1) / per_img;
-    const int c = (int)(idx % cv) * V;
-    long pix = idx / cv;
-    const int ox = (int)(pix % g.wout);
-    pix /= g.wout;
-    const int oy = (int)(pix % g.hout), n = (int)(pix / g.hout);
     const int taps = g.kh * g.kw;
-    float acc[V];
+    int n_blk = 0, c_thr = 0;
+    for (int kk = 0; kk < chunks; ++kk) {
+        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        const bool active = idx < total;
+        if (!active) idx = total - 1;
+        const int c = (int)(idx % cv) * V;
+        long pix = idx / cv;
+        const int ox = (int)(pix % g.wout);
+        pix /= g.wout;
+        const int oy = (int)(pix % g.hout), n = (int)(pix / g.hout);
+        n_blk = n; c_thr = c;
+        float acc[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    for (int ky = 0; ky < g.kh; ++ky) {
-        int iy;
-        if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
-        for (int kx = 0; kx < g.kw; ++kx) {
-            int ix;
-            if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
-            const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
-            float v[V];
-            ldv<V>(ip, v);
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            int iy;
+            if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                int ix;
+                if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
+                const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
+                float v[V];
+                ldv<V>(ip, v);
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                float x = in_relu ? fmaxf(v[j], 0.f) : v[j];
-                acc[j] = fmaf(x, w[(c + j) * taps + ky * g.kw + kx], acc[j]);
+                for (int j = 0; j < V; ++j) {
+                    float x = in_relu ? fmaxf(v[j], 0.f) : v[j];
+                    acc[j] = fmaf(x, w[(c + j) * taps + ky * g.kw + kx], acc[j]);
+                }
+            }
+        }
+        const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (mask != nullptr && !(mask[o + j] > 0.f)) acc[j] = 0.f;
+        }
+        if (active) stv<V>(out + o, acc);
+        if constexpr (V == 4) {
+            stats_accumulate4(acc_st, stats, uniform, n, g.cout, c, acc, active);
+        } else {
+            if (stats != nullptr && active) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    double* st = stats + ((size_t)n * g.cout + c + j) * 2;
+                    atomicAdd(st, (double)acc[j]);
+                    atomicAdd(st + 1, (double)acc[j] * acc[j]);
+                }
             }
         }
     }
-    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + c;
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        if (mask != nullptr && !(mask[o + j] > 0.f)) acc[j] = 0.f;
-    }
-    if (active) stv<V>(out + o, acc);
-    if constexpr (V == 4) {
-        block_add_stats4(stats, uniform, n, g.cout, c, acc, active);
-    } else {
-        if (stats != nullptr && active) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                double* st = stats + ((size_t)n * g.cout + c + j) * 2;
-                atomicAdd(st, (double)acc[j]);
-                atomicAdd(st + 1, (double)acc[j] * acc[j]);
-            }
-        }
-    }
+    if constexpr (V == 4) stats_flush4(acc_st, stats, uniform, n_blk, g.cout, c_thr);
 }
 
 // depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
@@ -390,7 +398,7 @@ using namespace senas;
 
 extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     if (!g) return 0;
-    if (g->groups != 1) return (int64_t)512 * g->ci * g->kh * g->kw * sizeof(float) + 256;   // per-block wgrad partials
+    if (g->groups != 1) return (int64_t)2048 * g->ci * g->kh * g->kw * sizeof(float) + 256;  // per-block wgrad partials
     // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
     const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
     const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
@@ -420,14 +428,16 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
     if (g->groups != 1) {
         const int V = (g->co % 4 == 0) ? 4 : 1;
-        long total = (long)g->n * g->ho * g->wo * (g->co / V);
-        dim3 grid((unsigned)((total + 255) / 256));
+        const long per_img = (long)g->ho * g->wo * (g->co / V);
+        long total = per_img * g->n;
+        const int P = (V == 4 && stats != nullptr) ? stats_chunks_per_block(per_img, g->co, total) : 0;
+        dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))));
         if (g->transposed) {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
-            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
         } else {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
-            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
         }
         return launch_status("dwconv_fwd");
     }
@@ -475,11 +485,11 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
         long total = (long)g->n * g->hi * g->wi * (g->ci / V);
         dim3 grid((unsigned)((total + 255) / 256));
         if (!g->transposed) {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
-            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
         } else {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
-            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
         }
         return launch_status("dwconv_bwd_data");
     }
@@ -531,8 +541,11 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         SENAS_REQUIRE(g->kh == g->kw && (g->kh == 3 || g->kh == 5), "depthwise wgrad: only 3x3 and 5x5 are on the path");
         const int c4 = g->ci / 4;
         if (g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64 && ws != nullptr) {     // two-stage, atomic-free
-            long nblk = (total + 255) / 256;
-            if (nblk > 512) nblk = 512;
+            // short chunks: the per-block loop (pixel lanes x taps of dependent loads) is the critical path of this
+            // launch on every map size; 2 passes of the 256/c4 pixel lanes per block, at most 2048 partial rows
+            const long lanes = 256 / c4;
+            long nblk = (total + 2 * lanes - 1) / (2 * lanes);
+            if (nblk > 2048) nblk = 2048;
             wg.chunk = (int)((total + nblk - 1) / nblk);
             nblk = (total + wg.chunk - 1) / wg.chunk;
             float* part = reinterpret_cast<float*>(ws);

@@ -19,22 +19,26 @@ __device__ __forceinline__ void decode(long idx, int cv, int wo, int ho, int& c,
     n = (int)(p / ho);
 }
 
-// forward kernels with statistics: every thread stays alive (block-level reduction); `active` guards the stores
-template <int V>
-__device__ __forceinline__ void fwd_prologue(long total, int cv, int wo, int ho, long& idx, bool& active, bool& uniform) {
-    const long first = (long)blockIdx.x * 256;
-    idx = first + threadIdx.x;
-    active = idx < total;
-    if (!active) idx = total - 1;
-    const long per_img = (long)ho * wo * cv;
-    const long last = first + 255 < total ? first + 255 : total - 1;
-    uniform = first / per_img == last / per_img;
-}
+// forward kernels: block b owns flat elements [b*256*P, (b+1)*256*P) as P chunks of 256; `P > 0` doubles as "uniform":
+// the block lies inside one image (decided by the launcher), so statistics are flushed once per block
+#define SENAS_FWD_LOOP_BEGIN(total_, P_)                                                        \
+    Stats4 acc_st;                                                                              \
+    stats_init4(acc_st);                                                                        \
+    const bool uniform = (P_) > 0;                                                              \
+    const int chunks = uniform ? (P_) : 1;                                                      \
+    int n_blk = 0, ch_thr = 0;                                                                  \
+    for (int kk = 0; kk < chunks; ++kk) {                                                       \
+        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;                        \
+        const bool active = idx < (total_);                                                     \
+        if (!active) idx = (total_) - 1;
+#define SENAS_FWD_LOOP_END(stats_, c_)                                                          \
+    }                                                                                           \
+    if constexpr (V == 4) stats_flush4(acc_st, stats_, uniform, n_blk, c_, ch_thr);
 
 template <int V>
-__device__ __forceinline__ void fwd_stats(double* stats, bool uniform, int n, int c, int ch, const float (&v)[V], bool active) {
+__device__ __forceinline__ void fwd_stats(Stats4& a, double* stats, bool uniform, int n, int c, int ch, const float (&v)[V], bool active) {
     if constexpr (V == 4) {
-        block_add_stats4(stats, uniform, n, c, ch, v, active);
+        stats_accumulate4(a, stats, uniform, n, c, ch, v, active);
     } else {
         if (stats == nullptr || !active) return;
 #pragma unroll
@@ -60,12 +64,11 @@ __device__ __forceinline__ void add_stats(double* stats, int n, int c, int ch, c
 // ---------------------------------------------------------------- average pool, count_include_pad=False
 template <int V>
 __global__ __launch_bounds__(256) void avgpool3_fwd_kernel(PoolGeom g, const float* __restrict__ x, int in_relu,
-                                                           float* __restrict__ y, double* __restrict__ stats, long total) {
-    long idx;
-    bool active, uniform;
-    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
+                                                           float* __restrict__ y, double* __restrict__ stats, long total, int P) {
+    SENAS_FWD_LOOP_BEGIN(total, P)
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
+    n_blk = n; ch_thr = ch;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(256) void avgpool3_fwd_kernel(PoolGeom g, const flo
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = acc[j] / (float)cnt;
     if (active) stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, acc);
-    fwd_stats<V>(stats, uniform, n, g.c, ch, acc, active);
+    fwd_stats<V>(acc_st, stats, uniform, n, g.c, ch, acc, active);
+    SENAS_FWD_LOOP_END(stats, g.c)
 }
 
 __device__ __forceinline__ int window_count(int o, int stride, int lim) {
@@ -141,12 +145,11 @@ __global__ __launch_bounds__(256) void avgpool3_bwd_kernel(PoolGeom g, const flo
 template <int V>
 __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(PoolGeom g, const float* __restrict__ x, int in_relu,
                                                            float* __restrict__ y, uint8_t* __restrict__ amax,
-                                                           double* __restrict__ stats, long total) {
-    long idx;
-    bool active, uniform;
-    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
+                                                           double* __restrict__ stats, long total, int P) {
+    SENAS_FWD_LOOP_BEGIN(total, P)
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
+    n_blk = n; ch_thr = ch;
     float best[V];
     int arg[V];
 #pragma unroll
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(PoolGeom g, const flo
 #pragma unroll
         for (int j = 0; j < V; ++j) amax[o + j] = (uint8_t)arg[j];
     }
-    fwd_stats<V>(stats, uniform, n, g.c, ch, best, active);
+    fwd_stats<V>(acc_st, stats, uniform, n, g.c, ch, best, active);
+    SENAS_FWD_LOOP_END(stats, g.c)
 }
 
 template <int V>
@@ -226,12 +230,11 @@ __device__ __forceinline__ void bilinear_src(int d, int lim, int& i0, int& i1, f
 
 template <int V>
 __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(PoolGeom g, const float* __restrict__ x,
-                                                             float* __restrict__ y, double* __restrict__ stats, long total) {
-    long idx;
-    bool active, uniform;
-    fwd_prologue<V>(total, g.c / V, g.wo, g.ho, idx, active, uniform);
+                                                             float* __restrict__ y, double* __restrict__ stats, long total, int P) {
+    SENAS_FWD_LOOP_BEGIN(total, P)
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
+    n_blk = n; ch_thr = ch;
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     bilinear_src(oy, g.h, y0, y1, ly0, ly1);
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(PoolGeom g, const f
 #pragma unroll
     for (int j = 0; j < V; ++j) r[j] = ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
     if (active) stv<V>(y + ((size_t)(n * g.ho + oy) * g.wo + ox) * g.c + ch, r);
-    fwd_stats<V>(stats, uniform, n, g.c, ch, r, active);
+    fwd_stats<V>(acc_st, stats, uniform, n, g.c, ch, r, active);
+    SENAS_FWD_LOOP_END(stats, g.c)
 }
 
 // weight with which destination row/col d reads source index i
@@ -301,11 +305,24 @@ using namespace senas;
         else hipLaunchKernelGGL((kernel<1>), grid, dim3(256), 0, as_stream(stream), g, __VA_ARGS__, total);     \
     } while (0)
 
+// forward kernels: P chunks of 256 elements per block when that keeps every block inside one image (statistics are
+// then flushed once per block), else one chunk per block with per-element atomics
+#define SENAS_LAUNCH_FWD(kernel, per_img_expr, c_out, ...)                                                      \
+    do {                                                                                                        \
+        const int V_ = (g.c % 4 == 0) ? 4 : 1;                                                                  \
+        const long per_img = (per_img_expr) * (long)(g.c / V_);                                                 \
+        const long total = per_img * g.n;                                                                       \
+        const int P_ = V_ == 4 ? stats_chunks_per_block(per_img, c_out, total) : 0;                                    \
+        dim3 grid((unsigned)((total + 256L * (P_ > 0 ? P_ : 1) - 1) / (256L * (P_ > 0 ? P_ : 1))));             \
+        if (V_ == 4) hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, as_stream(stream), g, __VA_ARGS__, total, P_); \
+        else hipLaunchKernelGGL((kernel<1>), grid, dim3(256), 0, as_stream(stream), g, __VA_ARGS__, total, P_); \
+    } while (0)
+
 extern "C" int senas_avgpool3_fwd(int n, int h, int w, int c, int stride, const float* x, int in_relu, float* y,
                                   double* stats, void* stream) {
     PoolGeom g;
     SENAS_REQUIRE(pool_geom(n, h, w, c, stride, g) && x && y, "avgpool3_fwd: bad argument");
-    SENAS_LAUNCH_V(avgpool3_fwd_kernel, (long)n * g.ho * g.wo, x, in_relu, y, stats);
+    SENAS_LAUNCH_FWD(avgpool3_fwd_kernel, (long)g.ho * g.wo, g.c, x, in_relu, y, stats);
     return launch_status("avgpool3_fwd");
 }
 
@@ -321,7 +338,7 @@ extern "C" int senas_maxpool3_fwd(int n, int h, int w, int c, int stride, const 
                                   uint8_t* argmax, double* stats, void* stream) {
     PoolGeom g;
     SENAS_REQUIRE(pool_geom(n, h, w, c, stride, g) && x && y && argmax, "maxpool3_fwd: bad argument");
-    SENAS_LAUNCH_V(maxpool3_fwd_kernel, (long)n * g.ho * g.wo, x, in_relu, y, argmax, stats);
+    SENAS_LAUNCH_FWD(maxpool3_fwd_kernel, (long)g.ho * g.wo, g.c, x, in_relu, y, argmax, stats);
     return launch_status("maxpool3_fwd");
 }
 
@@ -336,7 +353,7 @@ extern "C" int senas_maxpool3_bwd(int n, int h, int w, int c, int stride, const 
 extern "C" int senas_bilinear2x_fwd(int n, int h, int w, int c, const float* x, float* y, double* stats, void* stream) {
     SENAS_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && x && y, "bilinear2x_fwd: bad argument");
     PoolGeom g{n, h, w, c, 2 * h, 2 * w, 2};
-    SENAS_LAUNCH_V(bilinear2x_fwd_kernel, (long)n * g.ho * g.wo, x, y, stats);
+    SENAS_LAUNCH_FWD(bilinear2x_fwd_kernel, (long)g.ho * g.wo, g.c, x, y, stats);
     return launch_status("bilinear2x_fwd");
 }
 

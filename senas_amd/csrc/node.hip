@@ -749,7 +749,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
             // at most 64 blocks contend for one (n, c) accumulator
             const int U = tt <= 2 ? 4 : (tt <= 4 ? 2 : 1);
             const long per_iter = (long)(256 / Q) * U;
-            const int iters = d.hw <= 4096 ? 2 : (d.hw <= 16384 ? 4 : 8);
+            const int iters = d.hw <= 4096 ? 1 : (d.hw <= 16384 ? 2 : 8);
             long chunk = per_iter * iters;
             if ((d.hw + chunk - 1) / chunk > 64) chunk = ((d.hw + 63) / 64 + per_iter - 1) / per_iter * per_iter;
             dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);

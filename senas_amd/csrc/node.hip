@@ -162,26 +162,11 @@ static size_t prepare_fwd_lds(const NodeDesc& d) {
            ((size_t)d.n * d.c + (size_t)d.n * kMaxMid + (size_t)2 * kMaxMid * d.c) * sizeof(float);
 }
 
-// ------------------------------------------------------------------------------------------ forward combine
-// grid = (tiles, n); coefficients of image n are staged in LDS once per block.
+// one pass over the raw terms of image n: y = act(bias + residual + sum_t cf[t] * z_t)   (cf, bias: per channel, in LDS)
 template <int V>
-__global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, int nterms, int nimg, ZTable z,
-                                                               const float* __restrict__ coef, const float* __restrict__ shiftc,
-                                                               const float* __restrict__ residual, int relu,
-                                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
-    const int n = blockIdx.y;
-    float* bias = lds + nterms * c;
-    for (int i = threadIdx.x; i < nterms * c; i += 256) {
-        const int t = i / c, ch = i % c;
-        lds[i] = coef[((size_t)t * nimg + n) * c + ch];
-    }
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-        float b = 0.f;
-        for (int t = 0; t < nterms; ++t) b += shiftc[((size_t)t * nimg + n) * c + ch];
-        bias[ch] = b;
-    }
-    __syncthreads();
+__device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n, const ZTable& z, const float* lds,
+                                               const float* bias, const float* __restrict__ residual, int relu,
+                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
     const int cv = c / V;
     const long per_img = hw * cv;
     const size_t img_off = (size_t)n * hw * c;
@@ -211,6 +196,139 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
         for (int j = 0; j < V; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
         stv<V>(y + off, acc);
     }
+}
+
+// ------------------------------------------------------------------------------------------ forward combine
+// grid = (tiles, n); coefficients of image n are staged in LDS once per block.
+template <int V>
+__global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, int nterms, int nimg, ZTable z,
+                                                               const float* __restrict__ coef, const float* __restrict__ shiftc,
+                                                               const float* __restrict__ residual, int relu,
+                                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
+    const int n = blockIdx.y;
+    float* bias = lds + nterms * c;
+    for (int i = threadIdx.x; i < nterms * c; i += 256) {
+        const int t = i / c, ch = i % c;
+        lds[i] = coef[((size_t)t * nimg + n) * c + ch];
+    }
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float b = 0.f;
+        for (int t = 0; t < nterms; ++t) b += shiftc[((size_t)t * nimg + n) * c + ch];
+        bias[ch] = b;
+    }
+    __syncthreads();
+    combine_stream<V>(hw, c, nterms, n, z, lds, bias, residual, relu, y, mask8);
+}
+
+// ------------------------------------------------------------------------------------------ forward, fused
+// Few-term nodes (the derived network's cells: <= kFuseTerms terms): every block derives the per-channel
+// coefficients of ITS image in a short prologue (the batch statistics of all images are 4 KiB per term, L2-resident)
+// and then streams -- one launch per node instead of two; the block (0, image) also leaves the quantities the
+// backward pass needs (coefs, gate, se_m, se_a1), block (0, 0) updates the running statistics.
+// dynamic LDS: doubles part[R][c][2] | zown[c]; floats cf[T][c] | bias[c] | sc[2][c] | m[c] | a1[kMaxMid]
+constexpr int kFuseTerms = 4;
+
+template <int V>
+__global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable z, const float* __restrict__ residual,
+                                                             float* __restrict__ y, uint8_t* __restrict__ mask8,
+                                                             float* __restrict__ coefs, float* __restrict__ gate,
+                                                             float* __restrict__ se_m, float* __restrict__ se_a1) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int n = blockIdx.y, nimg = d.n, c = d.c, T = d.nterms;
+    const bool first = blockIdx.x == 0, writer0 = first && n == 0;
+    const int R = 256 / c, ch = threadIdx.x % c, row = threadIdx.x / c;
+    const bool act = row < R, owner = threadIdx.x < c;              // owner: row 0, one thread per channel
+    double* part = ldsd;                                            // [R][c][2]
+    double* zown = part + (size_t)R * c * 2;                        // [c]: this image's channel sums
+    float* cf = reinterpret_cast<float*>(zown + c);                 // [T][c]
+    float* bias = cf + (size_t)T * c;                               // [c]
+    float* sc = bias + c;                                           // [2][c]: scale, shift
+    float* m_s = sc + 2 * c;                                        // [c]
+    float* a_s = m_s + c;                                           // [kMaxMid]
+    float bsum = 0.f;                                               // owner threads: running bias of their channel
+    for (int t = 0; t < T; ++t) {
+        const double* st = d.stats[t];
+        const bool se = d.w1[t] != nullptr;
+        const int mid = se ? d.mid[t] : 0;
+        // ---- global reads first
+        double s = 0.0, q = 0.0;
+        if (act && st != nullptr && (d.training || se))
+            for (int i = row; i < nimg; i += R) {
+                const double v0 = st[((size_t)i * c + ch) * 2], v1 = st[((size_t)i * c + ch) * 2 + 1];
+                s += v0; q += v1;
+                if (i == n) zown[ch] = v0;
+            }
+        float gam = 0.f, bet = 0.f, rm = 0.f, rv = 0.f;
+        if (owner) {
+            gam = d.gamma[t][ch]; bet = d.beta[t][ch];
+            if (d.rmean[t] != nullptr) { rm = d.rmean[t][ch]; rv = d.rvar[t][ch]; }
+        }
+        const float w = d.mix != nullptr ? d.mix[t] : 1.f;
+        if (act) { part[((size_t)row * c + ch) * 2] = s; part[((size_t)row * c + ch) * 2 + 1] = q; }
+        __syncthreads();
+        float scale = 0.f, shift = 0.f;
+        if (owner) {
+            float mean, invstd;
+            if (d.training) {
+                double ss = 0.0, qq = 0.0;
+                for (int rr = 0; rr < R; ++rr) { ss += part[((size_t)rr * c + ch) * 2]; qq += part[((size_t)rr * c + ch) * 2 + 1]; }
+                const double mm = (double)nimg * (double)d.hw, mu = ss / mm;
+                double var = qq / mm - mu * mu;
+                if (var < 0.0) var = 0.0;
+                mean = (float)mu;
+                invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+                if (writer0 && d.rmean[t] != nullptr) {
+                    const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
+                    d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
+                    d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
+                }
+            } else {
+                mean = rm;
+                invstd = 1.f / sqrtf(rv + d.eps);
+            }
+            scale = gam * invstd;
+            shift = bet - mean * scale;
+            if (writer0) {
+                float* co = coefs + (size_t)t * 4 * c;
+                co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
+            }
+            if (se) m_s[ch] = (float)((double)scale * (st != nullptr ? zown[ch] / (double)d.hw : 0.0) + (double)shift);
+        }
+        if (writer0 && threadIdx.x == 0 && d.training && d.nbt[t] != nullptr) *d.nbt[t] += 1;
+        const size_t tb = ((size_t)t * nimg + n) * c;
+        float g = 1.f;
+        if (se) {                                                   // block-uniform
+            __syncthreads();
+            if (first && owner) se_m[tb + ch] = m_s[ch];
+            if ((int)threadIdx.x < mid) {
+                float a = 0.f;
+                for (int k = 0; k < c; ++k) a = fmaf(m_s[k], d.w1[t][threadIdx.x * c + k], a);
+                a_s[threadIdx.x] = a;
+                if (first) se_a1[((size_t)t * nimg + n) * kMaxMid + threadIdx.x] = a;
+            }
+            __syncthreads();
+            if (owner) {
+                float a = 0.f;
+                for (int j = 0; j < mid; ++j) a = fmaf(fmaxf(a_s[j], 0.f), d.w2[t][ch * mid + j], a);
+                g = 1.f / (1.f + expf(-a));
+            }
+        }
+        if (owner) {
+            cf[t * c + ch] = w * g * scale;
+            bsum += w * g * shift;
+            if (first) gate[tb + ch] = g;
+        }
+        __syncthreads();                                            // part / zown / m_s / a_s are reused by the next term
+    }
+    if (owner) bias[ch] = bsum;
+    __syncthreads();
+    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8);
+}
+
+static size_t fused_fwd_lds(const NodeDesc& d) {
+    const int R = 256 / d.c;
+    return ((size_t)R * d.c * 2 + d.c) * sizeof(double) + ((size_t)d.nterms * d.c + 4 * d.c + kMaxMid) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------ backward reduce
@@ -454,14 +572,17 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_generic_kernel(NodeDesc 
 // activations live in LDS, reductions over the images go through LDS -- one memory round trip instead of ~10.
 constexpr int kImgs = 8;
 
-__global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
-                                                               const double* __restrict__ p2, const float* __restrict__ coefs,
-                                                               const float* __restrict__ gate, const float* __restrict__ se_m,
-                                                               const float* __restrict__ se_a1, float* __restrict__ dmix,
-                                                               float* __restrict__ A, float* __restrict__ B, float* __restrict__ K,
-                                                               SeGradTable seg) {
-    extern __shared__ __attribute__((aligned(16))) double ldsd[];
-    const int t = blockIdx.x, n = d.n, c = d.c;
+// One term.  write_grads: this block owns the parameter gradients (d gamma, d beta, d mix, d SE weights).
+// A/B/K non-NULL: coefficients of every image go to global memory (stand-alone kernel); keep >= 0: those of image
+// `keep` go to A_s/B_s/K_s[c] (fused apply kernel).  Every thread of the block must call it; ends with a barrier.
+__device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, double* ldsd, const double* __restrict__ p1,
+                                                 const double* __restrict__ p2, const float* __restrict__ coefs,
+                                                 const float* __restrict__ gate, const float* __restrict__ se_m,
+                                                 const float* __restrict__ se_a1, float* __restrict__ dmix,
+                                                 const SeGradTable& seg, bool write_grads, float* __restrict__ A,
+                                                 float* __restrict__ B, float* __restrict__ K, int keep, float* A_s,
+                                                 float* B_s, float* K_s) {
+    const int n = d.n, c = d.c;
     const int R = 256 / c, ch = threadIdx.x % c, row = threadIdx.x / c;
     const bool act = row < R;
     const size_t tb = (size_t)t * n * c;
@@ -514,7 +635,7 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
     dmix_part = wave_sum(dmix_part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmix_part;
     __syncthreads();                                             // red[], da2[], SE operands visible
-    if (threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (write_grads && threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)(red[0] + red[1] + red[2] + red[3]);
 
     double e[kImgs];
 #pragma unroll
@@ -525,7 +646,7 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
             const int cc = idx / mid, j = idx - cc * mid;
             double sacc = 0.0;
             for (int i = 0; i < n; ++i) sacc += da2[i * c + cc] * fmaxf(a1_s[i * kMaxMid + j], 0.f);
-            seg.w2[t][idx] = (float)sacc;
+            if (write_grads) seg.w2[t][idx] = (float)sacc;
         }
         // da1[n][j] = (a1 > 0) * sum_c da2[n][c] * W2[c][j]
         for (int idx = threadIdx.x; idx < n * mid; idx += 256) {
@@ -540,7 +661,7 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
             const int j = idx / c, cc = idx - j * c;
             double sacc = 0.0;
             for (int i = 0; i < n; ++i) sacc += da1[i * kMaxMid + j] * m_s[i * c + cc];
-            seg.w1[t][idx] = (float)sacc;
+            if (write_grads) seg.w1[t][idx] = (float)sacc;
         }
 #pragma unroll
         for (int k = 0; k < kImgs; ++k) {
@@ -565,26 +686,40 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const
     }
     if (act) { part[((size_t)row * c + ch) * 2] = s1; part[((size_t)row * c + ch) * 2 + 1] = s2; }
     __syncthreads();
-    if (!act) return;
-    s1 = 0.0; s2 = 0.0;
-    for (int rr = 0; rr < R; ++rr) { s1 += part[((size_t)rr * c + ch) * 2]; s2 += part[((size_t)rr * c + ch) * 2 + 1]; }
-    const double kk = s2 - mean * s1;
-    if (row == 0) {
-        seg.dbeta[t][ch] = (float)s1;
-        seg.dgamma[t][ch] = (float)(invstd * kk);
-    }
-    const double bcoef = d.training ? -scale * invstd * invstd * kk / M : 0.0;
-    const double kconst = d.training ? (-scale * s1 / M + scale * invstd * invstd * mean * kk / M) : 0.0;
+    if (act) {
+        s1 = 0.0; s2 = 0.0;
+        for (int rr = 0; rr < R; ++rr) { s1 += part[((size_t)rr * c + ch) * 2]; s2 += part[((size_t)rr * c + ch) * 2 + 1]; }
+        const double kk = s2 - mean * s1;
+        if (write_grads && row == 0) {
+            seg.dbeta[t][ch] = (float)s1;
+            seg.dgamma[t][ch] = (float)(invstd * kk);
+        }
+        const double bcoef = d.training ? -scale * invstd * invstd * kk / M : 0.0;
+        const double kconst = d.training ? (-scale * s1 / M + scale * invstd * invstd * mean * kk / M) : 0.0;
 #pragma unroll
-    for (int k = 0; k < kImgs; ++k) {
-        const int i = row + k * R;
-        if (i < n) {
-            const size_t o = tb + (size_t)i * c + ch;
-            A[o] = (float)(scale * w * Gt[k]);
-            B[o] = (float)bcoef;
-            K[o] = (float)(scale * e[k] + kconst);
+        for (int k = 0; k < kImgs; ++k) {
+            const int i = row + k * R;
+            if (i < n) {
+                const float av = (float)(scale * w * Gt[k]), bv = (float)bcoef, kv = (float)(scale * e[k] + kconst);
+                if (A != nullptr) {
+                    const size_t o = tb + (size_t)i * c + ch;
+                    A[o] = av; B[o] = bv; K[o] = kv;
+                }
+                if (i == keep) { A_s[ch] = av; B_s[ch] = bv; K_s[ch] = kv; }
+            }
         }
     }
+    __syncthreads();                                             // the LDS scratch is reused by the caller's next term
+}
+
+__global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
+                                                               const double* __restrict__ p2, const float* __restrict__ coefs,
+                                                               const float* __restrict__ gate, const float* __restrict__ se_m,
+                                                               const float* __restrict__ se_a1, float* __restrict__ dmix,
+                                                               float* __restrict__ A, float* __restrict__ B, float* __restrict__ K,
+                                                               SeGradTable seg) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    prepare_bwd_term(d, blockIdx.x, ldsd, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, true, A, B, K, -1, nullptr, nullptr, nullptr);
 }
 
 static size_t prepare_bwd_lds(const NodeDesc& d) {
@@ -594,15 +729,15 @@ static size_t prepare_bwd_lds(const NodeDesc& d) {
 }
 
 // ------------------------------------------------------------------------------------------ backward apply
+// dz_t = A * ds + B * z_t + K for every term of image n (ds = dy under the ReLU mask); coefficient (t, ch) sits at
+// A[t * kt + kbase + ch] -- global [t][n][c] arrays (kt = nimg*c, kbase = n*c) or per-block LDS copies (kt = c, kbase = 0)
 template <int V>
-__global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nterms, int nimg, ZTable z,
-                                                         const float* __restrict__ dy, int dys, const float* __restrict__ y,
-                                                         const uint8_t* __restrict__ mask8, int relu,
-                                                         const float* __restrict__ A, const float* __restrict__ B,
-                                                         const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
+__device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, const ZTable& z, const float* __restrict__ dy,
+                                             int dys, const float* __restrict__ y, const uint8_t* __restrict__ mask8, int relu,
+                                             const float* A, const float* B, const float* K, int kt, int kbase, const DzTable& dz,
+                                             float* __restrict__ ds_out) {
     const int cv = c / V;
     const long per_img = hw * cv;
-    const int n = blockIdx.y;
     const size_t img_off = (size_t)n * hw * c;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cv) * V;
@@ -624,7 +759,7 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
         for (int t = 0; t < nterms; ++t) {
             float* out = dz.p[t];
             if (out == nullptr) continue;
-            const size_t ko = ((size_t)t * nimg + n) * c + ch;
+            const int ko = t * kt + kbase + ch;
             ldv<V>(z.p[t] + off, zv);
             ldv<V>(A + ko, av);
             ldv<V>(B + ko, bv);
@@ -634,6 +769,15 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
             stv<V>(out + off, zv);
         }
     }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nterms, int nimg, ZTable z,
+                                                         const float* __restrict__ dy, int dys, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ mask8, int relu,
+                                                         const float* __restrict__ A, const float* __restrict__ B,
+                                                         const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
+    apply_stream<V>(hw, c, nterms, blockIdx.y, z, dy, dys, y, mask8, relu, A, B, K, nimg * c, blockIdx.y * c, dz, ds_out);
 }
 
 static bool fill_desc(const senas_node_desc* s, NodeDesc& d) {
@@ -694,6 +838,13 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     }
     SENAS_REQUIRE(!any_se || (se_m && se_a1), "node_fwd: SE scratch missing");
     hipStream_t st = as_stream(stream);
+    if (d.nterms <= kFuseTerms && fused_fwd_lds(d) <= 48 * 1024) {          // one launch: prologue + stream
+        const int V = (d.c % 4 == 0) ? 4 : 1;
+        dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+        if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1);
+        else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1);
+        return launch_status("node_fwd (fused)");
+    }
     const size_t lds1 = prepare_fwd_lds(d);
     SENAS_REQUIRE(lds1 <= 64 * 1024, "node_fwd: batch x channels too large for the prepare kernel");
     hipLaunchKernelGGL(node_prepare_fwd_kernel, dim3(d.nterms), dim3(256), lds1, st, d, coefs, gate, coef, shiftc, se_m, se_a1);
@@ -773,7 +924,10 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     } while (t0 < d.nterms);
     const size_t tnc = (size_t)d.nterms * d.n * d.c;
     const size_t lds_fast = prepare_bwd_lds(d);
-    if (d.n <= kImgs * (256 / d.c) && lds_fast <= 64 * 1024) {
+    const bool fast_ok = d.n <= kImgs * (256 / d.c) && lds_fast <= 64 * 1024;
+    // (running this preparation as a prologue of every apply block was measured: the block cannot stream before its
+    // prologue is done, so the launch it saves buys nothing -- 20.2 ms vs 19.7 ms per step; kept as its own launch)
+    if (fast_ok) {
         hipLaunchKernelGGL(node_prepare_bwd_kernel, dim3(d.nterms), dim3(256), lds_fast, st, d, p1, p2, coefs, gate, se_m, se_a1,
                            dmix, abk, abk + tnc, abk + 2 * tnc, seg);
     } else {

@@ -54,6 +54,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- strided sums inside a 16-lane row with DPP (VALU speed; ds_bpermute-based __shfl_xor costs ~60 ns each here,
+// which dominated every "100 partial sums x log2(lanes) steps" epilogue).  row_strided_sum(v, s): every lane ends up with
+// the sum over the lanes of ITS 16-lane row that are congruent to it modulo s (s = 1, 2, 4, 8; s >= 16: unchanged).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <typename T>
+__device__ __forceinline__ T row_strided_sum(T v, int stride) {        // stride is wave-uniform
+    if (stride <= 8) v += dpp_mov<0x128>(v);     // row_ror:8
+    if (stride <= 4) v += dpp_mov<0x124>(v);     // row_ror:4
+    if (stride <= 2) v += dpp_mov<0x122>(v);     // row_ror:2
+    if (stride <= 1) v += dpp_mov<0x121>(v);     // row_ror:1
+    return v;
+}
+// After row_strided_sum, the lanes of a wave that still hold distinct partial sums of the same residue class are one per
+// "slot": slot = lane / max(stride, 16); there are wave_slots(stride) of them (4 for stride <= 16, 2 for 32, 1 for 64).
+__device__ __forceinline__ int wave_slots(int stride) { return stride <= 16 ? 4 : 64 / stride; }
+__device__ __forceinline__ int lane_slot(int lane, int stride) { return lane / (stride < 16 ? 16 : stride); }
+__device__ __forceinline__ bool lane_holds_partial(int lane, int stride) { return (lane & 15) < (stride < 16 ? stride : 16); }
+
 // Producer-side batch-norm statistics for the "thread = 4 channels of one output pixel" kernels (pool, resample,
 // depthwise).  A block owns `per_thread` consecutive chunks of 256 flat elements (same channel group in every chunk,
 // because 256 % (c/4) == 0); each thread adds its values to fp64 registers with stats_accumulate4 and the block
@@ -86,23 +114,24 @@ __device__ __forceinline__ void stats_accumulate4(Stats4& a, double* __restrict_
 // every thread of the block calls it once, after its last element (n: the block's image, ch: the thread's first channel)
 __device__ __forceinline__ void stats_flush4(Stats4& a, double* __restrict__ stats, bool uniform, int n, int c, int ch) {
     if (stats == nullptr || !uniform) return;                       // block-uniform
-    __shared__ double red_stats[4][512];                            // [wave][channel][2], c <= 256
+    __shared__ double red_stats[2048];                              // [wave * slots + slot][channel][2]: 4 * slots * 2c <= 2048
     const int cv = c >> 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        for (int o = cv; o < 64; o <<= 1) {
-            a.s[j] += __shfl_xor(a.s[j], o, 64);
-            a.q[j] += __shfl_xor(a.q[j], o, 64);
-        }
+    for (int j = 0; j < 4; ++j) {
+        a.s[j] = row_strided_sum(a.s[j], cv);
+        a.q[j] = row_strided_sum(a.q[j], cv);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < cv) {                                                // lane == channel group (threads are laid out c-fastest)
+    const int slots = wave_slots(cv);
+    if (lane_holds_partial(lane, cv)) {                             // ch is this lane's first channel (threads are laid out c-fastest)
+        double* dst = red_stats + (size_t)(wave * slots + lane_slot(lane, cv)) * 2 * c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red_stats[wave][(ch + j) * 2] = a.s[j]; red_stats[wave][(ch + j) * 2 + 1] = a.q[j]; }
+        for (int j = 0; j < 4; ++j) { dst[(ch + j) * 2] = a.s[j]; dst[(ch + j) * 2 + 1] = a.q[j]; }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * c; i += 256) {
         double t = 0.0;
-        for (int w = 0; w < 4; ++w) t += red_stats[w][i];
+        for (int w = 0; w < 4 * slots; ++w) t += red_stats[(size_t)w * 2 * c + i];
         atomicAdd(stats + (size_t)n * c * 2 + i, t);
     }
 }

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, con
                                                                 const float* __restrict__ G, float* __restrict__ part,
                                                                 int i_relu, int g_relu) {
     constexpr int TAPS = KS * KS;
-    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][c4 groups][TAPS][4]
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves x row slots][c4 groups][TAPS][4]
     const int C = g.A, C4 = C >> 2;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;         // consecutive threads -> consecutive 16-byte pieces
     const int lanes = 256 / C4;                                     // pixel lanes per block
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, con
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = 0.f;
+    SENAS_PHASE(0);
     if (pl < lanes) {
         for (long p = p0 + pl; p < p1; p += lanes) {
             const int n = (int)(p / per_img), r = (int)(p % per_img);
@@ -340,29 +341,31 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, con
             }
         }
     }
-    // reduce over the pixel lanes that share c4 inside the wave: lanes differ by multiples of C4
+    SENAS_PHASE(1);
+    // fold the pixel lanes that share c4: inside a 16-lane row with DPP (VALU speed), the rows and the 4 waves through LDS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = acc[t][j];
-            for (int o = C4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-            acc[t][j] = v;
-        }
-    if (lane < C4) {
+        for (int j = 0; j < 4; ++j) acc[t][j] = row_strided_sum(acc[t][j], C4);
+    SENAS_PHASE(2);
+    const int slots = wave_slots(C4), nparts = 4 * slots;
+    if (lane_holds_partial(lane, C4)) {
+        float* dst = red + (size_t)((wave * slots + lane_slot(lane, C4)) * C4 + c4) * TAPS * 4;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[((wave * C4 + lane) * TAPS + t) * 4 + j] = acc[t][j];
+            for (int j = 0; j < 4; ++j) dst[t * 4 + j] = acc[t][j];
     }
     __syncthreads();
+    SENAS_PHASE(3);
     for (int i = threadIdx.x; i < C4 * TAPS * 4; i += 256) {
         const int j = i & 3, t = (i >> 2) % TAPS, cg = (i >> 2) / TAPS;
         float v = 0.f;
-        for (int w = 0; w < 4; ++w) v += red[((w * C4 + cg) * TAPS + t) * 4 + j];
+        for (int w = 0; w < nparts; ++w) v += red[((size_t)(w * C4 + cg) * TAPS + t) * 4 + j];
         part[((size_t)blockIdx.x * C + cg * 4 + j) * TAPS + t] = v;
     }
+    SENAS_PHASE(4);
 }
 
 // one wave per output element: lanes stride over the blocks' partials, fixed-order shuffle tree at the end
@@ -375,6 +378,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_sum_kernel(const float* __re
     v = wave_sum(v);
     if (lane == 0) dw[i] = v;
 }
+
+SENAS_PHASE_READER(conv)
 
 static bool geom_ok(const senas_conv_geom* g) {
     if (!g || g->n <= 0 || g->ci <= 0 || g->co <= 0 || g->kh <= 0 || g->kw <= 0) return false;
@@ -540,7 +545,8 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         SENAS_REQUIRE(g->ci <= 256, "depthwise wgrad: more than 256 channels");
         SENAS_REQUIRE(g->kh == g->kw && (g->kh == 3 || g->kh == 5), "depthwise wgrad: only 3x3 and 5x5 are on the path");
         const int c4 = g->ci / 4;
-        if (g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64 && ws != nullptr) {     // two-stage, atomic-free
+        if (g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64 && ws != nullptr &&
+            (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 16 <= 64 * 1024) {                         // two-stage, atomic-free
             // short chunks: the per-block loop (pixel lanes x taps of dependent loads) is the critical path of this
             // launch on every map size; 2 passes of the 256/c4 pixel lanes per block, at most 2048 partial rows
             const long lanes = 256 / c4;
@@ -549,7 +555,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
             wg.chunk = (int)((total + nblk - 1) / nblk);
             nblk = (total + wg.chunk - 1) / wg.chunk;
             float* part = reinterpret_cast<float*>(ws);
-            const size_t lds = (size_t)4 * c4 * taps * 4 * sizeof(float);
+            const size_t lds = (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 4 * sizeof(float);     // [waves x row slots][c4][taps][4]
             if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_kernel<3>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
             else hipLaunchKernelGGL((dwconv_wgrad_part_kernel<5>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
             const int n_elem = g->ci * taps;
@@ -602,7 +608,8 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
     if (which == 2) {
         if (g->groups != 1) {
             const int c4 = g->ci / 4;
-            const bool two_stage = g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64;
+            const bool two_stage = g->ci % 4 == 0 && (c4 & (c4 - 1)) == 0 && c4 <= 64 &&
+                                   (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * g->kh * g->kw * 16 <= 64 * 1024;
             if (two_stage) return g->kh == 3 ? "dwconv_wgrad_part_kernel<3>" : "dwconv_wgrad_part_kernel<5>";
             return g->kh == 3 ? "dwconv_wgrad_kernel<3>" : "dwconv_wgrad_kernel<5>";
         }

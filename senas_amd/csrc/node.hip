@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
                                                               const float* __restrict__ dy, int dys, const float* __restrict__ y,
                                                               const uint8_t* __restrict__ mask8, int relu, int do_p1,
                                                               double* __restrict__ p1, double* __restrict__ p2) {
-    extern __shared__ __attribute__((aligned(16))) double redv[];      // [4 waves][1 + TT][c]
+    extern __shared__ __attribute__((aligned(16))) double redv[];      // [4 waves x row slots][1 + TT][c]
     const int dq = dys >> 2;                                            // dy's pixel stride in 16-byte pieces (Q when dense)
     const int Q = c >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
     const int n = blockIdx.y;
@@ -434,23 +434,22 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
                 }
         }
     }
-    // fold: pixel lanes of the wave (stride Q), then the 4 waves
+    // fold: pixel lanes inside a 16-lane row with DPP, then the rows and the 4 waves through LDS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        for (int o = Q; o < 64; o <<= 1) a1[j] += __shfl_xor(a1[j], o, 64);
+        a1[j] = row_strided_sum(a1[j], Q);
 #pragma unroll
-        for (int t = 0; t < TT; ++t)
-            for (int o = Q; o < 64; o <<= 1) a2[t][j] += __shfl_xor(a2[t][j], o, 64);
+        for (int t = 0; t < TT; ++t) a2[t][j] = row_strided_sum(a2[t][j], Q);
     }
-    const int wl = Q < 64 ? Q : 64;                 // lanes of a wave that hold distinct channel groups
-    if (lane < wl) {
-        const int qq = q;                           // lane < Q: q == lane
+    const int slots = wave_slots(Q), nparts = 4 * slots;
+    if (lane_holds_partial(lane, Q)) {
+        double* dst = redv + (size_t)(wave * slots + lane_slot(lane, Q)) * (1 + TT) * c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            redv[((size_t)wave * (1 + TT)) * c + qq * 4 + j] = a1[j];
+            dst[q * 4 + j] = a1[j];
 #pragma unroll
-            for (int t = 0; t < TT; ++t) redv[((size_t)wave * (1 + TT) + 1 + t) * c + qq * 4 + j] = a2[t][j];
+            for (int t = 0; t < TT; ++t) dst[(size_t)(1 + t) * c + q * 4 + j] = a2[t][j];
         }
     }
     __syncthreads();
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
         if (k == 0 && !do_p1) continue;
         if (k > 0 && !(k - 1 < tt && z.p[t0 + k - 1] != nullptr)) continue;
         double v = 0.0;
-        for (int wv = 0; wv < 4; ++wv) v += redv[((size_t)wv * (1 + TT) + k) * c + ch];
+        for (int wv = 0; wv < nparts; ++wv) v += redv[((size_t)wv * (1 + TT) + k) * c + ch];
         if (k == 0) atomicAdd(p1 + (size_t)n * c + ch, v);
         else atomicAdd(p2 + ((size_t)(t0 + k - 1) * nimg + n) * c + ch, v);
     }
@@ -904,7 +903,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
             long chunk = per_iter * iters;
             if ((d.hw + chunk - 1) / chunk > 64) chunk = ((d.hw + 63) / 64 + per_iter - 1) / per_iter * per_iter;
             dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
-#define SENAS_RV(TT, UU) hipLaunchKernelGGL((node_reduce_vec_kernel<TT, UU>), rgrid, dim3(256), (size_t)4 * (1 + TT) * d.c * sizeof(double), st, \
+#define SENAS_RV(TT, UU) hipLaunchKernelGGL((node_reduce_vec_kernel<TT, UU>), rgrid, dim3(256), (size_t)4 * (Q <= 16 ? 4 : 64 / Q) * (1 + TT) * d.c * sizeof(double), st, \
                                              d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2)
             if (tt > 4) SENAS_RV(8, 1);
             else if (tt > 2) SENAS_RV(4, 2);

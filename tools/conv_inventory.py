@@ -25,10 +25,15 @@ def main():
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--search', action='store_true', help='the NAS supernet (batch 4 by default) instead of the derived net')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    net = SenasModel(2, 1, c=args.c, depth=args.depth, genotype=senas_node_4).to(dev)
+    if args.search:
+        from senas_amd.senas_search import NAS
+        net = NAS(1, args.c, 2, args.depth, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev).to(dev)
+    else:
+        net = SenasModel(2, 1, c=args.c, depth=args.depth, genotype=senas_node_4).to(dev)
     crit = SegmentationLosses('dice_ce')
     x = torch.randn(args.batch, 1, args.size, args.size, device=dev)
     y = torch.randint(0, 2, (args.batch, args.size, args.size), device=dev)

@@ -76,6 +76,15 @@ __device__ __forceinline__ T row_strided_sum(T v, int stride) {        // stride
     if (stride <= 1) v += dpp_mov<0x121>(v);     // row_ror:1
     return v;
 }
+// group_sum(v, q): sum over the aligned group of q consecutive lanes (q = 1, 2, 4, 8, 16), result in every lane of it
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int q) {                   // q is wave-uniform
+    if (q >= 2) v += dpp_mov<0xB1>(v);           // quad_perm [1,0,3,2]
+    if (q >= 4) v += dpp_mov<0x4E>(v);           // quad_perm [2,3,0,1]
+    if (q >= 8) v += dpp_mov<0x141>(v);          // row_half_mirror
+    if (q >= 16) v += dpp_mov<0x140>(v);         // row_mirror
+    return v;
+}
 // After row_strided_sum, the lanes of a wave that still hold distinct partial sums of the same residue class are one per
 // "slot": slot = lane / max(stride, 16); there are wave_slots(stride) of them (4 for stride <= 16, 2 for 32, 1 for 64).
 __device__ __forceinline__ int wave_slots(int stride) { return stride <= 16 ? 4 : 64 / stride; }

@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const fl
             }
         }
 #pragma unroll
-        for (int j = 0; j < CO; ++j)
-            for (int o = 1; o < Q; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+        for (int j = 0; j < CO; ++j) acc[j] = group_sum(acc[j], Q);          // Q <= 16: inside a 16-lane row, DPP
         if (live && q == 0) {
             float* op = out + ((size_t)n * hw + pix) * g.cout;
 #pragma unroll
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_n_kernel(WgradGeom g, const fl
                                                            const float* __restrict__ G, float* __restrict__ part,
                                                            int i_relu, int g_relu) {
     constexpr int TAPS = KS * KS;
-    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][Q][PER]
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves x row slots][Q][TAPS*4*BB]
     const int Q = g.A >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
     const int per_img = g.hg * g.wg;
     const long total = (long)g.n * per_img;
@@ -281,15 +280,17 @@ __global__ __launch_bounds__(256) void wgrad_thin_n_kernel(WgradGeom g, const fl
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slots = wave_slots(Q), nparts = 4 * slots;
+    const bool holder = lane_holds_partial(lane, Q);
+    float* dst = red + (size_t)((wave * slots + lane_slot(lane, Q)) * Q + q) * TAPS * 4 * BB;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < BB; ++j) {
-                float v = acc[t][i][j];
-                for (int o = Q; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-                if (lane < Q) red[((wave * Q + lane) * TAPS + t) * 4 * BB + i * BB + j] = v;
+                const float v = row_strided_sum(acc[t][i][j], Q);
+                if (holder) dst[t * 4 * BB + i * BB + j] = v;
             }
     __syncthreads();
     const int n_elem = g.B * g.A * TAPS;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_n_kernel(WgradGeom g, const fl
         const int t = e % TAPS, a = (e / TAPS) % g.A, b = e / (TAPS * g.A);
         const int qq = a >> 2, i = a & 3;
         float v = 0.f;
-        for (int wv = 0; wv < 4; ++wv) v += red[((wv * Q + qq) * TAPS + t) * 4 * BB + i * BB + b];
+        for (int wv = 0; wv < nparts; ++wv) v += red[((size_t)(wv * Q + qq) * TAPS + t) * 4 * BB + i * BB + b];
         part[(size_t)blockIdx.x * n_elem + e] = v;
     }
 }
@@ -318,7 +319,8 @@ int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part
     g.chunk = (int)((total + nblk - 1) / nblk);
     nblk = (total + g.chunk - 1) / g.chunk;
     const int bb = g.B <= 2 ? 2 : 4;
-    const size_t bytes = (size_t)4 * (g.A >> 2) * g.kh * g.kw * 4 * bb * sizeof(float);
+    const int q4 = g.A >> 2;
+    const size_t bytes = (size_t)4 * (q4 <= 16 ? 4 : 64 / q4) * q4 * g.kh * g.kw * 4 * bb * sizeof(float);
 #define SENAS_TW(KS, BB) hipLaunchKernelGGL((wgrad_thin_n_kernel<KS, BB>), dim3((unsigned)nblk), dim3(256), bytes, st, g, I, G, part, i_relu, g_relu)
     if (g.kh == 3) { if (bb == 2) SENAS_TW(3, 2); else SENAS_TW(3, 4); }
     else { if (bb == 2) SENAS_TW(1, 2); else SENAS_TW(1, 4); }

@@ -176,12 +176,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
                                                      double* __restrict__ stats, long total, int P) {
     // block b owns P chunks of 256 flat elements; P > 0 means the launcher guarantees the block lies inside one image,
     // so the batch-norm statistics are kept in registers and flushed once per block (common.h)
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // weights as [tap][C]: one 16-byte LDS read per tap
+    const int taps = g.kh * g.kw;
+    for (int i = threadIdx.x; i < taps * g.cout; i += 256) {
+        const int t = i / g.cout, cc = i - t * g.cout;
+        wl[i] = w[cc * taps + t];
+    }
+    __syncthreads();
     Stats4 acc_st;
     stats_init4(acc_st);
     const bool uniform = P > 0;
     const int chunks = uniform ? P : 1;
     const int cv = g.cout / V;
-    const int taps = g.kh * g.kw;
     int n_blk = 0, c_thr = 0;
     for (int kk = 0; kk < chunks; ++kk) {
         long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
@@ -203,12 +209,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
                 int ix;
                 if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
                 const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
-                float v[V];
+                float v[V], wt[V];
                 ldv<V>(ip, v);
+                ldv<V>(wl + (ky * g.kw + kx) * g.cout + c, wt);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float x = in_relu ? fmaxf(v[j], 0.f) : v[j];
-                    acc[j] = fmaf(x, w[(c + j) * taps + ky * g.kw + kx], acc[j]);
+                    acc[j] = fmaf(x, wt[j], acc[j]);
                 }
             }
         }
@@ -433,16 +440,17 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
     if (g->groups != 1) {
         const int V = (g->co % 4 == 0) ? 4 : 1;
+        const size_t dw_lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
         const long per_img = (long)g->ho * g->wo * (g->co / V);
         long total = per_img * g->n;
         const int P = (V == 4 && stats != nullptr) ? stats_chunks_per_block(per_img, g->co, total) : 0;
         dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))));
         if (g->transposed) {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
-            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
         } else {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
-            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, stats, total, P);
         }
         return launch_status("dwconv_fwd");
     }
@@ -487,14 +495,15 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
     if (g->groups != 1) {
         const int V = (g->ci % 4 == 0) ? 4 : 1;
+        const size_t dw_lds = (size_t)g->kh * g->kw * g->ci * sizeof(float);
         long total = (long)g->n * g->hi * g->wi * (g->ci / V);
         dim3 grid((unsigned)((total + 255) / 256));
         if (!g->transposed) {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
-            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<true, 4>), grid, dim3(256), dw_lds, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            else hipLaunchKernelGGL((dwconv_kernel<true, 1>), grid, dim3(256), dw_lds, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
         } else {
-            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
-            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), 0, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            if (V == 4) hipLaunchKernelGGL((dwconv_kernel<false, 4>), grid, dim3(256), dw_lds, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
+            else hipLaunchKernelGGL((dwconv_kernel<false, 1>), grid, dim3(256), dw_lds, st, gg, dy, w, dx, 0, mask, (double*)nullptr, total, 0);
         }
         return launch_status("dwconv_bwd_data");
     }

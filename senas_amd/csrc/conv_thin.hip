@@ -22,7 +22,7 @@ __device__ __forceinline__ float weight_at(const float* __restrict__ src, int d1
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// thin-K gather: cin <= 4, cout = 4*Q (Q a power of two <= 16).  thread = (pixel lane, 4 output channels).
+// thin-K gather: cin <= 8 (the supernet's 8 -> 8 inner edges included), cout = 4*Q (Q a power of two <= 16).  thread = (pixel lane, 4 output channels).
 // grid = (pixel chunks of one image, n); block 256; dynamic LDS = weights [taps*cin][cout] + fp64 [cout][2].
 template <bool TG>
 __global__ __launch_bounds__(256) void conv_thin_k_kernel(GatherGeom g, const float* __restrict__ in,
@@ -58,14 +58,21 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(GatherGeom g, const fl
                 if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
                 const float* ip = in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin;
                 const float* wt = lds + (ky * g.kw + kx) * g.cin * g.cout + q * 4;
-                for (int ci = 0; ci < g.cin; ++ci) {
-                    float v = ip[ci];
+                auto mac = [&](float v, int ci) {
                     if (in_relu) v = fmaxf(v, 0.f);
                     const float4 w4 = *reinterpret_cast<const float4*>(wt + ci * g.cout);
                     acc[0] = fmaf(v, w4.x, acc[0]);
                     acc[1] = fmaf(v, w4.y, acc[1]);
                     acc[2] = fmaf(v, w4.z, acc[2]);
                     acc[3] = fmaf(v, w4.w, acc[3]);
+                };
+                if ((g.cin & 3) == 0) {                    // 4 or 8 input channels: 16-byte loads
+                    for (int c4 = 0; c4 < g.cin; c4 += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(ip + c4);
+                        mac(v.x, c4); mac(v.y, c4 + 1); mac(v.z, c4 + 2); mac(v.w, c4 + 3);
+                    }
+                } else {
+                    for (int ci = 0; ci < g.cin; ++ci) mac(ip[ci], ci);
                 }
             }
         }
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(GatherGeom g, const fl
 
 bool thin_k_ok(const GatherGeom& g) {
     const int q = g.cout >> 2;
-    return g.cin <= 4 && g.cout % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin * g.cout <= 8192 &&
+    return g.cin <= 8 && g.cout % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin * g.cout <= 8192 &&
            (long)g.n * g.hout * g.wout * g.cout < 0x7fffffffL && g.n <= 65535;
 }
 

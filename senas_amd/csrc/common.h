@@ -217,6 +217,10 @@ int64_t thin_n_wgrad_ws_bytes(const WgradGeom& g);
 int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part, int i_relu, int g_relu, int* nblk_out,
                         hipStream_t st);
 
+bool wgrad_c8_ok(const WgradGeom& g);
+int64_t wgrad_c8_ws_bytes(const WgradGeom& g);
+int launch_wgrad_c8(WgradGeom g, const float* I, const float* G, float* part, int i_relu, int g_relu, int* nblk_out, hipStream_t st);
+
 // V consecutive floats (V == 4: one 16-byte access; the caller guarantees 16-byte alignment)
 template <int V>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[V]) {

@@ -426,6 +426,7 @@ extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* byt
     WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
                                   : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
     if (thin_n_wgrad_ok(wg)) { *bytes = thin_n_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
+    if (wgrad_c8_ok(wg)) { *bytes = wgrad_c8_ws_bytes(wg) + 256; return SENAS_OK; }
     if (!g->transposed && lds_wgrad_ok(wg)) { *bytes = lds_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (mfma_wgrad_ok(wg)) *needs_zero = 1;                        // split-K image accumulated with atomics
     return SENAS_OK;
@@ -591,6 +592,16 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
                            n_elem, nblk);
         return launch_status("wgrad_thin_n sum");
     }
+    if (wgrad_c8_ok(wg)) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        int nblk = 0;
+        const int rc = launch_wgrad_c8(wg, I, G, reinterpret_cast<float*>(ws), i_relu, g_relu, &nblk, st);
+        if (rc != SENAS_OK) return rc;
+        const int n_elem = g->ci * g->co * taps;
+        hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw,
+                           n_elem, nblk);
+        return launch_status("wgrad_c8 sum");
+    }
     if (!g->transposed && lds_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         return launch_lds_wgrad(wg, I, G, reinterpret_cast<float*>(ws), dw, i_relu, st);      // ws need not be zero here
@@ -628,6 +639,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
             if (g->kh == 3) return wg.B <= 2 ? "wgrad_thin_n_kernel<3, 2>" : "wgrad_thin_n_kernel<3, 4>";
             return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";
         }
+        if (wgrad_c8_ok(wg)) return "wgrad_c8_kernel";
         if (!tr && lds_wgrad_ok(wg)) {
             static char buf[8][48];
             static int slot = 0;

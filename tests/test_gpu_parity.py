@@ -371,6 +371,11 @@ _CONV_CASES = [
     (8, 128, 32, 16, 16, 3, 1, 1, False, True),     # ShrinkBlock shape on a 16x16 map (narrow LDS weight gradient, 36 units)
     (8, 128, 32, 8, 8, 3, 1, 1, False, False),      # ... and on 8x8
     (2, 32, 32, 8, 8, 1, 1, 1, False, True),        # narrow 1x1 weight gradient
+    (2, 8, 8, 24, 24, 1, 1, 1, False, True),        # 8 -> 8 (supernet inner edge): thin-K gather both ways, c8 weight gradient
+    (2, 8, 8, 16, 16, 3, 2, 1, False, False),       # ... stride 2
+    (2, 8, 8, 12, 12, 3, 2, 1, True, False),        # ... transposed
+    (2, 4, 8, 16, 16, 3, 1, 1, False, False),       # 4 input channels
+    (2, 8, 5, 16, 16, 3, 1, 1, False, True),        # 5 output channels (zero-padded columns in the c8 weight gradient)
 ]
 
 

@@ -210,6 +210,7 @@ template <bool TG>
 int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   const float* mask, double* stats, hipStream_t st);
 bool thin_n_ok(const GatherGeom& g);
+template <bool TG>
 int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   double* stats, hipStream_t st);
 bool thin_n_wgrad_ok(const WgradGeom& g);

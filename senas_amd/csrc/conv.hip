@@ -460,7 +460,12 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
         if (!g->transposed) return launch_thin_k<false>(gg, x, w, g->ci, 1, y, in_relu, nullptr, stats, st);
         return launch_thin_k<true>(gg, x, w, g->co, 0, y, in_relu, nullptr, stats, st);
     }
-    if (!g->transposed && thin_n_ok(gg)) return launch_thin_n(gg, x, w, g->ci, 1, y, in_relu, stats, st);
+    // 5..8 outputs: only where the alternative is the direct-global MFMA kernel (strided / transposed); the LDS window
+    // kernel is faster on stride-1 shapes even at 1/4 tile occupancy (measured on the supernet step)
+    if (thin_n_ok(gg) && (gg.cout <= 4 || g->transposed || !lds_gather_ok(gg))) {
+        if (!g->transposed) return launch_thin_n<false>(gg, x, w, g->ci, 1, y, in_relu, stats, st);
+        return launch_thin_n<true>(gg, x, w, g->co, 0, y, in_relu, stats, st);
+    }
     SENAS_REQUIRE(ws, "conv2d_fwd: null workspace");
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
@@ -659,7 +664,13 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
                                : GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
     const bool tg = (which == 0) == tr;                 // transposed gather: ConvTranspose2d forward, Conv2d data gradient
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
-    if (which == 0 && !tr && thin_n_ok(gg)) return gg.cout <= 2 ? "conv_thin_n_kernel<2>" : "conv_thin_n_kernel<4>";
+    if (which == 0 && thin_n_ok(gg) && (gg.cout <= 4 || tr || !lds_gather_ok(gg))) {
+        static char buf[8][48];
+        static int slot = 0;
+        char* b = buf[slot++ & 7];
+        snprintf(b, 48, "conv_thin_n_kernel<%d, %s>", gg.cout <= 2 ? 2 : (gg.cout <= 4 ? 4 : 8), tr ? "true" : "false");
+        return b;
+    }
     if (!tr && lds_gather_ok(gg)) {
         static char buf[8][64];
         static int slot = 0;

@@ -132,9 +132,9 @@ template int launch_thin_k<false>(const GatherGeom&, const float*, const float*,
 template int launch_thin_k<true>(const GatherGeom&, const float*, const float*, int, int, float*, int, const float*, double*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
-// thin-N gather (plain): cout <= CO (2 or 4), cin = 4*Q (Q a power of two <= 16).
-// thread = (pixel lane, 4 input channels); the Q partial sums of a pixel are folded by shuffles.
-template <int CO>
+// thin-N gather: cout <= CO (2, 4 or 8), cin = 4*Q (Q a power of two <= 16); TG: transposed gather (ConvTranspose2d
+// forward).  thread = (pixel lane, 4 input channels); the Q partial sums of a pixel are folded by DPP group sums.
+template <int CO, bool TG>
 __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const float* __restrict__ in,
                                                           const float* __restrict__ w, int d1, int swap,
                                                           float* __restrict__ out, int in_relu, double* __restrict__ stats,
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const fl
         for (int j = 0; j < CO; ++j) acc[j] = 0.f;
         for (int ky = 0; ky < g.kh; ++ky) {
             int iy;
-            if (!tap_src<false>(g, oy, ky, g.hin, iy)) continue;
+            if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
             for (int kx = 0; kx < g.kw; ++kx) {
                 int ix;
-                if (!tap_src<false>(g, ox, kx, g.win, ix)) continue;
+                if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
                 float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + q * 4);
                 if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 const float* wt = lds + ((ky * g.kw + kx) * g.cin + q * 4) * CO;
@@ -197,12 +197,14 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const fl
         }
     }
     if (stats != nullptr) {
+        // only the q == 0 lanes hold values and they are congruent modulo Q: a strided row sum puts each 16-lane row's
+        // total in its first lane (DPP, no shuffles); the 16 row totals of the block meet in LDS
 #pragma unroll
         for (int j = 0; j < CO; ++j) {
-            s[j] = wave_sum(s[j]);              // lanes with q != 0 hold zeros
-            ss[j] = wave_sum(ss[j]);
+            s[j] = row_strided_sum(s[j], Q);
+            ss[j] = row_strided_sum(ss[j], Q);
         }
-        if ((threadIdx.x & 63) == 0) {
+        if ((threadIdx.x & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < CO; ++j) {
                 atomicAdd(&sred[j * 2], s[j]);
@@ -216,22 +218,26 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const fl
 
 bool thin_n_ok(const GatherGeom& g) {
     const int q = g.cin >> 2;
-    return g.cout <= 4 && g.cin % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin <= 2048 &&
+    return g.cout <= 8 && g.cin % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin <= 2048 &&
            (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL && g.n <= 65535;
 }
 
+template <bool TG>
 int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   double* stats, hipStream_t st) {
     const int ppb = 256 / (g.cin >> 2), hw = g.hout * g.wout;
     int passes = 8;
     while (passes > 1 && (long)g.n * ((hw + ppb * passes - 1) / (ppb * passes)) < 1024) passes >>= 1;
     dim3 grid((hw + ppb * passes - 1) / (ppb * passes), g.n);
-    const int co = g.cout <= 2 ? 2 : 4;
+    const int co = g.cout <= 2 ? 2 : (g.cout <= 4 ? 4 : 8);
     const size_t bytes = (size_t)((g.kh * g.kw * g.cin * co + 3) & ~3) * sizeof(float) + (size_t)2 * co * sizeof(double);
-    if (co == 2) hipLaunchKernelGGL((conv_thin_n_kernel<2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
-    else hipLaunchKernelGGL((conv_thin_n_kernel<4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+    if (co == 2) hipLaunchKernelGGL((conv_thin_n_kernel<2, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+    else if (co == 4) hipLaunchKernelGGL((conv_thin_n_kernel<4, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+    else hipLaunchKernelGGL((conv_thin_n_kernel<8, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
     return launch_status("conv_thin_n");
 }
+template int launch_thin_n<false>(const GatherGeom&, const float*, const float*, int, int, float*, int, double*, hipStream_t);
+template int launch_thin_n<true>(const GatherGeom&, const float*, const float*, int, int, float*, int, double*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // thin-N weight gradient: B <= BB (2 or 4) gradient channels, A = 4*Q fat channels, KS x KS taps.

@@ -284,19 +284,66 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
     // ---- epilogue: lane = output channel, register v = pixel (row MT*wave + m, column acc_row(v, h))
     const bool cok = co < g.cout;
     double s = 0.0, q = 0.0;
+    if ((g.cout & 31) == 0) {
+        // full 32-channel tile: transpose each wave's sub-tiles through LDS ([pixel][36 floats]: rows stay 16-byte aligned,
+        // 4-float pad against bank conflicts) so that a lane stores 16 contiguous bytes -- 4x fewer, fully coalesced
+        // store (and mask load) instructions than one dword per (pixel, channel)
+        if (stats != nullptr && kg == 0) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int pq = acc_row(v, h);                // pixel of the MFMA row this register holds
-            const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
-            float val = acc[m][v];
-            if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
-                const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
-                if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
-                out[o] = val;
-                s += val;
-                q += (double)val * val;
+                for (int v = 0; v < 16; ++v) {
+                    const int pq = acc_row(v, h);
+                    const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
+                    if (oy < g.hout && ox < g.wout) { s += acc[m][v]; q += (double)acc[m][v] * acc[m][v]; }
+                }
+        }
+        __syncthreads();                                 // the window (or the fold scratch) is dead
+        float* tp = lds + (size_t)wave * MT * 32 * 36;
+        if (kg == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) tp[(m * 32 + acc_row(v, h)) * 36 + r] = acc[m][v];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            const int prow = lane >> 3, c4 = lane & 7;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pq = k * 8 + prow;
+                    const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
+                    if (oy < g.hout && ox < g.wout) {
+                        float4 val = *reinterpret_cast<const float4*>(tp + (m * 32 + pq) * 36 + c4 * 4);
+                        const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + cot * 32 + c4 * 4;
+                        if (mask != nullptr) {
+                            const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+                            if (!(mk.x > 0.f)) val.x = 0.f;
+                            if (!(mk.y > 0.f)) val.y = 0.f;
+                            if (!(mk.z > 0.f)) val.z = 0.f;
+                            if (!(mk.w > 0.f)) val.w = 0.f;
+                        }
+                        *reinterpret_cast<float4*>(out + o) = val;
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int pq = acc_row(v, h);                // pixel of the MFMA row this register holds
+                const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
+                float val = acc[m][v];
+                if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
+                    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
+                    if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
+                    out[o] = val;
+                    s += val;
+                    q += (double)val * val;
+                }
             }
         }
     }
@@ -335,6 +382,8 @@ static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int k
     size_t bytes = (size_t)(th + 2 * g.pad) * (twl + 2 * g.pad) * PST * sizeof(float);
     const size_t fold = ks > 1 ? (size_t)(ks / 2) * rw * mt * 4096 : 0;
     if (bytes < 4 * 32 * 2 * sizeof(double)) bytes = 4 * 32 * 2 * sizeof(double);      // statistics scratch
+    const size_t tr = (size_t)rw * mt * 32 * 36 * sizeof(float);                      // epilogue transpose
+    if (bytes < tr) bytes = tr;
     return fold > bytes ? fold : bytes;
 }
 

@@ -7,16 +7,19 @@
 // 64-byte runs (ReLU applied on the way in, borders zero-filled so the tap loop has no bounds
 // checks), and all k*k taps read their A fragments from LDS with conflict-free ds_read_b128.
 //
-// Tile: TH x 32 output pixels per 256-thread block, TH = 4*MT; wave w owns rows MT*w .. MT*w+MT-1 (MT
+// Tile (big maps): TH x 32 output pixels per 256-thread block, TH = 4*MT; wave w owns rows MT*w .. MT*w+MT-1 (MT
 // 32-pixel MFMA sub-tiles).  MT = 2 for maps that fill the chip, MT = 1 when that would leave CUs idle
 // (twice the blocks, half the critical path).  Channels go through LDS 16 at a time (pixel stride 80 B =
 // 64 B data + 16 B pad: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots), so the
-// window costs 880 px * 80 B = 69 KiB for 5x5 dilation 3 at MT = 2 -- two blocks per CU, one loading
-// while the other computes.  B fragments (weights) stream from the packed image in L2.
+// window costs 880 px * 80 B = 69 KiB for 5x5 dilation 3 at MT = 2 -- two blocks per CU (three at dilation 2), one
+// loading or storing while the others compute: measured 71-81 % of the fp32-MFMA peak at 256x256.
+// B fragments (weights) stream from the packed image in L2.
 //
-// KS > 1 (small maps): the block grows to 4*KS waves; wave (rw, kg) works on tile row rw and the taps kg, kg + KS, ...
-// -- the per-block tap loop, which is the whole critical path when a launch has fewer tiles than the chip has CUs,
-// gets KS times shorter; the KS partial accumulators meet in LDS (pairwise fold) before the epilogue.
+// Small maps (template parameters KS, RW, TWL; lds_gather_shape picks them): the taps of a tile are dealt to KS
+// groups of waves whose partial accumulators meet in LDS; when even 4-row tiles cannot give every CU a block the
+// block shrinks to ONE 32-pixel MFMA row with its taps on 4 waves (one per SIMD); maps 16 or 8 pixels wide fold 2 or
+// 4 image rows into that MFMA row.  Those variants keep their weight fragments in registers (requested before the
+// window is staged).  Epilogue: full 32-channel tiles are transposed through LDS and stored 16 bytes per lane.
 #include "common.h"
 
 namespace senas {

@@ -3,14 +3,19 @@
 //   dW[tap][a][b] = sum over pixels p of  X[p + off(tap)][a] * G[p][b]        (a: in-channel, b: out-channel)
 //
 // GEMM view per tap: M = 32 in-channels, N = 32 out-channels, K = pixels; v_mfma_f32_32x32x2_f32 eats two
-// pixels per instruction.  A block (8 waves) walks 8x32 (or 4x32) pixel tiles persistently:
+// pixels per instruction.  A block (8 waves) walks 8x32 (or 4x32 / 2x32; 16- and 8-wide on narrow maps) pixel tiles
+// persistently:
 //   - the X window (tile + halo, zero-filled borders, ReLU on load) and the G tile go to LDS once per tile,
-//     so the k*k taps re-read X from LDS instead of L1 and the tap loop has no bounds checks at all;
-//   - the work units (tap, 32-channel slice of a) are dealt round-robin to the 8 waves; each wave keeps one
-//     32x32 accumulator per unit in registers ACROSS tiles and adds it to the result once, at the end --
-//     atomic traffic is (units x 4 KiB) per block instead of per 128 pixels.
+//     so the k*k taps re-read X from LDS instead of L1 and the tap loop has no bounds checks at all; the NEXT tile
+//     is requested into registers before the K loop of the current one, so staging hides behind the MFMAs;
+//   - the work units (tap, 32-channel slice of a) are dealt to the 8 waves as Q full units + REM row-shared units
+//     (perfect balance for any unit count); each wave keeps one 32x32 accumulator per unit in registers ACROSS
+//     tiles and writes it out once, at the end, into this block's slice of a partial image -- no atomics; the
+//     second launch adds the blocks' slices in a fixed order while transposing to the torch layout;
+//   - the K loop is straight-line ds_read2 + MFMA code (no wave-uniform branches inside);
 //   - K order inside a 32-pixel row is permuted (lane half h takes pixels 16h .. 16h+15) so that both
 //     operands advance by one pixel per MFMA with compile-time LDS offsets.
+// Measured: ~130 TFLOP/s (83 % of the fp32-MFMA peak) on 8x32->32x256x256 5x5 (was 92 with atomics and branches).
 #include "common.h"
 
 namespace senas {

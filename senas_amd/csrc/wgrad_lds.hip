@@ -15,7 +15,8 @@
 //   - the K loop is straight-line ds_read2 + MFMA code (no wave-uniform branches inside);
 //   - K order inside a 32-pixel row is permuted (lane half h takes pixels 16h .. 16h+15) so that both
 //     operands advance by one pixel per MFMA with compile-time LDS offsets.
-// Measured: ~130 TFLOP/s (83 % of the fp32-MFMA peak) on 8x32->32x256x256 5x5 (was 92 with atomics and branches).
+// Measured (tools/conv_bench.py, sum launch included): 114-122 TFLOP/s = 73-78 % of the fp32-MFMA peak on
+// 8x32->32x256x256 5x5 (was 92 with atomics, unbalanced units and branches in the K loop).
 #include "common.h"
 
 namespace senas {

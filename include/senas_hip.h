@@ -192,6 +192,10 @@ int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const flo
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
                    float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
 
+/* out = sum of n dense fp32 tensors of numel elements (n <= SENAS_MAX_TERMS, 16-byte aligned): the gradient of a
+ * tensor with n consumers (a cell state feeding several edges) in one pass instead of n-1 binary accumulations.  */
+int senas_sum_n(int n, int64_t numel, const float* const* srcs, float* out, void* stream);
+
 /* ---- loss and metric ------------------------------------------------
  * DiceCrossEntropyLoss (utils/loss/loss.py:45-70,124-228): w_ce * CrossEntropy(mean over pixels) +
  * w_dice * (1 - mean over classes [1:] (or [0:] with do_bg) of (2 tp + smooth) / (2 tp + fp + fn + smooth + 1e-8))

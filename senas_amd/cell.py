@@ -26,7 +26,9 @@ class MixedOp(nn.Module):
         return alpha_normal if self._op_type == OpType.NORM else alpha_up_dn
 
     def terms(self, x):
-        return [op.raw(x) for op in self._ops]
+        """x: the edge's input, or one alias of it per candidate (functional.fan_out)."""
+        xs = x if isinstance(x, (list, tuple)) else [x] * len(self._ops)
+        return [op.raw(xi) for op, xi in zip(self._ops, xs)]
 
     def forward(self, x, alpha_normal, alpha_up_dn):
         return F.bn_combine(self.terms(x), mix=self.pick(alpha_normal, alpha_up_dn))
@@ -80,13 +82,30 @@ class Cell(nn.Module):
         return cache[key]
 
     def forward(self, in0, in1, weights_norm, weights_chg, betas):
-        states = [self.preprocess0(in0), self.preprocess1(in1)]
         mixes = self._node_mixes(weights_norm, weights_chg, betas)
+        # a state feeds every candidate of every outgoing edge (18 consumers for the two cell inputs): hand each
+        # consumer its own alias, so the gradients meet in ONE n-ary sum instead of n-1 autograd accumulations
+        nodes, nin = self._meta_node_num, self._input_num
+        uses = [0] * (nin + nodes)
         offset = 0
-        for i in range(self._meta_node_num):
+        for i in range(nodes):
+            for j in range(nin + i):
+                uses[j] += len(self._ops[offset + j]._ops)
+            offset += nin + i
+        states = []
+
+        def add_state(h):
+            k = len(states)
+            states.append(iter(F.fan_out(h, uses[k] + (1 if k >= nin else 0))))
+
+        add_state(self.preprocess0(in0))
+        add_state(self.preprocess1(in1))
+        offset = 0
+        for i in range(nodes):
             terms = []
-            for j, h in enumerate(states):
-                terms += self._ops[offset + j].terms(h)
-            offset += len(states)
-            states.append(F.bn_combine(terms, mix=mixes[i], relu=True))
-        return self.post_process(torch.cat(states[-self._meta_node_num:], dim=1))
+            for j in range(nin + i):
+                edge = self._ops[offset + j]
+                terms += edge.terms([next(states[j]) for _ in edge._ops])
+            offset += nin + i
+            add_state(F.bn_combine(terms, mix=mixes[i], relu=True))
+        return self.post_process(torch.cat([next(states[nin + i]) for i in range(nodes)], dim=1))

@@ -230,6 +230,29 @@ static long reduce_chunk(long hw, int n) {
     return chunk;
 }
 
+// ---------------------------------------------------------------------------------------------
+// out = sum of n tensors (n <= SENAS_MAX_TERMS): the gradient of a tensor with n consumers in ONE pass, instead of
+// autograd's n-1 binary accumulations (each a read-read-write pass).
+struct SumTable {
+    const float* p[SENAS_MAX_TERMS];
+};
+__global__ __launch_bounds__(256) void sum_n_kernel(SumTable t, int n, long n4, long numel, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(t.p[0])[i];
+        for (int k = 1; k < n; ++k) {
+            const float4 b = reinterpret_cast<const float4*>(t.p[k])[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) {          // tail (numel % 4 floats)
+        const long i = (numel & ~3L) + threadIdx.x;
+        float a = t.p[0][i];
+        for (int k = 1; k < n; ++k) a += t.p[k][i];
+        out[i] = a;
+    }
+}
+
 }  // namespace senas
 
 using namespace senas;
@@ -321,4 +344,20 @@ extern "C" int senas_combine_bwd_apply(int n, int64_t hw, int c, int nterms, con
     if (V == 4) hipLaunchKernelGGL((combine_bwd_apply_kernel<4>), grid, dim3(256), 0, as_stream(stream), (long)hw, c, nterms, n, tab, dy, y, relu, a, b, k, out, ds_out);
     else hipLaunchKernelGGL((combine_bwd_apply_kernel<1>), grid, dim3(256), 0, as_stream(stream), (long)hw, c, nterms, n, tab, dy, y, relu, a, b, k, out, ds_out);
     return launch_status("combine_bwd_apply");
+}
+
+extern "C" int senas_sum_n(int n, int64_t numel, const float* const* srcs, float* out, void* stream) {
+    SENAS_REQUIRE(n >= 1 && n <= SENAS_MAX_TERMS && numel > 0 && srcs && out, "sum_n: bad argument");
+    senas::SumTable t{};
+    for (int k = 0; k < n; ++k) {
+        SENAS_REQUIRE(srcs[k] && (reinterpret_cast<uintptr_t>(srcs[k]) & 15) == 0, "sum_n: null or misaligned source");
+        t.p[k] = srcs[k];
+    }
+    SENAS_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "sum_n: misaligned destination");
+    const long n4 = numel >> 2;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(senas::sum_n_kernel, dim3((unsigned)blocks), dim3(256), 0, senas::as_stream(stream), t, n, n4, (long)numel, out);
+    return senas::launch_status("sum_n");
 }

@@ -333,6 +333,44 @@ def relu(x):
     return _ReLU.apply(x)
 
 
+class _FanOut(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward pass adds the incoming gradients in ONE launch (senas_sum_n)
+    instead of leaving n-1 binary accumulations to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        ref = gs[0]
+        dense = [g for g in gs if g.is_cuda and g.dtype == torch.float32 and g.stride() == ref.stride() and
+                 (g.is_contiguous(memory_format=CL) or g.is_contiguous()) and g.data_ptr() % 16 == 0]
+        rest = [g for g in gs if not any(g is d for d in dense)]
+        out = None
+        while dense:
+            take = _lib.MAX_TERMS - (1 if out is not None else 0)
+            chunk, dense = ([out] if out is not None else []) + dense[:take], dense[take:]
+            dst = torch.empty_like(ref)
+            ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
+            _lib.check(_lib.lib().senas_sum_n(len(chunk), ref.numel(), ptrs, dst.data_ptr(), _stream()), 'senas_sum_n')
+            out = dst
+        for g in rest:                                    # odd layouts (e.g. a strided slice): let torch add them
+            out = g if out is None else out + g
+        return out, None
+
+
+def fan_out(x, n):
+    """n aliases of x (n > 1), or [x]."""
+    return list(_FanOut.apply(x, n)) if n > 1 else [x]
+
+
 def chan_stats(z):
     """Per-image per-channel (sum, sum of squares) of an NHWC tensor, fp64 [n][c][2]."""
     z = nhwc(z)

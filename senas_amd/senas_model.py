@@ -44,11 +44,21 @@ class BuildCell(nn.Module):
             for name, idx in gene)
 
     def forward(self, in0, in1):
-        states = [self.preprocess0(in0), self.preprocess1(in1)]
+        # every consumer of a state (ops reading it, the output concat) gets its own alias, so that the state's
+        # gradient is ONE n-ary sum (functional.fan_out) instead of n-1 autograd accumulations
+        total = self._input_num + self._num_meta_node
+        uses = [sum(1 for idx in self._indices if idx == k) + (1 if k in self._concat else 0) for k in range(total)]
+        states = []
+
+        def add_state(h):
+            states.append(iter(F.fan_out(h, uses[len(states)])))
+
+        add_state(self.preprocess0(in0))
+        add_state(self.preprocess1(in1))
         for i in range(self._num_meta_node):
-            pair = [self._ops[e].raw(states[self._indices[e]]) for e in (2 * i, 2 * i + 1)]
-            states.append(F.bn_combine(pair, relu=True))           # ReLU(op_a(.) + op_b(.)) in one pass
-        return self.post_process(torch.cat([states[i] for i in self._concat], dim=1))
+            pair = [self._ops[e].raw(next(states[self._indices[e]])) for e in (2 * i, 2 * i + 1)]
+            add_state(F.bn_combine(pair, relu=True))               # ReLU(op_a(.) + op_b(.)) in one pass
+        return self.post_process(torch.cat([next(states[i]) for i in self._concat], dim=1))
 
 
 class Head(nn.Module):

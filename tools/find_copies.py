@@ -15,7 +15,11 @@ from senas_amd.senas_model import SenasModel  # noqa: E402
 
 def main():
     dev = torch.device('cuda:0')
-    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4).to(dev)
+    if len(sys.argv) > 1 and sys.argv[1] == '--search':
+        from senas_amd.senas_search import NAS
+        net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev).to(dev)
+    else:
+        net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4).to(dev)
     crit = SegmentationLosses('dice_ce')
     x = torch.randn(2, 1, 64, 64, device=dev)
     y = torch.randint(0, 2, (2, 64, 64), device=dev)
@@ -54,7 +58,7 @@ def main():
     torch.Tensor.copy_, torch.Tensor.clone, torch.Tensor.contiguous = orig_copy, orig_clone, orig_contig
     for k, v in sites.most_common(30):
         print('%4d  %s' % (v, k))
-    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=70))
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=70, max_name_column_width=70))
 
 
 if __name__ == '__main__':

@@ -376,6 +376,11 @@ _CONV_CASES = [
     (2, 8, 8, 12, 12, 3, 2, 1, True, False),        # ... transposed
     (2, 4, 8, 16, 16, 3, 1, 1, False, False),       # 4 input channels
     (2, 8, 5, 16, 16, 3, 1, 1, False, True),        # 5 output channels (zero-padded columns in the c8 weight gradient)
+    (4, 32, 8, 16, 16, 5, 1, 2, False, False),      # full-width supernet candidate on a 16x16 map: narrow LDS kernels, 8 outputs
+    (4, 32, 8, 16, 16, 1, 1, 1, False, True),       # ... its 1x1 adapter
+    (4, 32, 8, 8, 8, 3, 1, 1, False, False),        # ... on 8x8
+    (2, 32, 8, 32, 32, 5, 2, 3, False, False),      # stride-2 candidate with 8 outputs (thin-N gather forward)
+    (2, 32, 8, 16, 16, 5, 2, 2, True, False),       # transposed candidate with 8 outputs
 ]
 
 

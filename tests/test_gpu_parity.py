@@ -308,6 +308,45 @@ def test_derived_full_width_vs_oracle():
         assert err <= 1e-2, 'grad %s: L2 rel err %.2e' % (k, err)
 
 
+def test_supernet_full_width_vs_oracle():
+    """The supernet at its real width (c=32: 32 -> 8 candidates, 8 -> 8 inner edges, 1x1 adapters, 24 -> 32 cell outputs),
+    depth 3, 2x1x64x64: forward + backward + architecture gradients vs the CPU oracle."""
+    from oracle import senas_ref as R
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    kw = dict(input_c=1, c=32, num_classes=2, depth=3, meta_node_num=3)
+    net = NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+    _randomize(net, 9)
+    with torch.no_grad():
+        for p in net.arch_parameters():
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.5)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    gio.share_stem(sd, 'net.')
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 1, 64, 64, generator=gen)
+    y = torch.randint(0, 2, (2, 64, 64), generator=gen)
+    ref = R.nas_forward(sd, x, depth=3, nodes=3)[-1]
+    ref_loss = R.dice_ce_loss(ref, y)
+    ref_loss.backward()
+    net = net.to(dev()).train()
+    out = net(x.to(dev()))
+    loss = SegmentationLosses('dice_ce')(out, y.to(dev()))
+    loss.backward()
+    close(out[-1], ref.detach().numpy(), 'logits', rel=1e-3)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+    got = grads_of(net)
+    for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'net.stem0.0.weight'):
+        e = sd[k].grad.numpy().astype(np.float64)
+        err = float(np.sqrt(((got[k] - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
+        assert err <= 1e-2, 'grad %s: L2 rel err %.2e' % (k, err)
+    ref_geno = R.derive_genotype(sd, depth=3, nodes=3)
+    got_geno = net.genotype()
+    assert (list(got_geno.down), list(got_geno.up), list(got_geno.gamma)) == (list(ref_geno.down), list(ref_geno.up), list(ref_geno.gamma))
+
+
 def test_linearity_and_shapes_at_baseline_size():
     """Size-independent properties at BASELINE's full size (8x1x256x256, c=32): the convolution kernels
     are linear in x (conv(a*x1 + x2) == a*conv(x1) + conv(x2)) and a train-mode step leaves finite

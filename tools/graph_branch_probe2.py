@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cost of many fork/join regions inside one captured HIP graph: R regions x W branches x L spin kernels."""
+"""Cost of many fork/join regions inside one captured HIP graph: R regions x W branches x L spin kernels.
+(On ROCm 7.2 building a fifth graph of 16 regions x 4 x 8 in the same process segfaulted; left out.)"""
 import time
 
 import torch
@@ -40,7 +41,7 @@ def timeit(g, reps=20):
 if __name__ == '__main__':
     torch.zeros(1, device='cuda')
     for cycles in (5000, 20000, 100000):
-        for regions, width, length in ((64, 1, 8), (64, 2, 4), (64, 4, 2), (64, 8, 1), (16, 4, 8), (256, 2, 1), (256, 1, 2)):
+        for regions, width, length in ((64, 1, 8), (64, 2, 4), (64, 4, 2), (64, 8, 1)):
             t = timeit(build(regions, width, length, cycles))
             print('spin %6d  regions %3d x width %d x length %d (%4d kernels): graph %.3f ms  -> %.2f us per kernel' %
                   (cycles, regions, width, length, regions * width * length, t, t * 1e3 / (regions * width * length)), flush=True)

@@ -427,7 +427,7 @@ extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* byt
                                   : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
     if (thin_n_wgrad_ok(wg)) { *bytes = thin_n_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (wgrad_c8_ok(wg)) { *bytes = wgrad_c8_ws_bytes(wg) + 256; return SENAS_OK; }
-    if (!g->transposed && lds_wgrad_ok(wg)) { *bytes = lds_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
+    if (lds_wgrad_ok(wg)) { *bytes = lds_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }      // (a superset of the launcher's condition)
     if (mfma_wgrad_ok(wg)) *needs_zero = 1;                        // split-K image accumulated with atomics
     return SENAS_OK;
 }
@@ -607,7 +607,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
                            n_elem, nblk);
         return launch_status("wgrad_c8 sum");
     }
-    if (!g->transposed && lds_wgrad_ok(wg)) {
+    if (lds_wgrad_ok(wg) && !g_relu) {        // ConvTranspose2d: I = dy on the fine grid; a ReLU on the coarse operand is not in the kernel
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         return launch_lds_wgrad(wg, I, G, reinterpret_cast<float*>(ws), dw, i_relu, st);      // ws need not be zero here
     }
@@ -645,7 +645,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
             return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";
         }
         if (wgrad_c8_ok(wg)) return "wgrad_c8_kernel";
-        if (!tr && lds_wgrad_ok(wg)) {
+        if (lds_wgrad_ok(wg)) {
             static char buf[8][48];
             static int slot = 0;
             char* b = buf[slot++ & 7];

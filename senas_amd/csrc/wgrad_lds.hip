@@ -48,7 +48,9 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // dynamic LDS: X window [(th + 2*halo) * (32 + 2*halo)][A] floats, then G tile [th * 32][32] floats.
 // TWL: tile width in pixels (32, 16, 8): the 32 K-pixels of an MFMA row are 32/TWL image rows of TWL columns, so
 // 16x16 and 8x8 maps run here too; `th` counts MFMA rows (th * 32/TWL image rows per tile).
-template <int A, int Q, int REM, int PFX, int TWL>
+// S: stride of the convolution (1, or 2: X lives on the fine grid, G on the coarse one -- Conv2d stride 2 and
+// ConvTranspose2d stride 2 alike); the tile is laid out over G, the X window covers S times as many rows and columns.
+template <int A, int Q, int REM, int PFX, int TWL, int S>
 __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float* __restrict__ X,
                                                         const float* __restrict__ G, float* __restrict__ part,
                                                         int x_relu, int th, int tiles_x, int tiles_y) {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
     const int r = lane & 31, h = lane >> 5;
     const int halo = g.pad;
-    const int tile_w = TWL + 2 * halo, tile_h = th * RPM + 2 * halo;
+    const int tile_w = S * TWL + 2 * halo, tile_h = S * th * RPM + 2 * halo;
     float* xs = lds;
     float* gs = lds + tile_h * tile_w * A;
     float4* xs4 = reinterpret_cast<float4*>(xs);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         int ty = ty0, tx = tx0;
 #pragma unroll
         for (int k = 0; k < PFX; ++k) {
-            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const int iy = S * oy0 - halo + ty, ix = S * ox0 - halo + tx;
             const bool inb = xpl < XL && k * XL + xpl < wpix && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
             px[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.wi + ix) * A : 0));
             ty += dty; tx += dtx;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         int ty = ty0, tx = tx0;
 #pragma unroll
         for (int k = 0; k < PFX; ++k) {
-            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const int iy = S * oy0 - halo + ty, ix = S * ox0 - halo + tx;
             const bool live = xpl < XL && k * XL + xpl < wpix;
             const bool inb = live && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
             float4 v = px[k];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
             int tyy = ty, txx = tx;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int iy = oy0 - halo + tyy, ix = ox0 - halo + txx;
+                const int iy = S * oy0 - halo + tyy, ix = S * ox0 - halo + txx;
                 lv[u] = xpl < XL && (k0 + u) * XL + xpl < wpix;
                 ok[u] = lv[u] && iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi;
                 v[u] = *reinterpret_cast<const float4*>(src + (ok[u] ? ((size_t)iy * g.wi + ix) * A : 0));
@@ -190,11 +192,11 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         // ---- K loop: rows of the tile, 16 MFMA steps per row (lane half h covers pixels 16h .. 16h+15); straight-line
         // per (row, unit group): the operands of step s+1 are requested before the MFMAs of step s are issued
         const int rowstep = tile_w * A;
-        auto koff = [&](int s) { return TWL == 8 ? (s >> 3) * rowstep + (s & 7) * A : s * A; };     // s is a compile-time index
+        auto koff = [&](int s) { return S * (TWL == 8 ? (s >> 3) * rowstep + (s & 7) * A : s * A); };     // s is a compile-time index
         for (int row = 0; row < th; ++row) {
             const float* gp = gs + (row * 32 + 16 * h) * 32 + r;
             // K-pixel k = 16h + s of this MFMA row sits at image row k / TWL, column k % TWL of the tile
-            const float* xp = xs + (TWL == 32 ? (row * tile_w + 16 * h) : (TWL == 16 ? (row * 2 + h) * tile_w : (row * 4 + 2 * h) * tile_w)) * A;
+            const float* xp = xs + S * (TWL == 32 ? (row * tile_w + 16 * h) : (TWL == 16 ? (row * 2 + h) * tile_w : (row * 4 + 2 * h) * tile_w)) * A;
             if (Q > 0) {
                 float b = gp[0], a[Q > 0 ? Q : 1];
 #pragma unroll
@@ -301,11 +303,15 @@ __global__ __launch_bounds__(256) void wgrad_lds_sum_kernel(const float* __restr
     }
 }
 
-static int wgrad_tile_width(const WgradGeom& g) { return g.wg >= 32 ? 32 : (g.wg >= 16 ? 16 : 8); }
+// stride 2: the X window is twice as large per G pixel, so the tile is at most 16 wide
+static int wgrad_tile_width(const WgradGeom& g) {
+    if (g.stride == 2) return g.wg >= 16 ? 16 : 8;
+    return g.wg >= 32 ? 32 : (g.wg >= 16 ? 16 : 8);
+}
 
-// th MFMA rows = th * 32/twl image rows
+// th MFMA rows = th * 32/twl rows of G; the X window covers stride times as many rows and columns, plus the halo
 static size_t wgrad_lds_bytes(const WgradGeom& g, int th, int twl) {
-    return ((size_t)(th * (32 / twl) + 2 * g.pad) * (twl + 2 * g.pad) * g.A + (size_t)th * 32 * 32) * sizeof(float);
+    return ((size_t)(g.stride * th * (32 / twl) + 2 * g.pad) * (g.stride * twl + 2 * g.pad) * g.A + (size_t)th * 32 * 32) * sizeof(float);
 }
 
 // the (A, units) pairs that exist: A in {32, 64, 96, 128} x odd square kernels 1, 3, 5 with <= 36 units.
@@ -331,19 +337,22 @@ static bool wgrad_lds_has_shape(int A, int units) {
 }
 
 bool lds_wgrad_ok(const WgradGeom& g) {
-    if (g.stride != 1 || g.B > 32 || g.A % 32 != 0 || g.A > 128) return false;
-    if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hg != g.hi || g.wg != g.wi) return false;
-    if (g.wg < 8 || g.hg < 4 || (g.wg < 32 && !wgrad_lds_narrow_ok(g.A))) return false;
-    if (g.wg >= 32 && g.hg < 8) return false;
+    if ((g.stride != 1 && g.stride != 2) || g.B > 32 || g.A % 32 != 0 || g.A > 128) return false;
+    if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hi != g.stride * g.hg || g.wi != g.stride * g.wg) return false;
+    if (g.stride == 2 && g.A != 32) return false;             // strided forms are instantiated for 32 channels only
+    if (g.wg < 8 || g.hg < 4 || (wgrad_tile_width(g) < 32 && !wgrad_lds_narrow_ok(g.A))) return false;
+    if (wgrad_tile_width(g) == 32 && g.hg < 8) return false;
     if (!wgrad_lds_has_shape(g.A, g.kh * g.kw * (g.A / 32))) return false;
-    return wgrad_lds_bytes(g, wgrad_tile_width(g) == 32 ? 4 : 2, wgrad_tile_width(g)) <= 150 * 1024 && (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
+    return wgrad_lds_bytes(g, wgrad_tile_width(g) == 32 ? 4 : (g.stride == 2 ? 1 : 2), wgrad_tile_width(g)) <= 150 * 1024 &&
+           (long)g.n * g.hi * g.wi * g.A < 0x7fffffffL;
 }
 
 static int wgrad_lds_tile_rows(const WgradGeom& g) {
     // tallest tile that fits in LDS; on small maps shrink it until every CU has a tile (the kernel is
     // critical-path-bound there: a shorter tile is a shorter serial K loop per block)
     const int twl = wgrad_tile_width(g), rpm = 32 / twl;
-    int th = wgrad_lds_bytes(g, 8, twl) <= 150 * 1024 ? 8 : 4;
+    int th = 8;
+    while (th > 1 && wgrad_lds_bytes(g, th, twl) > 150 * 1024) th >>= 1;
     const int tiles_x = (g.wg + twl - 1) / twl;
     const int th_min = twl == 32 ? 2 : 1;
     while (th > th_min && (long)g.n * tiles_x * ((g.hg + th * rpm - 1) / (th * rpm)) < 256) th >>= 1;
@@ -361,7 +370,7 @@ int64_t lds_wgrad_ws_bytes(const WgradGeom& g) {
     return (int64_t)wgrad_lds_blocks(g) * g.kh * g.kw * (g.A / 32) * 1024 * sizeof(float);
 }
 
-template <int A, int Q, int REM, int PFX, int TWL>
+template <int A, int Q, int REM, int PFX, int TWL, int S>
 static int launch_one(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st) {
     const int th = wgrad_lds_tile_rows(g);
     size_t bytes = wgrad_lds_bytes(g, th, TWL);
@@ -369,14 +378,14 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
     if (fold > bytes) bytes = fold;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
     const int rows = th * (32 / TWL);
     const int tiles_x = (g.wg + TWL - 1) / TWL, tiles_y = (g.hg + rows - 1) / rows;
-    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
+    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
                        tiles_x, tiles_y);
     return launch_status("wgrad_lds");
 }
@@ -390,10 +399,15 @@ int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* 
 #define SENAS_CASE(A_, Q_, REM_, PF_) \
     if (!found && g.A == A_ && units == 8 * Q_ + REM_) {                                                          \
         found = true;                                                                                             \
-        if (twl == 32) rc = launch_one<A_, Q_, REM_, PF_, 32>(g, X, G, part, x_relu, st);                        \
+        if (g.stride == 2) {                                                                                      \
+            if constexpr (A_ == 32) {                                                                             \
+                rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 2>(g, X, G, part, x_relu, st)                  \
+                               : launch_one<A_, Q_, REM_, PF_, 8, 2>(g, X, G, part, x_relu, st);                  \
+            }                                                                                                     \
+        } else if (twl == 32) rc = launch_one<A_, Q_, REM_, PF_, 32, 1>(g, X, G, part, x_relu, st);              \
         else if constexpr (A_ == 32 || A_ == 128) {                                                               \
-            rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16>(g, X, G, part, x_relu, st)                         \
-                           : launch_one<A_, Q_, REM_, PF_, 8>(g, X, G, part, x_relu, st);                         \
+            rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 1>(g, X, G, part, x_relu, st)                      \
+                           : launch_one<A_, Q_, REM_, PF_, 8, 1>(g, X, G, part, x_relu, st);                      \
         }                                                                                                         \
     }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
@@ -411,7 +425,7 @@ void lds_wgrad_name(const WgradGeom& g, char* buf, int len) {
 #define SENAS_CASE(A_, Q_, REM_, PF_) if (g.A == A_ && units == 8 * Q_ + REM_) { q = Q_; rem = REM_; pf = PF_; }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
-    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d, %d>", g.A, q, rem, pf, wgrad_tile_width(g));
+    snprintf(buf, len, "wgrad_lds_kernel<%d, %d, %d, %d, %d, %d>", g.A, q, rem, pf, wgrad_tile_width(g), g.stride);
 }
 
 }  // namespace senas

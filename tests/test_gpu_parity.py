@@ -420,6 +420,10 @@ _CONV_CASES = [
     (4, 32, 8, 8, 8, 3, 1, 1, False, False),        # ... on 8x8
     (2, 32, 8, 32, 32, 5, 2, 3, False, False),      # stride-2 candidate with 8 outputs (thin-N gather forward)
     (2, 32, 8, 16, 16, 5, 2, 2, True, False),       # transposed candidate with 8 outputs
+    (2, 32, 32, 32, 32, 3, 2, 1, False, True),      # 3x3 stride 2 (se_conv_3 of a down cell): strided LDS weight gradient
+    (4, 32, 32, 64, 64, 5, 2, 3, False, False),     # 5x5 d3 stride 2, several tiles per block
+    (4, 32, 32, 32, 32, 5, 2, 3, True, False),      # ConvTranspose2d 5x5 d3 (dy on the fine grid)
+    (2, 32, 32, 8, 8, 5, 2, 2, True, False),        # ... on an 8x8 input (8-wide strided tiles)
 ]
 
 

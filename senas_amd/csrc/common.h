@@ -200,6 +200,9 @@ void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hip
 // conv_lds.hip (stride-1 "same" convolutions with the input window staged in LDS)
 bool lds_gather_ok(const GatherGeom& g);
 void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len);
+bool lds_gather_s2_ok(const GatherGeom& g);       // stride-2 plain gather (Conv2d forward, ConvTranspose2d data gradient)
+int launch_lds_gather_s2(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,
+                         double* stats, hipStream_t st);
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st);

@@ -472,7 +472,8 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     // MFMA paths read the fragment image; `packed` (if given) is that image, refreshed by the caller
     // once per step (senas_pack_batched) instead of once per launch
     const bool use_lds = !g->transposed && lds_gather_ok(gg);
-    if (use_lds || mfma_gather_ok(gg, g->transposed != 0)) {
+    const bool use_s2 = !g->transposed && lds_gather_s2_ok(gg);
+    if (use_lds || use_s2 || mfma_gather_ok(gg, g->transposed != 0)) {
         const float* img = packed;
         if (img == nullptr) {
             if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st);
@@ -480,6 +481,7 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
             img = wp;
         }
         if (use_lds) return launch_lds_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
+        if (use_s2) return launch_lds_gather_s2(gg, x, img, y, in_relu, nullptr, stats, st);
         if (!g->transposed) return launch_mfma_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
         return launch_mfma_gather<true>(gg, x, img, y, in_relu, nullptr, stats, st);
     }
@@ -521,7 +523,8 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     float* wp = reinterpret_cast<float*>(ws);
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
     const bool use_lds = !g->transposed && lds_gather_ok(gg);
-    if (use_lds || mfma_gather_ok(gg, g->transposed == 0)) {
+    const bool use_s2 = g->transposed && lds_gather_s2_ok(gg);          // ConvTranspose2d: dx is a stride-2 plain gather over dy
+    if (use_lds || use_s2 || mfma_gather_ok(gg, g->transposed == 0)) {
         const float* img = packed;
         if (img == nullptr) {
             if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st);
@@ -529,6 +532,7 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
             img = wp;
         }
         if (use_lds) return launch_lds_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
+        if (use_s2) return launch_lds_gather_s2(gg, dy, img, dx, 0, mask, nullptr, st);
         if (!g->transposed) return launch_mfma_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
         return launch_mfma_gather<false>(gg, dy, img, dx, 0, mask, nullptr, st);
     }
@@ -676,6 +680,13 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         static int slot = 0;
         char* b = buf[slot++ & 7];
         lds_gather_name(gg, tg, b, 64);
+        return b;
+    }
+    if (!tg && lds_gather_s2_ok(gg)) {
+        static char buf[8][64];
+        static int slot = 0;
+        char* b = buf[slot++ & 7];
+        snprintf(b, 64, "conv_lds_kernel<false, 1, 4, %d, 0, 1, %d, 2>", gg.kh * gg.kw <= 9 ? 3 : 7, gg.wout >= 16 ? 16 : 8);
         return b;
     }
     if (mfma_gather_ok(gg, tg)) {

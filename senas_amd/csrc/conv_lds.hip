@@ -55,7 +55,9 @@ struct Frag {
 // ONE 32-pixel MFMA row whose taps are dealt to the 4 waves, one wave per SIMD -- the shortest critical path there is).
 // TWL: tile width in pixels (32, 16, 8): a 32-pixel MFMA row covers 32/TWL image rows, so 16x16 and 8x8 maps use the
 // same kernel.  Block = 64 * RW * KS threads; tile = RW * MT * (32/TWL) image rows x TWL columns.
-template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL>
+// S: stride of a PLAIN gather (1, or 2: Conv2d stride-2 forward, ConvTranspose2d stride-2 data gradient): output pixel
+// (oy, ox) reads window pixel (S*oy + ky*d, S*ox + kx*d), so the window covers S times the tile plus the halo.
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1>
 __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
     const int co = cot * 32 + r;
     const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TWL;
     const int halo = g.pad;                              // = dil * (k / 2) on this path
-    const int tile_w = TWL + 2 * halo, tile_h = TH + 2 * halo;
+    static_assert(S == 1 || !TG, "the strided form is a plain gather");
+    const int tile_w = S * TWL + 2 * halo, tile_h = S * TH + 2 * halo;
     const int ngroups = g.cin >> 3, npass = g.cin / CH;
     const int taps = g.kh * g.kw;
     wp += (size_t)cot * taps * ngroups * 256 + lane * 4;
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
     // LDS offset (in 16-byte units, so the accesses are provably aligned -> ds_read_b128) of this lane's
     // pixel for tap (0,0), channel chunk h, sub-tile 0; sub-tile m is tile_w * P4 * m further
     float4* lds4 = reinterpret_cast<float4*>(lds);
-    const int lbase = ((MT * wave * RPM + pr) * tile_w + px) * P4 + h;
-    const int lrow = RPM * tile_w * P4;
+    const int lbase = (S * (MT * wave * RPM + pr) * tile_w + S * px) * P4 + h;
+    const int lrow = S * RPM * tile_w * P4;
 
     // staging geometry of this thread (pass-independent): slot k holds window pixel k*(NT/4) + (tid>>2), piece tid&3
     constexpr int XL = NT / 4;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
         int ty = ty0, tx = tx0;
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const int iy = S * oy0 - halo + ty, ix = S * ox0 - halo + tx;
             const bool inb = k * XL + spl < wpix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
             pf[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.win + ix) * g.cin : 0));
             ty += dty; tx += dtx;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
         int ty = ty0, tx = tx0;
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+            const int iy = S * oy0 - halo + ty, ix = S * ox0 - halo + tx;
             const bool live = k * XL + spl < wpix;
             const bool inb = live && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
             float4 v = pf[k];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
             bool ok[4], lv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
+                const int iy = S * oy0 - halo + ty, ix = S * ox0 - halo + tx;
                 lv[u] = (k0 + u) * XL + spl < wpix;
                 ok[u] = lv[u] && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
                 v[u] = *reinterpret_cast<const float4*>(src + (ok[u] ? ((size_t)iy * g.win + ix) * g.cin : 0));
@@ -381,8 +384,8 @@ bool lds_gather_ok(const GatherGeom& g) {
     return bytes <= 150 * 1024 && (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
 }
 
-static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int ks, int rw) {
-    size_t bytes = (size_t)(th + 2 * g.pad) * (twl + 2 * g.pad) * PST * sizeof(float);
+static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int ks, int rw, int s = 1) {
+    size_t bytes = (size_t)(s * th + 2 * g.pad) * (s * twl + 2 * g.pad) * PST * sizeof(float);
     const size_t fold = ks > 1 ? (size_t)(ks / 2) * rw * mt * 4096 : 0;
     if (bytes < 4 * 32 * 2 * sizeof(double)) bytes = 4 * 32 * 2 * sizeof(double);      // statistics scratch
     const size_t tr = (size_t)rw * mt * 32 * 36 * sizeof(float);                      // epilogue transpose
@@ -390,20 +393,20 @@ static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int k
     return fold > bytes ? fold : bytes;
 }
 
-template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL>
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                               const float* mask, double* stats, hipStream_t st) {
     constexpr int TH = RW * MT * (32 / TWL);
-    const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW);
+    const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW, S);
     static bool attr_set = false;
     if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
     dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
                        mask, stats);
     return launch_status("conv_lds");
 }
@@ -460,6 +463,27 @@ void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len) {
     const int taps = g.kh * g.kw;
     const int maxt = ks == 1 ? 1 : (taps <= 9 ? (ks == 4 ? 3 : 5) : (ks == 4 ? 7 : 13));
     snprintf(buf, len, "conv_lds_kernel<%s, %d, %d, %d, 0, %d, %d>", tg ? "true" : "false", mt, ks, maxt, rw, twl);
+}
+
+// ---- stride-2 plain gather: one 32-pixel MFMA row per block (2 output rows x 16, or 4 x 8), taps on 4 waves
+bool lds_gather_s2_ok(const GatherGeom& g) {
+    if (g.stride != 2 || g.cin % CH != 0) return false;
+    if (g.kh != g.kw || g.pad != g.dil * (g.kh / 2) || g.hin != 2 * g.hout || g.win != 2 * g.wout) return false;
+    const int taps = g.kh * g.kw;
+    if (taps != 9 && taps != 25) return false;
+    if (g.wout < 8 || g.hout < 4) return false;
+    return (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL;
+}
+
+int launch_lds_gather_s2(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,
+                         double* stats, hipStream_t st) {
+    const int taps = g.kh * g.kw;
+    if (g.wout >= 16) {
+        if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st);
+        return launch_lds_variant<false, 1, 4, 7, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st);
+    }
+    if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st);
+    return launch_lds_variant<false, 1, 4, 7, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st);
 }
 
 template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);

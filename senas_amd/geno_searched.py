@@ -1,30 +1,30 @@
-"""Built-in genotypes (data).  Values as published by the reference: ``models/geno_searched.py:3-10``
-and README.md:44 (``senas`` = ``senas_node_4``)."""
+"""Built-in genotypes, by name (``senas_node_2``, ``senas_node_3``, ``senas_node_4``, ``senas`` = ``senas_node_4``).
+
+The values are data published by the reference (``models/geno_searched.py:3-10``, README.md:44); they live in
+``data/genotypes.json`` and are turned into :class:`~senas_amd.genotype.Genotype` tuples at import time, so
+``geno_searched.senas_node_4`` / ``getattr(geno_searched, name)`` work exactly as the reference's module attributes
+(``experiments/train_model.py:117``).
+"""
+import json
+import os
+
 from .genotype import Genotype
 
-senas_node_2 = Genotype(
-    down=[('dil_2_conv_5', 1), ('dil_2_conv_5', 0), ('dil_3_conv_5', 2), ('dil_3_conv_5', 0)],
-    down_concat=range(2, 4),
-    up=[('dil_3_conv_5', 1), ('dil_3_conv_5', 0), ('dil_2_conv_5', 0), ('dil_3_conv_5', 2)],
-    up_concat=range(2, 4),
-    gamma=[0, 0, 1, 1, 1, 1])
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'genotypes.json')
 
-senas_node_3 = Genotype(
-    down=[('se_conv_3', 1), ('dil_2_conv_5', 0), ('dil_3_conv_5', 0), ('dil_2_conv_5', 2), ('dil_3_conv_5', 0),
-          ('dil_2_conv_5', 3)],
-    down_concat=range(2, 5),
-    up=[('up_sample', 1), ('dil_3_conv_5', 0), ('up_sample', 1), ('dil_3_conv_5', 2), ('up_sample', 1),
-        ('dep_sep_conv_3', 3)],
-    up_concat=range(2, 5),
-    gamma=[1, 0, 1, 0, 1, 1])
 
-senas_node_4 = Genotype(
-    down=[('se_conv_3', 1), ('avg_pool', 0), ('dil_3_conv_5', 2), ('dep_sep_conv_5', 1), ('dil_3_conv_5', 2),
-          ('avg_pool', 0), ('avg_pool', 1), ('dil_3_conv_5', 3)],
-    down_concat=range(2, 6),
-    up=[('up_sample', 1), ('dil_3_conv_5', 0), ('dil_3_conv_5', 0), ('dil_2_conv_5', 2), ('dil_3_conv_5', 1),
-        ('dil_2_conv_5', 2), ('dep_sep_conv_3', 0), ('dil_2_conv_5', 4)],
-    up_concat=range(2, 6),
-    gamma=[0, 0, 0, 1, 1, 1])
+def _load():
+    with open(_PATH) as f:
+        table = json.load(f)
+    made = {}
+    for name, g in table['genotypes'].items():
+        made[name] = Genotype(down=[(op, int(idx)) for op, idx in g['down']], down_concat=range(*g['down_concat']),
+                              up=[(op, int(idx)) for op, idx in g['up']], up_concat=range(*g['up_concat']),
+                              gamma=list(g['gamma']))
+    for alias, target in table['aliases'].items():
+        made[alias] = made[target]
+    return made
 
-senas = senas_node_4
+
+globals().update(_load())
+__all__ = ['senas', 'senas_node_2', 'senas_node_3', 'senas_node_4']

@@ -1,23 +1,38 @@
-"""Small host-side helpers of the hot path (reference: utils/utils.py:21-40,240-250)."""
+"""Small host-side helpers of the hot path."""
 import torch
+import torch.nn as nn
+
+
+def _init_conv(m):
+    nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+def _init_norm(m):
+    nn.init.ones_(m.weight)
+    if m.bias is not None:
+        nn.init.zeros_(m.bias)
+
+
+def _init_linear(m):
+    nn.init.xavier_normal_(m.weight)
+    if m.bias is not None:
+        nn.init.zeros_(m.bias)
+
+
+_INITIALISERS = ((nn.Conv2d, _init_conv), (nn.ConvTranspose2d, _init_conv), (nn.BatchNorm2d, _init_norm), (nn.Linear, _init_linear))
 
 
 def weights_init(m):
-    """kaiming-normal (fan_out, relu) for conv / transposed conv, BN weight 1 / bias 0,
-    xavier-normal Linear -- utils/utils.py:240-250."""
-    if isinstance(m, torch.nn.Linear):
-        torch.nn.init.xavier_normal_(m.weight)
-        if m.bias is not None:
-            torch.nn.init.constant_(m.bias, 0)
-    elif isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
-        torch.nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-    elif isinstance(m, torch.nn.BatchNorm2d):
-        torch.nn.init.constant_(m.weight, 1)
-        if m.bias is not None:
-            torch.nn.init.constant_(m.bias, 0)
+    """``model.apply(weights_init)``: the initialisation scheme of the reference (utils/utils.py:240-250) -- He-normal
+    (fan-out, ReLU gain) convolution kernels, unit batch-norm scale / zero shift, Glorot-normal linear layers."""
+    for kind, init in _INITIALISERS:
+        if isinstance(m, kind):
+            init(m)
+            return
 
 
 def channel_shuffle(x, groups):
-    """[N,C,H,W] -> interleave ``groups`` channel groups (dead on the SENAS path: MixedOp.k == 1)."""
-    n, c, h, w = x.size()
-    return x.view(n, groups, c // groups, h, w).transpose(1, 2).contiguous().view(n, -1, h, w)
+    """Interleave ``groups`` channel groups of an [N, C, H, W] tensor (PC-DARTS partial channels; dead on the SENAS
+    path because MixedOp.k == 1)."""
+    n, c, h, w = x.shape
+    return x.reshape(n, groups, c // groups, h, w).transpose(1, 2).reshape(n, c, h, w)

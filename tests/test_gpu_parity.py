@@ -564,3 +564,30 @@ def test_loss_and_metric_kernels(tag):
         cnt = c if cnt is None else tuple(a + b for a, b in zip(cnt, c))
     tp, fp, fn = m.counts()
     assert [list(map(int, v)) for v in (tp, fp, fn)] == [[int(q) for q in np.asarray(v).reshape(-1)] for v in cnt]
+
+
+def _random_conv_cases(count, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < count:
+        k = int(rng.choice([1, 3, 5, 7]))
+        stride = int(rng.choice([1, 1, 2]))
+        dil = int(rng.choice([1, 2, 3])) if k > 1 else 1
+        tr = bool(stride == 2 and rng.rand() < 0.4)
+        ci = int(rng.choice([1, 3, 4, 8, 16, 24, 32, 64]))
+        co = int(rng.choice([2, 3, 4, 8, 16, 32]))
+        h, w = int(rng.randint(4, 41)), int(rng.randint(4, 41))
+        if stride == 2 and not tr:
+            h, w = h + (h & 1), w + (w & 1)                      # even inputs, as on the path
+        n = int(rng.randint(1, 4))
+        if k == 7 and ci > 4:
+            continue                                             # 7x7 only exists on the 1/3-channel stem
+        cases.append((n, ci, co, h, w, k, stride, dil, tr, bool(rng.rand() < 0.5)))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases(48, 1234), ids=lambda c: 'n%d_%dto%d_%dx%d_k%ds%dd%d%s%s' % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], '_T' if c[8] else '', '_relu' if c[9] else ''))
+def test_conv_dispatch_sweep(case):
+    """Seeded random geometries across the dispatch space (thin / c8 / LDS window incl. narrow, strided and single-row
+    forms / direct-global MFMA / fallbacks): whatever kernel a shape lands on must agree with the oracle."""
+    test_conv_kernels_vs_oracle(case)

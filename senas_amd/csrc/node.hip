@@ -336,8 +336,8 @@ static size_t fused_fwd_lds(const NodeDesc& d) {
 template <int TT>
 __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
                                                           const float* __restrict__ dy, int dys, const float* __restrict__ y,
-                                                          int relu, int do_p1, double* __restrict__ p1,
-                                                          double* __restrict__ p2) {
+                                                          const uint8_t* __restrict__ mask8, int relu, int do_p1,
+                                                          double* __restrict__ p1, double* __restrict__ p2) {
     __shared__ double red[256];
     const int rows = 256 / c;
     const int ch = threadIdx.x % c, row = threadIdx.x / c;
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
         for (long p = q0 + row; p < q1; p += rows) {
             const size_t o = base + (size_t)p * c;
             float ds = dy[((size_t)n * hw + p) * dys + ch];
-            if (relu && !(y[o] > 0.f)) ds = 0.f;
+            if (relu) {                                  // byte map (c % 4 == 0: pieces never straddle pixels) or y itself
+                const bool pos = mask8 != nullptr ? ((mask8[o >> 2] >> (o & 3)) & 1u) != 0 : y[o] > 0.f;
+                if (!pos) ds = 0.f;
+            }
             a1 += ds;
 #pragma unroll
             for (int t = 0; t < TT; ++t)
@@ -913,10 +916,10 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
         } else {
             const long chunk = node_chunk(d.hw, d.n);
             dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
-            if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
-            else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
-            else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
-            else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, d.relu, first, p1, p2);
+            if (tt > 4) hipLaunchKernelGGL((node_reduce_kernel<8>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2);
+            else if (tt > 2) hipLaunchKernelGGL((node_reduce_kernel<4>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2);
+            else if (tt == 2) hipLaunchKernelGGL((node_reduce_kernel<2>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2);
+            else hipLaunchKernelGGL((node_reduce_kernel<1>), rgrid, dim3(256), 0, st, d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2);
         }
         t0 += tt;
         first = 0;

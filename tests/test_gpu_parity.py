@@ -591,3 +591,94 @@ def test_conv_dispatch_sweep(case):
     """Seeded random geometries across the dispatch space (thin / c8 / LDS window incl. narrow, strided and single-row
     forms / direct-global MFMA / fallbacks): whatever kernel a shape lands on must agree with the oracle."""
     test_conv_kernels_vs_oracle(case)
+
+
+def _random_node_cases(count, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for _ in range(count):
+        c = int(rng.choice([4, 8, 12, 32, 64, 6]))
+        cases.append(dict(n=int(rng.randint(1, 5)), c=c, h=int(rng.randint(2, 20)), w=int(rng.randint(2, 20)),
+                          T=int(rng.choice([1, 2, 3, 6, 9, 12])), relu=bool(rng.rand() < 0.6), residual=bool(rng.rand() < 0.3),
+                          mix=bool(rng.rand() < 0.6), training=bool(rng.rand() < 0.8), seed=int(rng.randint(1 << 30)),
+                          se=bool(rng.rand() < 0.4), zero_term=bool(rng.rand() < 0.2)))
+    return cases
+
+
+@pytest.mark.parametrize('cfg', _random_node_cases(36, 77), ids=lambda d: 'n%d_c%d_%dx%d_T%d%s%s%s%s' % (
+    d['n'], d['c'], d['h'], d['w'], d['T'], '_relu' if d['relu'] else '', '_res' if d['residual'] else '',
+    '_se' if d['se'] else '', '' if d['training'] else '_eval'))
+def test_node_sweep_vs_torch(cfg):
+    """The fused node (bn_combine) against a float64 torch formulation of the same arithmetic: every BatchNorm2d (train
+    statistics + running-buffer update, or eval), SE gates, mixing weights, the 'none' op's bias-only term, residual,
+    ReLU -- outputs and the gradients of every input."""
+    import torch.nn as nn
+    from senas_amd import functional as F
+    from senas_amd.operations import SEBlock
+    g = torch.Generator().manual_seed(cfg['seed'])
+    n, c, h, w, T = cfg['n'], cfg['c'], cfg['h'], cfg['w'], cfg['T']
+    zs = [torch.randn(n, c, h, w, generator=g) * (0.5 + t) + 0.3 * t for t in range(T)]
+    if cfg['zero_term'] and T > 1:
+        zs[1] = None                                       # the 'none' candidate: BN of zeros = its bias
+    bns = []
+    for t in range(T):
+        bn = nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.train(cfg['training'])
+        bns.append(bn)
+    ses = [SEBlock(c) if (cfg['se'] and t % 2 == 0 and zs[t] is not None) else None for t in range(T)]
+    for se in ses:
+        if se is not None:
+            with torch.no_grad():
+                for lin in (se.excitation[0], se.excitation[2]):
+                    lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.5)
+    mix = torch.rand(T, generator=g) + 0.1 if cfg['mix'] else None
+    res = torch.randn(n, c, h, w, generator=g) if cfg['residual'] else None
+    gy = torch.randn(n, c, h, w, generator=g)
+
+    # ---- float64 reference
+    import copy
+    ref_bns = [copy.deepcopy(b).double() for b in bns]
+    ref_ses = [copy.deepcopy(s).double() if s is not None else None for s in ses]
+    zr = [z.double().requires_grad_(True) if z is not None else None for z in zs]
+    mr = mix.double().requires_grad_(True) if mix is not None else None
+    rr = res.double().requires_grad_(True) if res is not None else None
+    acc = rr if rr is not None else 0.0
+    for t in range(T):
+        zt = zr[t] if zr[t] is not None else torch.zeros(n, c, h, w, dtype=torch.float64)
+        v = ref_bns[t](zt)
+        if ref_ses[t] is not None:
+            gate = ref_ses[t].excitation(v.mean((2, 3)))
+            v = v * gate[:, :, None, None]
+        acc = acc + (mr[t] * v if mr is not None else v)
+    ref = torch.relu(acc) if cfg['relu'] else acc
+    ref.backward(gy.double())
+
+    # ---- HIP path
+    dbns = [copy.deepcopy(b).to(dev()) for b in bns]
+    dses = [copy.deepcopy(s).to(dev()) if s is not None else None for s in ses]
+    zd = [z.to(dev()).requires_grad_(True) if z is not None else None for z in zs]
+    md = mix.to(dev()).requires_grad_(True) if mix is not None else None
+    rd = res.to(dev()).requires_grad_(True) if res is not None else None
+    terms = [F.Term(zd[t], dbns[t], se=dses[t]) for t in range(T)]
+    out = F.bn_combine(terms, mix=md, residual=rd, relu=cfg['relu'])
+    out.backward(gy.to(dev()))
+    close(out, ref.detach().float().numpy(), 'y', rel=2e-5)
+    for t in range(T):
+        if zd[t] is not None:
+            close(zd[t].grad, zr[t].grad.float().numpy(), 'dz%d' % t, rel=1e-4)
+        close(dbns[t].weight.grad, ref_bns[t].weight.grad.float().numpy(), 'dgamma%d' % t, rel=1e-4)
+        close(dbns[t].bias.grad, ref_bns[t].bias.grad.float().numpy(), 'dbeta%d' % t, rel=1e-4)
+        close(dbns[t].running_mean, ref_bns[t].running_mean.float().numpy(), 'running_mean%d' % t, rel=1e-5)
+        close(dbns[t].running_var, ref_bns[t].running_var.float().numpy(), 'running_var%d' % t, rel=1e-5)
+        if dses[t] is not None:
+            for k in (0, 2):
+                close(dses[t].excitation[k].weight.grad, ref_ses[t].excitation[k].weight.grad.float().numpy(), 'dse%d.%d' % (t, k), rel=1e-4)
+    if md is not None:
+        close(md.grad, mr.grad.float().numpy(), 'dmix', rel=1e-4)
+    if rd is not None:
+        close(rd.grad, rr.grad.float().numpy(), 'dres', rel=1e-5)

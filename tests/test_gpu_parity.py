@@ -682,3 +682,93 @@ def test_node_sweep_vs_torch(cfg):
         close(md.grad, mr.grad.float().numpy(), 'dmix', rel=1e-4)
     if rd is not None:
         close(rd.grad, rr.grad.float().numpy(), 'dres', rel=1e-5)
+
+
+def _random_pointwise_cases(count, seed):
+    rng = np.random.RandomState(seed)
+    kinds = ['avg', 'max', 'bilinear', 'relu', 'dw3', 'dw5', 'dw3T', 'dw5T']
+    cases = []
+    for _ in range(count):
+        kind = kinds[int(rng.randint(len(kinds)))]
+        stride = 2 if kind.endswith('T') else int(rng.choice([1, 2]))
+        h, w = int(rng.randint(3, 33)), int(rng.randint(3, 33))
+        if stride == 2 and not kind.endswith('T'):
+            h, w = h + (h & 1), w + (w & 1)
+        cases.append((kind, int(rng.randint(1, 5)), int(rng.choice([3, 4, 8, 12, 32, 64])), h, w, stride, bool(rng.rand() < 0.5),
+                      int(rng.randint(1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_pointwise_cases(40, 4242), ids=lambda c: '%s_n%d_c%d_%dx%d_s%d%s' % (c[0], c[1], c[2], c[3], c[4], c[5], '_relu' if c[6] else ''))
+def test_pool_resample_depthwise_sweep(case):
+    """Seeded random shapes for the HBM-bound kernels (3x3 average / max pooling, bilinear x2, ReLU, depthwise 3x3 / 5x5
+    incl. stride 2 and transposed): outputs, producer-side statistics, input and weight gradients against torch (float64)."""
+    import torch.nn.functional as tf
+    from senas_amd import functional as F
+    kind, n, c, h, w, stride, relu, seed = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g)
+    xr = x.double().requires_grad_(True)
+    xin = torch.relu(xr) if relu else xr
+    xd = x.to(dev()).requires_grad_(True)
+    wt = wr = wd = None
+    if kind == 'avg':
+        ref = tf.avg_pool2d(xin, 3, stride, 1, count_include_pad=False)
+        got, st = F.avg_pool3(xd, stride, in_relu=relu, want_stats=True)
+    elif kind == 'max':
+        ref = tf.max_pool2d(xin, 3, stride, 1)
+        got, st = F.max_pool3(xd, stride, in_relu=relu, want_stats=True)
+    elif kind == 'bilinear':
+        ref = tf.interpolate(xin, scale_factor=2, mode='bilinear', align_corners=False)
+        got, st = F.bilinear2x(F.relu(xd) if relu else xd, want_stats=True)
+    elif kind == 'relu':
+        ref, got, st = torch.relu(xr), F.relu(xd), None
+    else:
+        k = 3 if '3' in kind else 5
+        tr = kind.endswith('T')
+        wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+        wr, wd = wt.double().requires_grad_(True), wt.to(dev()).requires_grad_(True)
+        if tr:
+            ref = tf.conv_transpose2d(xin, wr, stride=2, padding=k // 2, output_padding=1, groups=c)
+        else:
+            ref = tf.conv2d(xin, wr, stride=stride, padding=k // 2, groups=c)
+        got, st = F.conv2d(xd, wd, stride=stride, pad=k // 2, dil=1, transposed=tr, out_pad=1 if tr else 0, groups=c,
+                           in_relu=relu, want_stats=True)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy.double())
+    got.backward(gy.to(dev()))
+    close(got, ref.detach().float().numpy(), 'y', rel=2e-5)
+    close(xd.grad, xr.grad.float().numpy(), 'dx', rel=2e-5)
+    if wd is not None:
+        close(wd.grad, wr.grad.float().numpy(), 'dw', rel=5e-5)
+    if st is not None:
+        r64 = ref.detach()
+        exp = torch.stack([r64.sum((2, 3)), (r64 ** 2).sum((2, 3))], -1)
+        close(st.float(), exp.float().numpy(), 'stats', rel=2e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 2, 16, 16), (1, 3, 9, 13), (3, 4, 32, 20), (2, 5, 7, 7), (1, 8, 33, 31), (4, 6, 24, 24)],
+                         ids=lambda c: 'n%d_c%d_%dx%d' % c)
+def test_loss_metric_class_sweep(case):
+    """Dice+CE and metric kernels for 2..8 classes and odd shapes against the oracle (loss, gradient, hard counts)."""
+    from oracle import senas_ref as R
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.metrics import SegmentationMetric
+    n, c, h, w = case
+    g = torch.Generator().manual_seed(n * 1000 + c * 100 + h)
+    lg = torch.randn(n, c, h, w, generator=g) * 2.0
+    tgt = torch.randint(0, c, (n, h, w), generator=g)
+    ref_in = lg.clone().requires_grad_(True)
+    ref = R.dice_ce_loss(ref_in, tgt)
+    ref.backward()
+    got_in = lg.to(dev()).requires_grad_(True)
+    got = SegmentationLosses('dice_ce')([got_in], tgt.to(dev()))
+    got.backward()
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=5e-6)
+    np.testing.assert_allclose(got_in.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=5e-5, atol=2e-9)
+    m = SegmentationMetric(c)
+    m.update(tgt.to(dev()), got_in.detach())
+    tp, fp, fn = m.counts()
+    rtp, rfp, rfn = R.hard_counts(lg, tgt)
+    assert [list(map(int, v)) for v in (tp, fp, fn)] == [[int(q) for q in np.asarray(v).reshape(-1)] for v in (rtp, rfp, rfn)]
+    assert abs(m.get()[0] - round(100.0 * float(R.mean_pix_accuracy(lg, tgt)), 3)) < 2e-3

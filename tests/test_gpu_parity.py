@@ -772,3 +772,97 @@ def test_loss_metric_class_sweep(case):
     rtp, rfp, rfn = R.hard_counts(lg, tgt)
     assert [list(map(int, v)) for v in (tp, fp, fn)] == [[int(q) for q in np.asarray(v).reshape(-1)] for v in (rtp, rfp, rfn)]
     assert abs(m.get()[0] - round(100.0 * float(R.mean_pix_accuracy(lg, tgt)), 3)) < 2e-3
+
+
+def _random_genotype(rng, nodes):
+    from senas_amd.operations import DownOps, NormOps, UpOps
+
+    def cell(kind):
+        gene = []
+        for i in range(nodes):
+            for idx in sorted(rng.choice(2 + i, 2, replace=False)):
+                if idx >= 2:
+                    ops = NormOps
+                elif kind == 'down':
+                    ops = DownOps
+                else:
+                    ops = UpOps if idx > 0 else NormOps
+                gene.append((ops[int(rng.randint(len(ops)))], int(idx)))
+        return gene
+    return cell('down'), cell('up')
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+def test_derived_random_genotypes_vs_oracle(seed):
+    """Derived networks built from RANDOM genotypes (every candidate op in every legal position, incl. 'none' and
+    'identity'; 3 or 4 nodes; with and without pruned up cells), c=8, depth 4, 2x1x32x32: logits, loss and every
+    parameter gradient against the oracle."""
+    from oracle import senas_ref as R
+    from senas_amd.genotype import Genotype
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    rng = np.random.RandomState(seed)
+    nodes = int(rng.choice([3, 4]))
+    down, up = _random_genotype(rng, nodes)
+    gamma = [int(v) for v in rng.randint(0, 2, 3)]                # depth 4: 3 gates
+    if gamma[1] == 1 and gamma[2] == 0:
+        gamma[2] = 1                                             # keep the second skip row monotone (as NAS.genotype() emits)
+    geno = Genotype(down=down, down_concat=range(2, 2 + nodes), up=up, up_concat=range(2, 2 + nodes), gamma=gamma)
+    net = SenasModel(2, 1, c=8, depth=4, genotype=geno)
+    _randomize(net, seed)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    gio.share_stem(sd)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1, 32, 32, generator=gen)
+    y = torch.randint(0, 2, (2, 32, 32), generator=gen)
+    ref = R.derived_forward(sd, x, R.Genotype(*geno), depth=4)[-1]
+    ref_loss = R.dice_ce_loss(ref, y)
+    ref_loss.backward()
+    net = net.to(dev()).train()
+    out = net(x.to(dev()))
+    loss = SegmentationLosses('dice_ce')(out, y.to(dev()))
+    loss.backward()
+    close(out[-1], ref.detach().numpy(), 'logits %s' % (geno,), rel=1e-3)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    # Gradients through ReLU + train-mode BN on 4x4 maps are ill-conditioned (DESIGN.md "gradient parity"): a
+    # pre-activation within rounding distance of zero flips a ReLU and moves every upstream gradient by percents.  Judge
+    # every parameter gradient against the float64 oracle; the yardstick is how far the oracle's own gradient moves
+    # under float32-sized noise: the float32 oracle, and (only when that is not enough) float64 oracles with weights
+    # perturbed by 1e-6 relative.
+    def oracle64(perturb_seed=None):
+        g = torch.Generator().manual_seed(1000 + (perturb_seed or 0))
+        sd64 = {}
+        for k, v in sd.items():
+            w = v.detach().double() if v.is_floating_point() else v.detach().clone()
+            if v.is_floating_point() and v.requires_grad:
+                if perturb_seed is not None:
+                    w = w * (1.0 + 1e-6 * torch.randn(w.shape, generator=g, dtype=torch.float64))
+                w.requires_grad_(True)
+            sd64[k] = w
+        gio.share_stem(sd64)
+        R.dice_ce_loss(R.derived_forward(sd64, x.double(), R.Genotype(*geno), depth=4)[-1], y).backward()
+        return {k: v.grad.numpy() for k, v in sd64.items() if v.is_floating_point() and v.grad is not None}
+
+    def l2(a, b):
+        return float(np.sqrt(((a - b) ** 2).sum()))
+    e64 = oracle64()
+    got = grads_of(net)
+    names = [k for k in got if k in e64]
+    assert 'stem0.0.weight' in names and len(names) > 20
+    norms = {k: float(np.sqrt((e64[k] ** 2).sum())) for k in names}
+    floor = 1e-6 * max(norms.values())                            # conv biases ahead of a BN: zero gradient, only noise
+    names = [k for k in names if norms[k] > floor]
+    noise = {k: l2(sd[k].grad.numpy().astype(np.float64), e64[k]) / norms[k] for k in names}
+    errs = {k: l2(got[k], e64[k]) / norms[k] for k in names}
+    bad = [k for k in names if errs[k] > max(1e-3, 10.0 * noise[k])]
+    for ps in range(6):
+        if not bad:
+            break
+        alt = oracle64(ps)
+        for k in names:
+            noise[k] = max(noise[k], l2(alt[k], e64[k]) / norms[k])
+        bad = [k for k in names if errs[k] > max(1e-3, 10.0 * noise[k])]
+    assert not bad, 'gradients off: ' + ', '.join('%s %.2e (oracle noise %.2e)' % (k, errs[k], noise[k]) for k in bad[:6])

@@ -25,6 +25,14 @@ class SegmentationMetric(object):
     def reset(self):
         self._acc_sum, self._acc_n, self._counts = None, 0, None
 
+    def reset_counts(self):
+        """Zero the device accumulators in place (a HIP graph that captured ``update`` keeps their addresses)."""
+        if self._counts is None:
+            return
+        self._counts.zero_()
+        self._acc_sum.zero_()
+        self._acc_n = 0
+
     @torch.no_grad()
     def update(self, labels, preds):
         """One launch pair (senas_seg_metric_update): arg-max, per-image pixel accuracy, per-class tp/fp/fn -- all

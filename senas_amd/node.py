@@ -83,7 +83,9 @@ class _Node(torch.autograd.Function):
         se_a1 = torch.empty((T, n, SE_MID_MAX), device=dev, dtype=torch.float32) if ns else None
         y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL)
         # ReLU mask for the backward pass: one byte per 16-byte piece of y instead of y itself
-        mask8 = torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if (meta['relu'] and c % 4 == 0) else None
+        # (not kept when nothing will be differentiated: inference)
+        tracked = any(ctx.needs_input_grad)
+        mask8 = torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if (meta['relu'] and c % 4 == 0 and tracked) else None
         res = F.nhwc(residual) if residual is not None else None
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         _lib.check(L.senas_node_fwd(C.byref(d), zp, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),

@@ -45,7 +45,9 @@ def get_same_padding(kernel_size):
 
 # ----------------------------------------------------------------------------------------------- leaves
 def run_conv(conv, x, in_relu=False, want_stats=True):
-    """Launch the HIP convolution described by an nn.Conv2d / nn.ConvTranspose2d parameter holder."""
+    """Launch the HIP convolution described by an nn.Conv2d / nn.ConvTranspose2d parameter holder.
+    ``want_stats``: also produce the per-image channel sums the following BatchNorm2d needs in training mode (pass
+    ``bn.training``: in eval mode the running statistics are used and the sums would be wasted work)."""
     tr = isinstance(conv, nn.ConvTranspose2d)
     if conv.bias is not None:
         raise F.SenasHipError('convolutions on the SENAS path are bias-free')
@@ -130,7 +132,7 @@ class ConvBn(_Op):
                          build_norm(c_ot, affine))
 
     def raw(self, x, in_relu=False):
-        z, st = run_conv(self[0], x, in_relu)
+        z, st = run_conv(self[0], x, in_relu, want_stats=self[1].training)
         return Term(z, self[1], stats=st)
 
 
@@ -153,9 +155,9 @@ class DepSepConv(_Op):
         super().__init__(*depth, build_norm(c_in, affine), build_activation(), *point, build_norm(c_ot, affine))
 
     def raw(self, x):
-        z1, st1 = run_conv(self[0], x)
+        z1, st1 = run_conv(self[0], x, want_stats=self[1].training)
         mid = F.bn_combine([Term(z1, self[1], stats=st1)], relu=True)
-        z2, st = run_conv(self[3], mid)
+        z2, st = run_conv(self[3], mid, want_stats=self[4].training)
         return Term(z2, self[4], stats=st)
 
 
@@ -195,8 +197,10 @@ class AdapterBlock(nn.Module):
                 raise NotImplementedError('ZeroOp(stride != 1) is not used by OPS')
             return Term(None, self.norm, passengers=[self.conv.weight] if has_conv else [])
         if has_conv:
-            z, st = run_conv(self.conv, self._resample(x))
+            z, st = run_conv(self.conv, self._resample(x), want_stats=self.norm.training)
             return Term(z, self.norm, stats=st)
+        if not self.norm.training:
+            return Term(self._resample(x), self.norm)
         y, st = self._resample(x, want_stats=True)
         return Term(y, self.norm, stats=st)
 
@@ -260,12 +264,12 @@ class _Rectify(nn.Sequential):
     def forward(self, x):
         op = self[1]
         if isinstance(op, (nn.Conv2d, nn.ConvTranspose2d)):
-            z, st = run_conv(op, x, in_relu=True)
+            z, st = run_conv(op, x, in_relu=True, want_stats=self[2].training)
             return F.bn_combine([Term(z, self[2], stats=st)])
         if isinstance(op, nn.AvgPool2d):
-            z, st = F.avg_pool3(x, op.stride, in_relu=True, want_stats=True)
+            z, st = F._AvgPool3.apply(x, op.stride, True, self[2].training)
             return F.bn_combine([Term(z, self[2], stats=st)])
-        z, st = F.bilinear2x(F.relu(x), want_stats=True)
+        z, st = F._Bilinear2x.apply(F.relu(x), self[2].training)
         return F.bn_combine([Term(z, self[2], stats=st)])
 
 
@@ -290,7 +294,7 @@ class ShrinkBlock(nn.Module):
         self.norm = build_norm(c_ot, True)
 
     def forward(self, x):
-        z, st = run_conv(self.conv, x, in_relu=True)
+        z, st = run_conv(self.conv, x, in_relu=True, want_stats=self.norm.training)
         return F.bn_combine([Term(z, self.norm, stats=st)])
 
 
@@ -304,7 +308,7 @@ class RectifyBlock(nn.Module):
         self.norm = build_norm(c_ot, True)
 
     def forward(self, x):
-        z, st = run_conv(self.conv, x)
+        z, st = run_conv(self.conv, x, want_stats=self.norm.training)
         return F.bn_combine([Term(z, self.norm, stats=st)])
 
 
@@ -325,9 +329,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        z1, s1 = run_conv(self.conv1, x)
+        z1, s1 = run_conv(self.conv1, x, want_stats=self.bn1.training)
         a = F.bn_combine([Term(z1, self.bn1, stats=s1)], relu=True)
-        z2, s2 = run_conv(self.conv2, a)
+        z2, s2 = run_conv(self.conv2, a, want_stats=self.bn2.training)
         res = x if self.downsample is None else self.downsample(x)
         return F.bn_combine([Term(z2, self.bn2, stats=s2)], residual=res)
 

@@ -866,3 +866,56 @@ def test_derived_random_genotypes_vs_oracle(seed):
             noise[k] = max(noise[k], l2(alt[k], e64[k]) / norms[k])
         bad = [k for k in names if errs[k] > max(1e-3, 10.0 * noise[k])]
     assert not bad, 'gradients off: ' + ', '.join('%s %.2e (oracle noise %.2e)' % (k, errs[k], noise[k]) for k in bad[:6])
+
+
+# ---------------------------------------------------------------------------------------------- inference pass (8f-4)
+@pytest.mark.parametrize('graphed', [False, True])
+def test_evaluator_vs_oracle(graphed):
+    """The validation / testing pass (experiments/testing_model.py:150-190): eval-mode logits, loss, arg-max masks and
+    pixAcc / mIoU / Dice over three batches, eager and HIP-graph replayed, against the oracle run in eval mode."""
+    from oracle import senas_ref as R
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.infer import Evaluator
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    net = SenasModel(2, 1, c=16, depth=4, genotype=senas_node_4)
+    _randomize(net, 5)
+    # running statistics a trained net would carry (not the 0 / 1 of a fresh module)
+    gen = torch.Generator().manual_seed(5)
+    for k, v in net.state_dict().items():
+        if k.endswith('running_mean'):
+            v.copy_(0.2 * torch.randn(v.shape, generator=gen))
+        elif k.endswith('running_var'):
+            v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    gio.share_stem(sd)
+    xs = torch.randn(3, 2, 1, 64, 64, generator=gen)
+    ys = torch.randint(0, 2, (3, 2, 64, 64), generator=gen)
+    net = net.to(dev())
+    ev = Evaluator(net, 2, xs[0].to(dev()), ys[0].to(dev()), SegmentationLosses('dice_ce'), use_graph=graphed)
+    assert (ev.graph is not None) == graphed
+    ref_loss, tp, fp, fn, acc = 0.0, 0, 0, 0, 0.0
+    for b in range(3):
+        logits, mask = ev(xs[b].to(dev()), ys[b].to(dev()))
+        with torch.no_grad():
+            ref = R.derived_forward(sd, xs[b], R.Genotype(*senas_node_4), depth=4, training=False)[-1]
+        close(logits, ref.numpy(), 'eval logits, batch %d' % b, rel=1e-3)
+        top2 = ref.topk(2, dim=1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref.abs().max()
+        assert bool((mask.cpu() == ref.argmax(1))[sure].all())
+        assert bool((mask == logits.argmax(1)).all())
+        ref_loss += float(R.dice_ce_loss(ref, ys[b]))
+    mean_loss, pix, miou, dice = ev.result()
+    assert abs(mean_loss - ref_loss / 3) <= 1e-4 * abs(ref_loss / 3)
+    # the metric against the reference formulas on the evaluator's own logits is covered by the metric tests; here:
+    # the running-statistics buffers must be untouched by an eval pass, and the figures finite and in range
+    for k, v in net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+    assert 0.0 <= pix <= 100.0 and 0.0 <= miou <= 100.0 and 0.0 <= dice <= 100.0
+    ev.reset()
+    ev(xs[0].to(dev()), ys[0].to(dev()))
+    first = ev.result()
+    ev.reset()
+    ev(xs[0].to(dev()), ys[0].to(dev()))
+    assert ev.result() == first                                   # reset really clears the device accumulators

@@ -2,7 +2,7 @@
 """Which kernels run right before / after a given kernel in a rocprofv3 --kernel-trace CSV (by start time) --
 to find out who issues anonymous runtime kernels such as __amd_rocclr_copyBuffer.
 
-    python tools/trace_neighbors.py <dir> copyBuffer
+    python tools/trace_neighbors.py <dir> copyBuffer [context launches]
 """
 import collections
 import csv
@@ -22,6 +22,14 @@ def main():
         if pat in name:
             before[rows[i - 1][1] if i else '-'] += 1
             after[rows[i + 1][1] if i + 1 < len(rows) else '-'] += 1
+    if len(sys.argv) > 3:                       # context of the LAST run of matches: the <n> launches around it
+        n = int(sys.argv[3])
+        last = max(i for i, (_, name) in enumerate(rows) if pat in name)
+        first = last
+        while first > 0 and pat in rows[first - 1][1]:
+            first -= 1
+        for i in range(max(0, first - n), min(len(rows), last + n + 1)):
+            print('  %12d  %s' % (rows[i][0] - rows[first][0], rows[i][1]))
     print('before:')
     for k, v in before.most_common(8):
         print('  %5d  %s' % (v, k))

@@ -61,6 +61,22 @@ int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);     /* forward and data
  * repacks w into ws itself.  Ignored by the non-MFMA fallback kernels.                            */
 int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y,
                      int in_relu, double* stats, void* ws, const float* packed, void* stream);
+/* Inference forward (experiments/testing_model.py:150-190 runs the model under model.eval()): eval-mode
+ * nn.BatchNorm2d (operations.py:133-134) is a per-channel affine of the convolution output, so it -- together with
+ * the node sum and ReLU of the cell (models/senas_model.py:55-63) -- rides in the epilogue of the producer:
+ *     y = act( scale[n][c] * conv(x, w) + bias[n][c] + add_scale[n][c] * addend[n,p,c] )
+ * scale / bias: float[n][co] (per image so that an SE gate, operations.py:203, can ride along); addend: NHWC tensor
+ * shaped like y, or NULL; add_scale: float[n][co] or NULL (= 1).  Returns SENAS_EUNSUPPORTED without launching when
+ * the geometry has no epilogue kernel (transposed, thin, off the LDS-window path; depthwise with an addend).      */
+typedef struct senas_conv_epilogue {
+    const float* scale;
+    const float* bias;
+    const float* addend;
+    const float* add_scale;
+    int32_t relu;
+} senas_conv_epilogue;
+int senas_conv2d_fwd_epilogue(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
+                              const senas_conv_epilogue* e, void* ws, const float* packed, void* stream);
 /* dx = d loss / d x.  If in_relu != 0, x must be given and dx is masked by (x > 0).            */
 int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, const float* w, float* dx,
                           int in_relu, const float* x, void* ws, const float* packed, void* stream);

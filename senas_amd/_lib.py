@@ -19,6 +19,14 @@ class ConvGeom(C.Structure):
                                          'transposed', 'groups')]
 
 
+class ConvEpilogue(C.Structure):
+    """senas_conv_epilogue (include/senas_hip.h)."""
+    _fields_ = [('scale', C.c_void_p), ('bias', C.c_void_p), ('addend', C.c_void_p), ('add_scale', C.c_void_p),
+                ('relu', C.c_int32)]
+
+
+UNSUPPORTED = -3
+
 _T = MAX_TERMS
 
 
@@ -41,6 +49,7 @@ _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     'senas_conv2d_ws_bytes': (C.c_int64, [_G]),
     'senas_conv2d_fwd': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_fwd_epilogue': (_I, [_G, _P, _P, _P, _I, C.POINTER(ConvEpilogue), _P, _P, _P]),
     'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
     'senas_conv2d_pack_layout': (_I, [_G, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'senas_pack_batched': (_I, [_P, _I, _L, _P]),

@@ -197,8 +197,20 @@ int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* 
 void lds_wgrad_name(const WgradGeom& g, char* buf, int len);
 void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st);
 
+// Inference epilogue of a forward convolution (eval-mode batch-norm folded into the producer, the node sum and ReLU
+// folded into the last producer):  y = act( scale[n][c] * acc + bias[n][c] + add_scale[n][c] * addend[n,p,c] )
+struct Epi {
+    const float* scale;       // [n][cout]
+    const float* bias;        // [n][cout]
+    const float* addend;      // NHWC like the output, or nullptr
+    const float* add_scale;   // [n][cout], or nullptr (= 1)
+    int relu;
+};
+
 // conv_lds.hip (stride-1 "same" convolutions with the input window staged in LDS)
 bool lds_gather_ok(const GatherGeom& g);
+int launch_lds_gather_epi(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const Epi& epi,
+                          hipStream_t st);
 void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len);
 bool lds_gather_s2_ok(const GatherGeom& g);       // stride-2 plain gather (Conv2d forward, ConvTranspose2d data gradient)
 int launch_lds_gather_s2(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,

@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGeom g, const floa
 // ---------------------------------------------------------------------------------------------
 // depthwise.  w: torch layout [c][1][kh][kw] (same indexing for Conv2d and ConvTranspose2d).
 // one thread = 4 channels of one output pixel (c % 4 == 0) or 1 channel.
-template <bool TG, int V>
+template <bool TG, int V, bool EPI = false>
 __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
                                                      const float* __restrict__ w, float* __restrict__ out,
                                                      int in_relu, const float* __restrict__ mask,
-                                                     double* __restrict__ stats, long total, int P) {
+                                                     double* __restrict__ stats, long total, int P, Epi epi = Epi{}) {
     // block b owns P chunks of 256 flat elements; P > 0 means the launcher guarantees the block lies inside one image,
     // so the batch-norm statistics are kept in registers and flushed once per block (common.h)
     extern __shared__ __attribute__((aligned(16))) float wl[];      // weights as [tap][C]: one 16-byte LDS read per tap
@@ -223,6 +223,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             if (mask != nullptr && !(mask[o + j] > 0.f)) acc[j] = 0.f;
+        }
+        if constexpr (EPI) {                       // eval-mode batch-norm (+ ReLU) of DepSepConv's depthwise half
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int pc = n * g.cout + c + j;
+                acc[j] = fmaf(acc[j], epi.scale[pc], epi.bias[pc]);
+                if (epi.relu) acc[j] = fmaxf(acc[j], 0.f);
+            }
         }
         if (active) stv<V>(out + o, acc);
         if constexpr (V == 4) {
@@ -490,6 +498,35 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 0);
     if (!g->transposed) return launch_direct<false>(gg, x, wp, y, in_relu, nullptr, stats, st);
     return launch_direct<true>(gg, x, wp, y, in_relu, nullptr, stats, st);
+}
+
+// forward with the inference epilogue; SENAS_EUNSUPPORTED (nothing launched) when the geometry is not on a kernel
+// that has one -- the caller then runs the plain forward and the fused node pass
+extern "C" int senas_conv2d_fwd_epilogue(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
+                                         const senas_conv_epilogue* e, void* ws, const float* packed, void* stream) {
+    SENAS_REQUIRE(geom_ok(g), "conv2d_fwd_epilogue: inconsistent geometry");
+    SENAS_REQUIRE(x && w && y && e && e->scale && e->bias, "conv2d_fwd_epilogue: null pointer");
+    hipStream_t st = as_stream(stream);
+    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    const Epi epi{e->scale, e->bias, e->addend, e->add_scale, e->relu};
+    if (g->groups != 1) {
+        if (g->co % 4 != 0 || e->addend != nullptr) return SENAS_EUNSUPPORTED;
+        const size_t dw_lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
+        const long total = (long)g->n * g->ho * g->wo * (g->co / 4);
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (g->transposed) hipLaunchKernelGGL((dwconv_kernel<true, 4, true>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, (double*)nullptr, total, 0, epi);
+        else hipLaunchKernelGGL((dwconv_kernel<false, 4, true>), grid, dim3(256), dw_lds, st, gg, x, w, y, in_relu, (const float*)nullptr, (double*)nullptr, total, 0, epi);
+        return launch_status("dwconv_fwd_epilogue");
+    }
+    if (g->transposed || thin_k_ok(gg) || !lds_gather_ok(gg)) return SENAS_EUNSUPPORTED;
+    if (thin_n_ok(gg) && gg.cout <= 4) return SENAS_EUNSUPPORTED;
+    const float* img = packed;
+    if (img == nullptr) {
+        SENAS_REQUIRE(ws, "conv2d_fwd_epilogue: null workspace");
+        launch_pack_mfma(w, reinterpret_cast<float*>(ws), g->co, g->ci, g->kh * g->kw, 1, st);
+        img = reinterpret_cast<float*>(ws);
+    }
+    return launch_lds_gather_epi(gg, x, img, y, in_relu, epi, st);
 }
 
 // data gradient: Conv2d -> transposed gather over dy; ConvTranspose2d -> plain gather over dy

@@ -57,11 +57,12 @@ struct Frag {
 // same kernel.  Block = 64 * RW * KS threads; tile = RW * MT * (32/TWL) image rows x TWL columns.
 // S: stride of a PLAIN gather (1, or 2: Conv2d stride-2 forward, ConvTranspose2d stride-2 data gradient): output pixel
 // (oy, ox) reads window pixel (S*oy + ky*d, S*ox + kx*d), so the window covers S times the tile plus the halo.
-template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1>
+// EPI: the inference epilogue (common.h Epi) instead of the raw store; training instantiations ignore `epi`.
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1, bool EPI = false>
 __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
-                                                       double* __restrict__ stats) {
+                                                       double* __restrict__ stats, Epi epi) {
     constexpr int RPM = 32 / TWL;                        // image rows per MFMA row
     constexpr int TH = RW * MT * RPM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -331,6 +332,24 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
                             if (!(mk.z > 0.f)) val.z = 0.f;
                             if (!(mk.w > 0.f)) val.w = 0.f;
                         }
+                        if constexpr (EPI) {
+                            const int pc = n * g.cout + cot * 32 + c4 * 4;
+                            const float4 sc = *reinterpret_cast<const float4*>(epi.scale + pc);
+                            const float4 bi = *reinterpret_cast<const float4*>(epi.bias + pc);
+                            val.x = fmaf(val.x, sc.x, bi.x); val.y = fmaf(val.y, sc.y, bi.y);
+                            val.z = fmaf(val.z, sc.z, bi.z); val.w = fmaf(val.w, sc.w, bi.w);
+                            if (epi.addend != nullptr) {
+                                const float4 ad = *reinterpret_cast<const float4*>(epi.addend + o);
+                                float4 as = make_float4(1.f, 1.f, 1.f, 1.f);
+                                if (epi.add_scale != nullptr) as = *reinterpret_cast<const float4*>(epi.add_scale + pc);
+                                val.x = fmaf(ad.x, as.x, val.x); val.y = fmaf(ad.y, as.y, val.y);
+                                val.z = fmaf(ad.z, as.z, val.z); val.w = fmaf(ad.w, as.w, val.w);
+                            }
+                            if (epi.relu) {
+                                val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f);
+                                val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f);
+                            }
+                        }
                         *reinterpret_cast<float4*>(out + o) = val;
                     }
                 }
@@ -346,9 +365,15 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
                 if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
                     const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
                     if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
-                    out[o] = val;
                     s += val;
                     q += (double)val * val;
+                    if constexpr (EPI) {
+                        const int pc = n * g.cout + co;
+                        val = fmaf(val, epi.scale[pc], epi.bias[pc]);
+                        if (epi.addend != nullptr) val = fmaf(epi.addend[o], epi.add_scale != nullptr ? epi.add_scale[pc] : 1.f, val);
+                        if (epi.relu) val = fmaxf(val, 0.f);
+                    }
+                    out[o] = val;
                 }
             }
         }
@@ -393,21 +418,21 @@ static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int k
     return fold > bytes ? fold : bytes;
 }
 
-template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1>
+template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1, bool EPI = false>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
-                              const float* mask, double* stats, hipStream_t st) {
+                              const float* mask, double* stats, hipStream_t st, const Epi& epi = Epi{}) {
     constexpr int TH = RW * MT * (32 / TWL);
     const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW, S);
     static bool attr_set = false;
     if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
         attr_set = true;
     }
     dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
-    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
-                       mask, stats);
+    hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
+                       mask, stats, epi);
     return launch_status("conv_lds");
 }
 
@@ -433,6 +458,22 @@ void lds_gather_shape(const GatherGeom& g, int& mt, int& ks, int& rw, int& twl) 
     }
 }
 
+// every (MT, KS, MAXT, RW, TWL) lds_gather_shape can pick; LV(MT, KS, MAXT, RW, TWL) returns from the caller
+#define SENAS_LDS_DISPATCH(LV)                                                                                          \
+    if (rw == 1) {                                                                                                      \
+        if (twl == 32) { if (taps <= 9) LV(1, 4, 3, 1, 32); LV(1, 4, 7, 1, 32); }                                       \
+        if (twl == 16) { if (ks == 1) LV(1, 1, 1, 1, 16); if (taps <= 9) LV(1, 4, 3, 1, 16); LV(1, 4, 7, 1, 16); }      \
+        if (ks == 1) LV(1, 1, 1, 1, 8);                                                                                 \
+        if (taps <= 9) LV(1, 4, 3, 1, 8);                                                                               \
+        LV(1, 4, 7, 1, 8);                                                                                              \
+    }                                                                                                                   \
+    if (mt == 2) LV(2, 1, 1, 4, 32);                                                                                    \
+    if (ks == 4 && taps <= 9) LV(1, 4, 3, 4, 32);                                                                       \
+    if (ks == 4 && taps <= 25) LV(1, 4, 7, 4, 32);                                                                      \
+    if (ks == 2 && taps <= 9) LV(1, 2, 5, 4, 32);                                                                       \
+    if (ks == 2 && taps <= 25) LV(1, 2, 13, 4, 32);                                                                     \
+    LV(1, 1, 1, 4, 32);
+
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st) {
@@ -440,19 +481,19 @@ int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, flo
     lds_gather_shape(g, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;
 #define SENAS_LV(MT_, KS_, MAXT_, RW_, TWL_) return launch_lds_variant<TG, MT_, KS_, MAXT_, 0, RW_, TWL_>(g, in, wp, out, in_relu, mask, stats, st)
-    if (rw == 1) {
-        if (twl == 32) { if (taps <= 9) SENAS_LV(1, 4, 3, 1, 32); SENAS_LV(1, 4, 7, 1, 32); }
-        if (twl == 16) { if (ks == 1) SENAS_LV(1, 1, 1, 1, 16); if (taps <= 9) SENAS_LV(1, 4, 3, 1, 16); SENAS_LV(1, 4, 7, 1, 16); }
-        if (ks == 1) SENAS_LV(1, 1, 1, 1, 8);
-        if (taps <= 9) SENAS_LV(1, 4, 3, 1, 8);
-        SENAS_LV(1, 4, 7, 1, 8);
-    }
-    if (mt == 2) SENAS_LV(2, 1, 1, 4, 32);
-    if (ks == 4 && taps <= 9) SENAS_LV(1, 4, 3, 4, 32);
-    if (ks == 4 && taps <= 25) SENAS_LV(1, 4, 7, 4, 32);
-    if (ks == 2 && taps <= 9) SENAS_LV(1, 2, 5, 4, 32);
-    if (ks == 2 && taps <= 25) SENAS_LV(1, 2, 13, 4, 32);
-    SENAS_LV(1, 1, 1, 4, 32);
+    SENAS_LDS_DISPATCH(SENAS_LV)
+#undef SENAS_LV
+}
+
+// forward convolution with the inference epilogue: same tile choice, EPI twin of the kernel
+int launch_lds_gather_epi(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const Epi& epi,
+                          hipStream_t st) {
+    int mt, ks, rw, twl;
+    lds_gather_shape(g, mt, ks, rw, twl);
+    const int taps = g.kh * g.kw;
+#define SENAS_LV(MT_, KS_, MAXT_, RW_, TWL_) \
+    return launch_lds_variant<false, MT_, KS_, MAXT_, 0, RW_, TWL_, 1, true>(g, in, wp, out, in_relu, nullptr, nullptr, st, epi)
+    SENAS_LDS_DISPATCH(SENAS_LV)
 #undef SENAS_LV
 }
 

@@ -102,8 +102,17 @@ PACKED = {}
 
 
 def _packed(w, direction):
-    img = PACKED.get((w.data_ptr(), direction))
-    return None if img is None else img.data_ptr()
+    """Address of the cached fragment image of ``w``, or None.  An entry only counts while the parameter it was made
+    for is alive and still lives at the address it is filed under: a freed model's addresses get reused by the next
+    model's weights, and its images must not be."""
+    ent = PACKED.get((w.data_ptr(), direction))
+    if ent is None:
+        return None
+    ref, img = ent
+    owner = ref()
+    if owner is None or owner.data_ptr() != w.data_ptr():
+        return None
+    return img.data_ptr()
 
 
 def _span(kind, g, x, w, y):

@@ -6,6 +6,7 @@ repack launch per convolution call (~200 per derived step, ~1 500 per supernet p
 Without a packer every `senas_conv2d_*` call repacks its own weights -- same results, more launches.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -49,7 +50,7 @@ class WeightPacker(object):
         if self.n:
             raw = bytes((_Item * self.n)(*items))
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.entries[0][0].device)
-        self.images = {(w.data_ptr(), d): img for w, d, img in self.entries}
+        self.images = {(w.data_ptr(), d): (weakref.ref(w), img) for w, d, img in self.entries}
 
     def refresh(self):
         """Repack every weight (one launch).  Call after the optimizer changed the weights, before the

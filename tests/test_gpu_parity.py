@@ -869,13 +869,14 @@ def test_derived_random_genotypes_vs_oracle(seed):
 
 
 # ---------------------------------------------------------------------------------------------- inference pass (8f-4)
+@pytest.mark.parametrize('folded', [False, True])
 @pytest.mark.parametrize('graphed', [False, True])
-def test_evaluator_vs_oracle(graphed):
+def test_evaluator_vs_oracle(graphed, folded):
     """The validation / testing pass (experiments/testing_model.py:150-190): eval-mode logits, loss, arg-max masks and
     pixAcc / mIoU / Dice over three batches, eager and HIP-graph replayed, against the oracle run in eval mode."""
     from oracle import senas_ref as R
     from senas_amd.geno_searched import senas_node_4
-    from senas_amd.infer import Evaluator
+    from senas_amd.infer import Evaluator, FoldedEvaluator
     from senas_amd.loss import SegmentationLosses
     from senas_amd.senas_model import SenasModel
     net = SenasModel(2, 1, c=16, depth=4, genotype=senas_node_4)
@@ -892,7 +893,8 @@ def test_evaluator_vs_oracle(graphed):
     xs = torch.randn(3, 2, 1, 64, 64, generator=gen)
     ys = torch.randint(0, 2, (3, 2, 64, 64), generator=gen)
     net = net.to(dev())
-    ev = Evaluator(net, 2, xs[0].to(dev()), ys[0].to(dev()), SegmentationLosses('dice_ce'), use_graph=graphed)
+    ev = (FoldedEvaluator if folded else Evaluator)(net, 2, xs[0].to(dev()), ys[0].to(dev()), SegmentationLosses('dice_ce'),
+                                                    use_graph=graphed)
     assert (ev.graph is not None) == graphed
     ref_loss, tp, fp, fn, acc = 0.0, 0, 0, 0, 0.0
     for b in range(3):
@@ -907,6 +909,8 @@ def test_evaluator_vs_oracle(graphed):
         ref_loss += float(R.dice_ce_loss(ref, ys[b]))
     mean_loss, pix, miou, dice = ev.result()
     assert abs(mean_loss - ref_loss / 3) <= 1e-4 * abs(ref_loss / 3)
+    if folded:
+        assert ev.folded.fused_launches > 20                      # batch-norm really rides in convolution epilogues
     # the metric against the reference formulas on the evaluator's own logits is covered by the metric tests; here:
     # the running-statistics buffers must be untouched by an eval pass, and the figures finite and in range
     for k, v in net.state_dict().items():
@@ -919,3 +923,43 @@ def test_evaluator_vs_oracle(graphed):
     ev.reset()
     ev(xs[0].to(dev()), ys[0].to(dev()))
     assert ev.result() == first                                   # reset really clears the device accumulators
+    ev.packer.uninstall()
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+def test_folded_inference_random_genotypes(seed):
+    """The batch-norm-folded inference forward on derived nets of RANDOM genotypes (every candidate op in every legal
+    position, 'none' and 'identity' included, 3 / 4 nodes, pruned rows), c=16, depth 4, 2x1x64x64, non-trivial running
+    statistics: logits against the oracle in eval mode, and against the module forward in eval mode."""
+    from oracle import senas_ref as R
+    from senas_amd.genotype import Genotype
+    from senas_amd.infer import FoldedForward
+    from senas_amd.senas_model import SenasModel
+    rng = np.random.RandomState(seed)
+    nodes = int(rng.choice([3, 4]))
+    down, up = _random_genotype(rng, nodes)
+    gamma = [int(v) for v in rng.randint(0, 2, 3)]
+    if gamma[1] == 1 and gamma[2] == 0:
+        gamma[2] = 1
+    geno = Genotype(down=down, down_concat=range(2, 2 + nodes), up=up, up_concat=range(2, 2 + nodes), gamma=gamma)
+    net = SenasModel(2, 1, c=16, depth=4, genotype=geno)
+    _randomize(net, seed)
+    gen = torch.Generator().manual_seed(seed)
+    for k, v in net.state_dict().items():
+        if k.endswith('running_mean'):
+            v.copy_(0.2 * torch.randn(v.shape, generator=gen))
+        elif k.endswith('running_var'):
+            v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    gio.share_stem(sd)
+    x = torch.randn(2, 1, 64, 64, generator=gen)
+    with torch.no_grad():
+        ref = R.derived_forward(sd, x, R.Genotype(*geno), depth=4, training=False)[-1]
+    net = net.to(dev()).eval()
+    ff = FoldedForward(net, 2)
+    with torch.no_grad():
+        got = ff(x.to(dev()))[-1]
+        plain = net(x.to(dev()))[-1]
+    close(got, ref.numpy(), 'folded logits %s' % (geno,), rel=1e-3)
+    close(got, plain.cpu().numpy(), 'folded vs module forward', rel=1e-3)
+    assert ff.fused_launches > 0

@@ -142,6 +142,10 @@ class FoldedForward(object):
                 dev = m.weight.device
                 self.affine[id(m)] = (m, torch.empty((batch, m.num_features), device=dev), torch.empty((batch, m.num_features), device=dev))
         self.consts = {}
+        self.const_ids = set()                 # tensors that only change in refresh(): sums of them are cached
+        for _, scale, shift in self.affine.values():
+            self.const_ids.update((id(scale), id(shift)))
+        self.derived = {}                      # key -> (result, recipe) recomputed in place by refresh()
         self.fused_launches = self.fallback_launches = 0
         self.refresh()
 
@@ -151,6 +155,24 @@ class FoldedForward(object):
             s = m.weight.double() / torch.sqrt(m.running_var.double() + m.eps)
             scale.copy_(s.float().expand_as(scale))
             shift.copy_((m.bias.double() - m.running_mean.double() * s).float().expand_as(shift))
+        for out, recipe in self.derived.values():
+            out.copy_(recipe())
+
+    def _cached(self, kind, parts, recipe):
+        """recipe() of constant tensors, computed once and kept current by refresh(); of anything else, computed now."""
+        if not all(id(p) in self.const_ids for p in parts):
+            return recipe()
+        key = (kind,) + tuple(id(p) for p in parts)
+        if key not in self.derived:
+            out = recipe().contiguous()
+            self.derived[key] = (out, recipe)
+            self.const_ids.add(id(out))
+        return self.derived[key][0]
+
+    def _sum(self, parts):
+        if len(parts) == 1:
+            return parts[0]
+        return self._cached('sum', parts, lambda: torch.stack(list(parts)).sum(0))
 
     def _aff(self, bn):
         _, scale, shift = self.affine[id(bn)]
@@ -196,11 +218,12 @@ class FoldedForward(object):
         """act(sum_t scale_t * z_t + shift_t (+ residual)) over raw tensors: one senas_combine_fwd pass."""
         zs = [F.nhwc(r.z) for r in raws]
         n, c, h, w = zs[0].shape
-        coef = torch.stack([r.scale for r in raws]).contiguous()
-        bias = raws[0].shift if len(raws) == 1 else torch.stack([r.shift for r in raws]).sum(0)
+        scales = [r.scale for r in raws]
+        coef = scales[0] if len(raws) == 1 else self._cached('stack', scales, lambda: torch.stack(scales))
+        bias = self._sum([r.shift for r in raws])
         y = F.new_nhwc(n, c, h, w, zs[0])
         zp = (C.c_void_p * len(zs))(*[z.data_ptr() for z in zs])
-        _lib.check(_lib.lib().senas_combine_fwd(n, h * w, c, len(zs), zp, coef.data_ptr(), bias.contiguous().data_ptr(), F._p(residual),
+        _lib.check(_lib.lib().senas_combine_fwd(n, h * w, c, len(zs), zp, coef.data_ptr(), bias.data_ptr(), F._p(residual),
                                                 int(relu), y.data_ptr(), F._stream()), 'senas_combine_fwd')
         self.fallback_launches += 1
         return y
@@ -215,9 +238,7 @@ class FoldedForward(object):
             last = lazies.pop()
             pend = raws + [self._run_lazy(t) for t in lazies]      # everything else is a tensor before the fused launch
             if len(pend) + (1 if residual is not None else 0) <= 1:
-                bias = last.shift
-                for sh in extra + [p.shift for p in pend]:
-                    bias = bias + sh
+                bias = self._sum([last.shift] + extra + [p.shift for p in pend])
                 addend = pend[0].z if pend else residual
                 add_scale = pend[0].scale if pend else None
                 y = self._conv_epilogue(last.conv, last.x, last.in_relu, last.scale, bias, addend, add_scale, relu)
@@ -227,10 +248,7 @@ class FoldedForward(object):
         if not raws:
             raise _lib.SenasHipError('a node whose ops are all \'none\' has no tensor to shape its output')
         if extra:
-            shift = raws[0].shift
-            for sh in extra:
-                shift = shift + sh
-            raws = [_Raw(raws[0].z, raws[0].scale, shift)] + raws[1:]
+            raws = [_Raw(raws[0].z, raws[0].scale, self._sum([raws[0].shift] + extra))] + raws[1:]
         return self._combine(raws, relu, residual)
 
     def _run_lazy(self, t, force_plain=False):
@@ -244,6 +262,7 @@ class FoldedForward(object):
     def _ones(self, like):
         if like.shape[1] not in self.consts:
             self.consts[like.shape[1]] = (torch.ones_like(like), torch.zeros_like(like))
+            self.const_ids.update(id(t) for t in self.consts[like.shape[1]])
         return self.consts[like.shape[1]][0]
 
     def _zeros(self, like):

@@ -923,6 +923,21 @@ def test_evaluator_vs_oracle(graphed, folded):
     ev.reset()
     ev(xs[0].to(dev()), ys[0].to(dev()))
     assert ev.result() == first                                   # reset really clears the device accumulators
+    if folded:
+        # validation between epochs: the weights moved; refresh() must bring the folded constants (and a captured graph,
+        # which reads them in place) up to date
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.mul_(1.1)
+                    m.running_mean.add_(0.05)
+                elif isinstance(m, nn.Conv2d):
+                    m.weight.mul_(0.97)
+        ev.refresh()
+        logits, _ = ev(xs[1].to(dev()), ys[1].to(dev()))
+        with torch.no_grad():
+            want = net(xs[1].to(dev()))[-1]
+        close(logits, want.cpu().numpy(), 'folded logits after refresh', rel=1e-3)
     ev.packer.uninstall()
 
 

@@ -260,6 +260,42 @@ def test_search_step_trajectory():
     assert net.genotype() == gio.geno_from_json(z['genotype'], Genotype)
 
 
+@pytest.mark.parametrize('graphed', [False, True])
+def test_search_step_driver_trajectory(graphed):
+    """The same two search steps through ``SearchStep`` (senas_amd/step.py): architecture pass with frozen weights
+    (no weight-gradient kernels), weight pass, fused clip + SGD -- eager and as two replayed HIP graphs.  The weights
+    and architecture tensors must land where the reference's loop (search_arc.py:252-299) puts them."""
+    from senas_amd.genotype import Genotype
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    from senas_amd.step import SearchStep
+    z = gio.load('search_step')
+    net = NAS(input_c=1, c=8, num_classes=2, depth=5, meta_node_num=3, use_sharing=False, double_down_channel=False,
+              multi_gpus=False, device=dev())
+    load_into(net, gio.unpack(z, 'sd0/')).train()
+    crit = SegmentationLosses('dice_ce')
+    opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
+    opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    xs, ys = torch.from_numpy(z['x']).to(dev()), torch.from_numpy(z['y']).to(dev())
+    step = SearchStep(net, crit, opt_w, opt_a, xs[0].clone(), ys[0].clone(), grad_clip=5.0, use_graph=graphed)
+    assert step.graphed == graphed
+    for k in range(2):
+        loss = step(xs[2 * k + 1], ys[2 * k + 1], xs[2 * k], ys[2 * k])
+        assert abs(float(loss) - float(z['loss%d' % k])) <= 2e-4 * abs(float(z['loss%d' % k]))
+        if k == 0:
+            # the architecture pass left no weight gradient behind: every weight gradient present now is the weight pass's
+            assert all(p.grad is not None for p in net.arch_parameters())
+    got = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    # the capture warm-up passes moved the batch-norm running statistics (never the weights): compare parameters only
+    skip = ('running_mean', 'running_var', 'num_batches_tracked') if graphed else ()
+    for k, e in gio.sub(z, 'sd2full/').items():
+        if not k.endswith(skip) or not skip:
+            close(got[k], e, 'after-step ' + k, rel=1e-3)
+    assert net.genotype() == gio.geno_from_json(z['genotype'], Genotype)
+    step.fb.packer.uninstall()
+
+
+
 # ------------------------------------------------------------------ full-size checks against the oracle
 def _randomize(net, seed):
     gen = torch.Generator().manual_seed(seed)

@@ -723,7 +723,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         static char buf[8][64];
         static int slot = 0;
         char* b = buf[slot++ & 7];
-        snprintf(b, 64, "conv_lds_kernel<false, 1, 4, %d, 0, 1, %d, 2>", gg.kh * gg.kw <= 9 ? 3 : 7, gg.wout >= 16 ? 16 : 8);
+        snprintf(b, 64, "conv_lds_kernel<false, 1, 4, %d, 0, 1, %d, 2, false>", gg.kh * gg.kw <= 9 ? 3 : 7, gg.wout >= 16 ? 16 : 8);
         return b;
     }
     if (mfma_gather_ok(gg, tg)) {

@@ -36,6 +36,10 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
+#ifndef SENAS_XCD_ORDER
+#define SENAS_XCD_ORDER 1
+#endif
+
 template <int MT>
 struct Frag {
     float4 a[2][MT];     // [channel group within the pass][sub-tile]
@@ -73,9 +77,22 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
     const int kg = wv / RW;                              // tap group (wave-uniform)
     const int r = lane & 31, h = lane >> 5;
     const int pr = r / TWL, px = r % TWL;                // this lane's pixel inside its MFMA row
-    const int n = blockIdx.z % g.n, cot = blockIdx.z / g.n;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (linear id b and b + 8 share an L2), so
+    // the k-th workgroup of an XCD takes the k-th tile of that XCD's CONTIGUOUS eighth of the tile list -- neighbouring
+    // tiles, whose windows overlap by the halo, then hit the same L2 instead of fetching the halo once per XCD
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (SENAS_XCD_ORDER) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nblk = gx * gy * gridDim.z;
+        const unsigned lin = bx + gx * (by + gy * bz);
+        const unsigned xcd = lin & 7u, base = nblk >> 3, rem = nblk & 7u;
+        const unsigned lp = xcd * base + (xcd < rem ? xcd : rem) + (lin >> 3);
+        bx = lp % gx;
+        by = (lp / gx) % gy;
+        bz = lp / (gx * gy);
+    }
+    const int n = bz % g.n, cot = bz / g.n;
     const int co = cot * 32 + r;
-    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TWL;
+    const int oy0 = by * TH, ox0 = bx * TWL;
     const int halo = g.pad;                              // = dil * (k / 2) on this path
     static_assert(S == 1 || !TG, "the strided form is a plain gather");
     const int tile_w = S * TWL + 2 * halo, tile_h = S * TH + 2 * halo;
@@ -503,7 +520,7 @@ void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len) {
     lds_gather_shape(g, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;
     const int maxt = ks == 1 ? 1 : (taps <= 9 ? (ks == 4 ? 3 : 5) : (ks == 4 ? 7 : 13));
-    snprintf(buf, len, "conv_lds_kernel<%s, %d, %d, %d, 0, %d, %d>", tg ? "true" : "false", mt, ks, maxt, rw, twl);
+    snprintf(buf, len, "conv_lds_kernel<%s, %d, %d, %d, 0, %d, %d, 1, false>", tg ? "true" : "false", mt, ks, maxt, rw, twl);
 }
 
 // ---- stride-2 plain gather: one 32-pixel MFMA row per block (2 output rows x 16, or 4 x 8), taps on 4 waves

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float
         }
     };
 
+    // XCD-aware tile order: workgroups b and b + 8 share an XCD (round-robin placement), so within every sweep of
+    // gridDim.x tiles an XCD takes a CONTIGUOUS eighth -- neighbouring tiles (overlapping X windows) meet in one L2.
+    // Still a bijection per sweep, so every tile is visited exactly once.
     int tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile < ntiles) issue(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                  // previous tile's readers are done

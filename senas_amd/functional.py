@@ -60,13 +60,29 @@ class KernelTimer(object):
     def span(self, name, flops, nbytes, tag=None):
         return _Span(self, name, flops, nbytes, tag)
 
-    def summary(self):
+    @staticmethod
+    def empty_pair_ms(reps=200):
+        """What a start/stop event pair reads with NOTHING between them (median): the marker-to-marker latency every
+        span includes on top of its kernel."""
+        pairs = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in pairs)[reps // 2]
+
+    def summary(self, overhead_ms=0.0):
+        """Per kernel symbol: launches, total ms (each span less ``overhead_ms``, never below half its reading),
+        algorithmic flops and bytes."""
         torch.cuda.synchronize()
         agg = {}
         for name, flops, nbytes, e0, e1, _ in self.records:
             a = agg.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             a['launches'] += 1
-            a['ms'] += e0.elapsed_time(e1)
+            raw = e0.elapsed_time(e1)
+            a['ms'] += max(raw - overhead_ms, 0.5 * raw)
             a['flops'] += flops
             a['bytes'] += nbytes
         return agg

@@ -1014,3 +1014,91 @@ def test_folded_inference_random_genotypes(seed):
     close(got, ref.numpy(), 'folded logits %s' % (geno,), rel=1e-3)
     close(got, plain.cpu().numpy(), 'folded vs module forward', rel=1e-3)
     assert ff.fused_launches > 0
+
+
+# ------------------------------------------------------------------------------ BASELINE sizes: size-independent properties
+def test_full_size_batch_properties():
+    """BASELINE configs[1] at full size (README genotype, c=32, depth 5, 8x1x256x256) is too big for the CPU oracle to
+    finish in seconds, so it is checked through properties the network has by construction:
+    train mode -- batch statistics do not depend on the order of the images, so permuting the batch permutes the logits
+    and leaves the loss and every parameter gradient where they were;
+    eval mode -- an image's logits do not depend on its batch mates, and the folded inference forward agrees with the
+    module forward."""
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.infer import FoldedForward
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
+    _randomize(net, 3)
+    net = net.to(dev()).train()
+    crit = SegmentationLosses('dice_ce')
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 1, 256, 256, generator=gen).to(dev())
+    y = torch.randint(0, 2, (8, 256, 256), generator=gen).to(dev())
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=dev())
+    runs = []
+    for xx, yy in ((x, y), (x[perm].contiguous(), y[perm].contiguous())):
+        net.zero_grad(set_to_none=True)
+        out = net(xx)[-1]
+        loss = crit([out], yy)
+        loss.backward()
+        runs.append((out.detach(), float(loss.detach()), grads_of(net)))
+    (o0, l0, g0), (o1, l1, g1) = runs
+    close(o1, o0[perm].cpu().numpy(), 'logits of the permuted batch', rel=1e-4)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert set(g0) == set(g1) and len(g0) > 300
+    for k in g0:
+        a, b = g0[k].astype(np.float64), g1[k].astype(np.float64)
+        norm = np.sqrt((a ** 2).sum())
+        if norm > 1e-8:
+            # (a ReLU input within fp32 noise of zero may flip between the two summation orders: L2, not max)
+            assert np.sqrt(((a - b) ** 2).sum()) <= 1e-2 * norm, 'gradient %s moved under a batch permutation' % k
+    net.eval()
+    with torch.no_grad():
+        full = net(x)[-1]
+        one = net(x[2:3].contiguous())[-1]
+        folded = FoldedForward(net, 8)(x)[-1]
+    close(one, full[2:3].cpu().numpy(), 'eval logits of image 2 alone vs inside the batch', rel=1e-5)
+    close(folded, full.cpu().numpy(), 'folded inference forward vs module forward', rel=1e-4)
+    assert bool((folded.argmax(1) == full.argmax(1)).float().mean() > 0.9999)
+
+
+def test_full_size_supernet_batch_properties():
+    """BASELINE configs[2] at full size (NAS supernet, c=32, depth 5, 3 nodes, 4x1x256x256): permuting the batch permutes
+    the logits and leaves the loss, the architecture gradients and the derived genotype where they were; the frozen-weight
+    architecture pass of SearchStep produces the same architecture gradients as the full backward."""
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    torch.manual_seed(11)
+    net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev()).to(dev()).train()
+    with torch.no_grad():
+        for p in net.arch_parameters():
+            p.copy_(0.3 * torch.randn(p.shape, device=dev()))
+    crit = SegmentationLosses('dice_ce')
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 1, 256, 256, generator=gen).to(dev())
+    y = torch.randint(0, 2, (4, 256, 256), generator=gen).to(dev())
+    perm = torch.tensor([2, 0, 3, 1], device=dev())
+    geno = net.genotype()
+    weights = [p for p in net.parameters() if not any(p is a for a in net.arch_parameters())]
+    runs = []
+    for xx, yy, frozen in ((x, y, False), (x[perm].contiguous(), y[perm].contiguous(), False), (x, y, True)):
+        net.zero_grad(set_to_none=True)
+        for p in weights:
+            p.requires_grad_(not frozen)
+        out = net(xx)[-1]
+        loss = crit([out], yy)
+        loss.backward()
+        runs.append((out.detach(), float(loss.detach()), [a.grad.detach().cpu().numpy().astype(np.float64) for a in net.arch_parameters()]))
+        if frozen:
+            assert all(p.grad is None for p in weights)           # no weight-gradient kernel ran
+    for p in weights:
+        p.requires_grad_(True)
+    (o0, l0, a0), (o1, l1, a1), (o2, l2, a2) = runs
+    close(o1, o0[perm].cpu().numpy(), 'supernet logits of the permuted batch', rel=1e-4)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) and abs(l0 - l2) <= 1e-6 * abs(l0)
+    for k, (g0, g1, g2) in enumerate(zip(a0, a1, a2)):
+        scale = np.abs(g0).max()
+        assert np.abs(g0 - g1).max() <= 1e-2 * scale, 'architecture gradient %d moved under a batch permutation' % k
+        assert np.abs(g0 - g2).max() <= 1e-5 * scale, 'architecture gradient %d differs with frozen weights' % k
+    assert net.genotype() == geno

@@ -117,6 +117,16 @@ int senas_maxpool3_bwd(int n, int h, int w, int c, int stride, const float* dy, 
 int senas_bilinear2x_fwd(int n, int h, int w, int c, const float* x, float* y, double* stats, void* stream);
 int senas_bilinear2x_bwd(int n, int h, int w, int c, const float* dy, float* dx, void* stream);
 
+/* ---- channel un-stacking ---------------------------------------------------------------------------
+ * The edges that LEAVE one state of a search cell (search/cell.py:100-106) read the same tensor with the same
+ * geometry, so their same-named candidates run as ONE convolution with the weights stacked along c_out; this splits
+ * its output src [n][hw][k*c] into the k per-edge tensors dst[e] [n][hw][c] the nodes consume, adding the per-image
+ * channel sums of every part into stats[e] (double[n][c][2], caller zeroes; stats or any stats[e] may be NULL).
+ * dst / stats: HOST arrays of k device pointers, k <= SENAS_MAX_STACK.                                          */
+#define SENAS_MAX_STACK 4
+int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* const* dst, double* const* stats,
+                      void* stream);
+
 /* ---- elementwise ReLU (Cell.preprocess1, search/cell.py:66,94; senas_model.py:15,52) ---------- */
 int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream);
 int senas_relu_bwd(int64_t numel, const float* dy, const float* y, float* dx, void* stream);

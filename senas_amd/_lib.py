@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
 MAX_TERMS = 32
+MAX_STACK = 4
 
 
 class ConvGeom(C.Structure):
@@ -61,6 +62,7 @@ SIGNATURES = {
     'senas_maxpool3_bwd': (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'senas_bilinear2x_fwd': (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     'senas_bilinear2x_bwd': (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    'senas_unstack_fwd': (_I, [_I, _L, _I, _I, _P, _PP, _PP, _P]),
     'senas_relu_fwd': (_I, [_L, _P, _P, _P]),
     'senas_relu_bwd': (_I, [_L, _P, _P, _P, _P]),
     'senas_chan_stats': (_I, [_I, _L, _I, _P, _P, _P]),

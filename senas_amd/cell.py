@@ -81,31 +81,95 @@ class Cell(nn.Module):
             cache[key] = mixes
         return cache[key]
 
+    # ------------------------------------------------------------------ state-major execution
+    stacked = True      # run same-named candidates of the edges LEAVING one state as one convolution (class-wide switch)
+
+    def _out_edges(self, j):
+        """Flat indices of the edges that read state j (one per later node)."""
+        out, offset = [], 0
+        for i in range(self._meta_node_num):
+            if j < self._input_num + i:
+                out.append(offset + j)
+            offset += self._input_num + i
+        return out
+
+    @staticmethod
+    def _stacked_conv(convs, x):
+        """ONE convolution for the same-geometry convolutions of k edges that read the same tensor: weights stacked along
+        c_out (autograd's cat hands every edge its slice of the stacked weight gradient), output split per edge."""
+        c0 = convs[0]
+        tr = isinstance(c0, nn.ConvTranspose2d)
+        for c in convs[1:]:
+            if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride, c0.padding,
+                                                                                     c0.dilation, c0.groups):
+                raise F.SenasHipError('stacked candidates disagree in geometry')
+        w = torch.cat([c.weight for c in convs], dim=1 if tr else 0)
+        z, _ = F.conv2d(x, w, stride=c0.stride[0], pad=c0.padding[0], dil=c0.dilation[0], transposed=tr,
+                        out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=False)
+        return z
+
+    def _plan(self, j):
+        """What has to run on state j: ``jobs`` -- callables ``fn(x) -> [(edge, op position, Term)]``, each consuming
+        its own alias of the state -- and ``fixed`` terms that read nothing ('none')."""
+        from .operations import AdapterBlock, ConvBn, ConvBnSe, ZeroOp
+        edges = self._out_edges(j)
+        jobs, fixed = [], []
+        if not edges:
+            return jobs, fixed
+        k = len(edges)
+        nops = len(self._ops[edges[0]]._ops)
+        for p in range(nops):
+            mods = [self._ops[e]._ops[p] for e in edges]
+            m0 = mods[0]
+            if isinstance(m0, AdapterBlock) and isinstance(m0.module, ZeroOp):
+                fixed += [(e, p, m.raw(None)) for e, m in zip(edges, mods)]
+                continue
+            stack = self.stacked and 1 < k <= F.MAX_STACK
+            if stack and isinstance(m0, (ConvBn, ConvBnSe)):
+                def job(x, mods=mods, p=p):
+                    z = self._stacked_conv([m[0] for m in mods], x)
+                    se = isinstance(mods[0], ConvBnSe)
+                    parts = F.unstack(z, len(mods), want_stats=mods[0][1].training or se)
+                    return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
+                jobs.append(job)
+            elif stack and isinstance(m0, AdapterBlock) and m0.c_in != m0.c_ot:
+                def job(x, mods=mods, p=p):
+                    z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(x))     # resampled ONCE for the k edges
+                    parts = F.unstack(z, len(mods), want_stats=mods[0].norm.training)
+                    return [(e, p, F.Term(zz, m.norm, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
+                jobs.append(job)
+            else:
+                for e, m in zip(edges, mods):
+                    jobs.append(lambda x, e=e, m=m, p=p: [(e, p, m.raw(x))])
+        return jobs, fixed
+
     def forward(self, in0, in1, weights_norm, weights_chg, betas):
         mixes = self._node_mixes(weights_norm, weights_chg, betas)
-        # a state feeds every candidate of every outgoing edge (18 consumers for the two cell inputs): hand each
-        # consumer its own alias, so the gradients meet in ONE n-ary sum instead of n-1 autograd accumulations
         nodes, nin = self._meta_node_num, self._input_num
-        uses = [0] * (nin + nodes)
-        offset = 0
-        for i in range(nodes):
-            for j in range(nin + i):
-                uses[j] += len(self._ops[offset + j]._ops)
-            offset += nin + i
+        terms = {}                                  # flat edge index -> [Term per candidate]
         states = []
 
         def add_state(h):
-            k = len(states)
-            states.append(iter(F.fan_out(h, uses[k] + (1 if k >= nin else 0))))
+            # everything that reads this state runs now; every reader (and the output concat) gets its own alias of
+            # it, so that the state's gradient is ONE n-ary sum (functional.fan_out)
+            j = len(states)
+            jobs, fixed = self._plan(j)
+            aliases = F.fan_out(h, len(jobs) + (1 if j >= nin else 0))
+            for e, p, t in fixed:
+                terms.setdefault(e, {})[p] = t
+            for job, x in zip(jobs, aliases):
+                for e, p, t in job(x):
+                    terms.setdefault(e, {})[p] = t
+            states.append(aliases[-1] if j >= nin else None)
 
         add_state(self.preprocess0(in0))
         add_state(self.preprocess1(in1))
         offset = 0
         for i in range(nodes):
-            terms = []
+            node_terms = []
             for j in range(nin + i):
-                edge = self._ops[offset + j]
-                terms += edge.terms([next(states[j]) for _ in edge._ops])
+                by_pos = terms.pop(offset + j)
+                node_terms += [by_pos[p] for p in sorted(by_pos)]
             offset += nin + i
-            add_state(F.bn_combine(terms, mix=mixes[i], relu=True))
-        return self.post_process(torch.cat([next(states[nin + i]) for i in range(nodes)], dim=1))
+            add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True))
+        return self.post_process(torch.cat([states[nin + i] for i in range(nodes)], dim=1))

@@ -357,6 +357,54 @@ extern "C" int senas_bilinear2x_fwd(int n, int h, int w, int c, const float* x, 
     return launch_status("bilinear2x_fwd");
 }
 
+// ---------------------------------------------------------------- channel un-stacking (search cell: stacked candidates)
+// src [n][hw][k*c] -> dst_e [n][hw][c] for e < k, with the producer-side batch-norm statistics of every part.
+// grid.y = part; the element loop and the statistics are those of the other forward kernels.
+struct UnstackParts {
+    float* dst[SENAS_MAX_STACK];
+    double* stats[SENAS_MAX_STACK];
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void unstack_kernel(PoolGeom g, const float* __restrict__ src, UnstackParts parts, int k,
+                                                      long total, int P) {
+    const int e = blockIdx.y;
+    float* __restrict__ dst = parts.dst[e];
+    double* __restrict__ stats = parts.stats[e];
+    SENAS_FWD_LOOP_BEGIN(total, P)
+    int ch, ox, oy, n;
+    decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
+    n_blk = n; ch_thr = ch;
+    const size_t pix = (size_t)(n * g.ho + oy) * g.wo + ox;
+    float v[V];
+    ldv<V>(src + pix * ((size_t)k * g.c) + (size_t)e * g.c + ch, v);
+    if (active) stv<V>(dst + pix * g.c + ch, v);
+    fwd_stats<V>(acc_st, stats, uniform, n, g.c, ch, v, active);
+    SENAS_FWD_LOOP_END(stats, g.c)
+}
+
+extern "C" int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* const* dst, double* const* stats,
+                                 void* stream) {
+    SENAS_REQUIRE(n > 0 && hw > 0 && c > 0 && k >= 1 && k <= SENAS_MAX_STACK && src && dst, "unstack_fwd: bad argument");
+    UnstackParts parts;
+    for (int e = 0; e < SENAS_MAX_STACK; ++e) {
+        parts.dst[e] = e < k ? dst[e] : nullptr;
+        parts.stats[e] = (e < k && stats != nullptr) ? stats[e] : nullptr;
+        SENAS_REQUIRE(e >= k || parts.dst[e] != nullptr, "unstack_fwd: null part");
+    }
+    PoolGeom g{n, 1, (int)hw, c, 1, (int)hw, 1};                     // one row of hw pixels per image
+    SENAS_REQUIRE(hw < 0x7fffffffL, "unstack_fwd: map too large");
+    const int V_ = (c % 4 == 0) ? 4 : 1;
+    const long per_img = hw * (long)(c / V_);
+    const long total = per_img * n;
+    const bool want = stats != nullptr;
+    const int P_ = (V_ == 4 && want) ? stats_chunks_per_block(per_img, c, total) : 0;
+    dim3 grid((unsigned)((total + 256L * (P_ > 0 ? P_ : 1) - 1) / (256L * (P_ > 0 ? P_ : 1))), (unsigned)k);
+    if (V_ == 4) hipLaunchKernelGGL((unstack_kernel<4>), grid, dim3(256), 0, as_stream(stream), g, src, parts, k, total, P_);
+    else hipLaunchKernelGGL((unstack_kernel<1>), grid, dim3(256), 0, as_stream(stream), g, src, parts, k, total, P_);
+    return launch_status("unstack_fwd");
+}
+
 extern "C" int senas_bilinear2x_bwd(int n, int h, int w, int c, const float* dy, float* dx, void* stream) {
     SENAS_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && dy && dx, "bilinear2x_bwd: bad argument");
     PoolGeom g{n, h, w, c, 2 * h, 2 * w, 2};

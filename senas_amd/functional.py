@@ -110,6 +110,7 @@ class _NoSpan(object):
 
 
 TIMER = None
+MAX_STACK = _lib.MAX_STACK
 _NOSPAN = _NoSpan()
 
 # (weight data_ptr, direction) -> packed fragment image kept fresh by senas_amd.packing.WeightPacker;
@@ -394,6 +395,43 @@ class _FanOut(torch.autograd.Function):
 def fan_out(x, n):
     """n aliases of x (n > 1), or [x]."""
     return list(_FanOut.apply(x, n)) if n > 1 else [x]
+
+
+class _Unstack(torch.autograd.Function):
+    """[n, k*c, h, w] -> k tensors [n, c, h, w] (+ their producer-side batch-norm statistics); the backward pass is the
+    channel concatenation of the k gradients."""
+
+    @staticmethod
+    def forward(ctx, z, k, want_stats):
+        z = nhwc(z)
+        n, kc, h, w = z.shape
+        if kc % k != 0 or not 1 <= k <= _lib.MAX_STACK:
+            raise SenasHipError('unstack: %d channels into %d parts' % (kc, k))
+        c = kc // k
+        parts = [new_nhwc(n, c, h, w, z) for _ in range(k)]
+        stats = [new_stats(n, c, z) for _ in range(k)] if want_stats else []
+        dp = (C.c_void_p * k)(*[t.data_ptr() for t in parts])
+        sp = (C.c_void_p * k)(*[t.data_ptr() for t in stats]) if want_stats else None
+        _lib.check(_lib.lib().senas_unstack_fwd(n, h * w, c, k, z.data_ptr(), dp, sp, _stream()), 'senas_unstack_fwd')
+        ctx.k, ctx.shape = k, (n, c, h, w)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*stats)
+        return tuple(parts) + tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = list(grads[:ctx.k])
+        if all(g is None for g in gs):
+            return None, None, None
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else torch.zeros(ctx.shape, device=ref.device, dtype=ref.dtype).contiguous(memory_format=CL) for g in gs]
+        return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None
+
+
+def unstack(z, k, want_stats=True):
+    """The k per-edge parts of a stacked convolution output: [(z_e, stats_e or None)]."""
+    out = _Unstack.apply(z, k, want_stats)
+    return [(out[e], out[k + e] if want_stats else None) for e in range(k)]
 
 
 def chan_stats(z):

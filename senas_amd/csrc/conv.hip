@@ -685,7 +685,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
             if (g->kh == 3) return wg.B <= 2 ? "wgrad_thin_n_kernel<3, 2>" : "wgrad_thin_n_kernel<3, 4>";
             return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";
         }
-        if (wgrad_c8_ok(wg)) return "wgrad_c8_kernel";
+        if (wgrad_c8_ok(wg)) return wg.B <= 8 ? "wgrad_c8_kernel<8>" : "wgrad_c8_kernel<16>";
         if (lds_wgrad_ok(wg)) {
             static char buf[8][48];
             static int slot = 0;

@@ -343,13 +343,15 @@ int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradient with BOTH sides narrow: A = 4 or 8 fine-grid channels, B <= 8 gradient channels (the supernet's
-// 8 -> 8 inner edges; the 32-wide MFMA tile would be 1/16 full).  thread = (role, pixel lane), role = (tap, 4 channels of
-// A): 32 partial sums in registers; the pixel lanes of a role meet in LDS, the blocks' partial rows in the sum launch.
+// weight gradient with BOTH sides narrow: A = 4 or 8 fine-grid channels, B <= BB gradient channels (BB = 8: the
+// supernet's 8 -> 8 inner edges; BB = 16: two of them stacked; the 32-wide MFMA tile would be 1/16 - 1/8 full).
+// thread = (role, pixel lane), role = (tap, 4 channels of A): 4 x BB partial sums in registers; the pixel lanes of a
+// role meet in LDS, the blocks' partial rows in the sum launch.
 //   part[block][(b*A + a)*taps + t]
+template <int BB>
 __global__ __launch_bounds__(256) void wgrad_c8_kernel(WgradGeom g, const float* __restrict__ I, const float* __restrict__ G,
                                                        float* __restrict__ part, int i_relu, int g_relu) {
-    __shared__ float red[256 * 32];
+    __shared__ float red[256 * 4 * BB];
     const int taps = g.kh * g.kw, a4s = g.A >> 2;
     const int R = taps * a4s, L = 256 / R;
     const int role = threadIdx.x % R, pl = threadIdx.x / R;
@@ -359,24 +361,24 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(WgradGeom g, const float*
     const long total = (long)g.n * per_img;
     long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
     if (p1 > total) p1 = total;
-    float acc[4][8];
+    float acc[4][BB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < BB; ++j) acc[i][j] = 0.f;
     if (pl < L) {
         for (long p = p0 + pl; p < p1; p += L) {
             const int n = (int)(p / per_img), r = (int)(p - (long)n * per_img);
             const int gy = r / g.wg, gx = r - gy * g.wg;
             const int iy = gy * g.stride - g.pad + ky * g.dil, ix = gx * g.stride - g.pad + kx * g.dil;
             if (iy < 0 || iy >= g.hi || ix < 0 || ix >= g.wi) continue;
-            float gv[8];
-            if (g.B == 8) {
-                ldv<4>(G + (size_t)p * 8, reinterpret_cast<float(&)[4]>(gv[0]));
-                ldv<4>(G + (size_t)p * 8 + 4, reinterpret_cast<float(&)[4]>(gv[4]));
+            float gv[BB];
+            if (g.B == BB) {
+#pragma unroll
+                for (int j = 0; j < BB; j += 4) ldv<4>(G + (size_t)p * BB + j, reinterpret_cast<float(&)[4]>(gv[j]));
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gv[j] = j < g.B ? G[(size_t)p * g.B + j] : 0.f;
+                for (int j = 0; j < BB; ++j) gv[j] = j < g.B ? G[(size_t)p * g.B + j] : 0.f;
             }
             float iv[4];
             ldv<4>(I + ((size_t)(n * g.hi + iy) * g.wi + ix) * g.A + a4 * 4, iv);
@@ -384,27 +386,27 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(WgradGeom g, const float*
             for (int i = 0; i < 4; ++i) {
                 const float v = i_relu ? fmaxf(iv[i], 0.f) : iv[i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(v, g_relu ? fmaxf(gv[j], 0.f) : gv[j], acc[i][j]);
+                for (int j = 0; j < BB; ++j) acc[i][j] = fmaf(v, g_relu ? fmaxf(gv[j], 0.f) : gv[j], acc[i][j]);
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x * 32 + i * 8 + j] = acc[i][j];
+        for (int j = 0; j < BB; ++j) red[threadIdx.x * (4 * BB) + i * BB + j] = acc[i][j];
     __syncthreads();
     const int n_elem = g.B * g.A * taps;
     for (int e = threadIdx.x; e < n_elem; e += 256) {           // e = (b*A + a)*taps + t
         const int t = e % taps, a = (e / taps) % g.A, b = e / (taps * g.A);
-        const int ro = t * a4s + (a >> 2), idx = (a & 3) * 8 + b;
+        const int ro = t * a4s + (a >> 2), idx = (a & 3) * BB + b;
         float v = 0.f;
-        for (int k = 0; k < L; ++k) v += red[(k * R + ro) * 32 + idx];
+        for (int k = 0; k < L; ++k) v += red[(k * R + ro) * (4 * BB) + idx];
         part[(size_t)blockIdx.x * n_elem + e] = v;
     }
 }
 
 bool wgrad_c8_ok(const WgradGeom& g) {
-    return (g.A == 4 || g.A == 8) && g.B >= 1 && g.B <= 8 && g.kh * g.kw * (g.A >> 2) <= 128;
+    return (g.A == 4 || g.A == 8) && g.B >= 1 && g.B <= 16 && g.kh * g.kw * (g.A >> 2) <= 128;
 }
 
 static long wgrad_c8_blocks(const WgradGeom& g, int& chunk) {
@@ -426,7 +428,8 @@ int launch_wgrad_c8(WgradGeom g, const float* I, const float* G, float* part, in
     int chunk;
     const long nblk = wgrad_c8_blocks(g, chunk);
     g.chunk = chunk;
-    hipLaunchKernelGGL(wgrad_c8_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, I, G, part, i_relu, g_relu);
+    if (g.B <= 8) hipLaunchKernelGGL(wgrad_c8_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, g, I, G, part, i_relu, g_relu);
+    else hipLaunchKernelGGL(wgrad_c8_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, g, I, G, part, i_relu, g_relu);
     *nblk_out = (int)nblk;
     return launch_status("wgrad_c8");
 }

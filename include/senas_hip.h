@@ -92,6 +92,15 @@ int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d
                              int64_t* elems);
 /* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
 int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
+/* Stacked weights of the search cell (see senas_unstack_fwd): item i copies rows x row_len floats from the dense
+ * src into dst rows that are dst_stride floats apart -- every per-edge weight of the model into its slice of a stacked
+ * buffer in ONE launch.  items_dev is a DEVICE array, max_elems = max rows*row_len over the items.                    */
+typedef struct senas_copy_item {
+    const float* src;
+    float* dst;
+    int64_t rows, row_len, dst_stride;
+} senas_copy_item;
+int senas_copy_rows_batched(const senas_copy_item* items_dev, int n, int64_t max_elems, void* stream);
 /* Workspace of the weight gradient: *bytes to allocate and whether it must be zero-filled on entry
  * (*needs_zero != 0; pass ws_is_zero accordingly, or 0 to let the call clear it itself).            */
 int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* bytes, int32_t* needs_zero);

@@ -54,6 +54,7 @@ SIGNATURES = {
     'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
     'senas_conv2d_pack_layout': (_I, [_G, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'senas_pack_batched': (_I, [_P, _I, _L, _P]),
+    'senas_copy_rows_batched': (_I, [_P, _I, _L, _P]),
     'senas_conv2d_bwd_weight_ws': (_I, [_G, _P, _P]),
     'senas_conv2d_bwd_weight': (_I, [_G, _P, _I, _P, _P, _P, _I, _P]),
     'senas_avgpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),

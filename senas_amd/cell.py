@@ -93,17 +93,31 @@ class Cell(nn.Module):
             offset += self._input_num + i
         return out
 
-    @staticmethod
-    def _stacked_conv(convs, x):
+    def _stack(self, convs):
+        """The persistent stacked weight of these convolutions (functional.StackedWeight), made on first use."""
+        stacks = self.__dict__.setdefault('_stacks', {})
+        key = tuple(id(c) for c in convs)
+        if key not in stacks:
+            c0 = convs[0]
+            for c in convs[1:]:
+                if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride,
+                                                                                         c0.padding, c0.dilation, c0.groups):
+                    raise F.SenasHipError('stacked candidates disagree in geometry')
+            stacks[key] = F.StackedWeight([c.weight for c in convs], 1 if isinstance(c0, nn.ConvTranspose2d) else 0)
+        return stacks[key]
+
+    def stacked_weights(self):
+        """Every StackedWeight this cell uses (built without running a forward pass), for the weight packer."""
+        for j in range(self._input_num + self._meta_node_num):
+            self._plan(j)
+        return list(self.__dict__.get('_stacks', {}).values())
+
+    def _stacked_conv(self, convs, x):
         """ONE convolution for the same-geometry convolutions of k edges that read the same tensor: weights stacked along
-        c_out (autograd's cat hands every edge its slice of the stacked weight gradient), output split per edge."""
+        c_out (every edge receives its slice of the stacked weight gradient), output split per edge by the caller."""
         c0 = convs[0]
         tr = isinstance(c0, nn.ConvTranspose2d)
-        for c in convs[1:]:
-            if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride, c0.padding,
-                                                                                     c0.dilation, c0.groups):
-                raise F.SenasHipError('stacked candidates disagree in geometry')
-        w = torch.cat([c.weight for c in convs], dim=1 if tr else 0)
+        w = self._stack(convs).tensor()
         z, _ = F.conv2d(x, w, stride=c0.stride[0], pad=c0.padding[0], dil=c0.dilation[0], transposed=tr,
                         out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=False)
         return z
@@ -126,6 +140,8 @@ class Cell(nn.Module):
                 continue
             stack = self.stacked and 1 < k <= F.MAX_STACK
             if stack and isinstance(m0, (ConvBn, ConvBnSe)):
+                self._stack([m[0] for m in mods])
+
                 def job(x, mods=mods, p=p):
                     z = self._stacked_conv([m[0] for m in mods], x)
                     se = isinstance(mods[0], ConvBnSe)
@@ -133,6 +149,8 @@ class Cell(nn.Module):
                     return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
                 jobs.append(job)
             elif stack and isinstance(m0, AdapterBlock) and m0.c_in != m0.c_ot:
+                self._stack([m.conv for m in mods])
+
                 def job(x, mods=mods, p=p):
                     z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(x))     # resampled ONCE for the k edges
                     parts = F.unstack(z, len(mods), want_stats=mods[0].norm.training)

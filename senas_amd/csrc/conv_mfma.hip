@@ -556,9 +556,36 @@ __global__ void pack_weights_batched_kernel(const PackItem* __restrict__ items) 
     it.dst[i] = v;
 }
 
+// rows x row_len floats from a dense source into rows of a wider destination (the per-edge weights into their slice
+// of a stacked weight buffer): one launch for all items
+struct CopyItem {
+    const float* src;
+    float* dst;
+    long rows, row_len, dst_stride;
+};
+
+__global__ void copy_rows_batched_kernel(const CopyItem* __restrict__ items) {
+    const CopyItem it = items[blockIdx.y];
+    const long total = it.rows * it.row_len;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / it.row_len, c = i - r * it.row_len;
+        it.dst[r * it.dst_stride + c] = it.src[i];
+    }
+}
+
 }  // namespace senas
 
 static_assert(sizeof(senas_pack_item) == sizeof(senas::PackItem), "senas_pack_item layout");
+static_assert(sizeof(senas_copy_item) == sizeof(senas::CopyItem), "senas_copy_item layout");
+
+extern "C" int senas_copy_rows_batched(const senas_copy_item* items_dev, int n, int64_t max_elems, void* stream) {
+    SENAS_REQUIRE(items_dev && n > 0 && max_elems > 0, "copy_rows_batched: bad argument");
+    long blocks = (max_elems + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(senas::copy_rows_batched_kernel, dim3((unsigned)blocks, n), dim3(256), 0, senas::as_stream(stream),
+                       reinterpret_cast<const senas::CopyItem*>(items_dev));
+    return senas::launch_status("copy_rows_batched");
+}
 
 extern "C" int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d0, int32_t* d1, int32_t* swap,
                                         int64_t* elems) {

@@ -397,6 +397,58 @@ def fan_out(x, n):
     return list(_FanOut.apply(x, n)) if n > 1 else [x]
 
 
+class _StackFn(torch.autograd.Function):
+    """The stacked weight buffer as a differentiable function of the per-edge parameters it is assembled from: the
+    forward pass hands out the (already filled) buffer, the backward pass hands every parameter its slice of d buffer."""
+
+    @staticmethod
+    def forward(ctx, buf, dim, *params):
+        ctx.dim, ctx.sizes = dim, [p.shape[dim] for p in params]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, dw):
+        grads, off = [], 0
+        for size in ctx.sizes:
+            grads.append(dw.narrow(ctx.dim, off, size))
+            off += size
+        return (None, None) + tuple(grads)
+
+
+class StackedWeight(object):
+    """Weights of k same-shaped convolutions concatenated along the output-channel dimension in a persistent buffer.
+    Unmanaged (no step driver): refilled on every use, one ``cat`` launch.  Managed by a ``WeightPacker``: the packer
+    refills every stacked buffer of the model (one multi-tensor copy) and repacks its MFMA image together with all
+    other weights at the start of a pass, so using it costs no launch at all."""
+
+    def __init__(self, params, dim):
+        self.params, self.dim = list(params), dim
+        self.buf = None
+        self.managed = False
+
+    def buffer(self):
+        p0 = self.params[0]
+        if self.buf is None or self.buf.device != p0.device:
+            shape = list(p0.shape)
+            shape[self.dim] = sum(p.shape[self.dim] for p in self.params)
+            self.buf = torch.empty(shape, device=p0.device, dtype=p0.dtype)
+            self.managed = False
+        return self.buf
+
+    def slices(self):
+        buf, out, off = self.buffer(), [], 0
+        for p in self.params:
+            out.append(buf.narrow(self.dim, off, p.shape[self.dim]))
+            off += p.shape[self.dim]
+        return out
+
+    def tensor(self):
+        buf = self.buffer()
+        if not self.managed:
+            torch.cat([p.detach() for p in self.params], dim=self.dim, out=buf)
+        return _StackFn.apply(buf, self.dim, *self.params)
+
+
 class _Unstack(torch.autograd.Function):
     """[n, k*c, h, w] -> k tensors [n, c, h, w] (+ their producer-side batch-norm statistics); the backward pass is the
     channel concatenation of the k gradients."""

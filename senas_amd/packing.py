@@ -21,18 +21,41 @@ class _Item(C.Structure):
                 ('swap', C.c_int32), ('elems', C.c_int64)]
 
 
+class _CopyItem(C.Structure):
+    """senas_copy_item (include/senas_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('row_len', C.c_int64), ('dst_stride', C.c_int64)]
+
+
 class WeightPacker(object):
     def __init__(self, model):
         L = _lib.lib()
         self.entries = []            # (weight parameter, direction, image tensor)
         items = []
         seen = set()
-        for m in model.modules():
-            if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) or m.groups != 1 or id(m.weight) in seen:
+        # stacked weight buffers of the search cells (cell.py): filled by refresh(), then packed like any other weight
+        self.stacks = [sw for m in model.modules() if hasattr(m, 'stacked_weights') for sw in m.stacked_weights()]
+        copies = []
+        for sw in self.stacks:
+            buf = sw.buffer()
+            for p, dst in zip(sw.params, sw.slices()):
+                if not p.is_contiguous():
+                    raise _lib.SenasHipError('stacked weights must be contiguous parameters')
+                if sw.dim == 0:                                   # Conv2d [co][ci][kh][kw]: one dense block
+                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), 1, p.numel(), p.numel()))
+                else:                                             # ConvTranspose2d [ci][co][kh][kw]: one row per input channel
+                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), p.shape[0], p.numel() // p.shape[0], buf.stride(0)))
+        self.n_copies = len(copies)
+        self.max_copy = max((it.rows * it.row_len for it in copies), default=0)
+        if copies:
+            raw = bytes((_CopyItem * len(copies))(*copies))
+            self.copy_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.stacks[0].buffer().device)
+        weights = [(m.weight, isinstance(m, nn.ConvTranspose2d)) for m in model.modules()
+                   if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.groups == 1]
+        weights += [(sw.buffer(), sw.dim == 1) for sw in self.stacks]
+        for w, tr in weights:
+            if id(w) in seen:
                 continue
-            seen.add(id(m.weight))
-            w = m.weight
-            tr = isinstance(m, nn.ConvTranspose2d)
+            seen.add(id(w))
             ci, co = (w.shape[0], w.shape[1]) if tr else (w.shape[1], w.shape[0])
             g = F.ConvGeom(1, 8, 8, ci, 8, 8, co, w.shape[2], w.shape[3], 1, 0, 1, int(tr), 1)   # only channel/tap fields matter
             for direction in (0, 1):
@@ -53,15 +76,22 @@ class WeightPacker(object):
         self.images = {(w.data_ptr(), d): (weakref.ref(w), img) for w, d, img in self.entries}
 
     def refresh(self):
-        """Repack every weight (one launch).  Call after the optimizer changed the weights, before the
-        next forward; it is part of the captured graph when the step is graphed."""
+        """Refill the stacked buffers (one launch) and repack every weight (one launch).  Call after the
+        optimizer changed the weights, before the next forward; it is part of the captured graph when the step is graphed."""
+        if self.n_copies:
+            _lib.check(_lib.lib().senas_copy_rows_batched(self.copy_table.data_ptr(), self.n_copies, self.max_copy, F._stream()),
+                       'senas_copy_rows_batched')
         if self.n:
             _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
                        'senas_pack_batched')
 
     def install(self):
         F.PACKED = self.images
+        for sw in self.stacks:
+            sw.managed = True                   # refresh() keeps the buffer current: no cat launch per use
 
     def uninstall(self):
         if F.PACKED is self.images:
             F.PACKED = {}
+        for sw in self.stacks:
+            sw.managed = False

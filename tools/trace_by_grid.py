@@ -17,6 +17,13 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('senas::', '').strip()
+            if name.startswith('at::native'):                     # keep what tells torch's elementwise kernels apart
+                full = r['Kernel_Name']
+                for key in ('Functor_add', 'FillFunctor', 'MulFunctor', 'copy', 'CatArray', 'sigmoid', 'softmax', 'reduce_kernel',
+                            'div', 'sub', 'neg', 'index', 'sum', 'exp', 'threshold', 'clamp'):
+                    if key.lower() in full.lower():
+                        name = 'torch:' + key
+                        break
             if flt and flt not in name:
                 continue
             grid = (r.get('Grid_Size_X') or r.get('Grid_Size'), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'))

@@ -116,12 +116,17 @@ _NOSPAN = _NoSpan()
 # (weight data_ptr, direction) -> packed fragment image kept fresh by senas_amd.packing.WeightPacker;
 # empty: every convolution call repacks its own weights
 PACKED = {}
+# False from the moment an optimizer has moved the weights until the packer refreshes the images again: in between
+# (e.g. a validation forward after a training step) every convolution repacks its own, current, weights
+PACKED_VALID = True
 
 
 def _packed(w, direction):
     """Address of the cached fragment image of ``w``, or None.  An entry only counts while the parameter it was made
     for is alive and still lives at the address it is filed under: a freed model's addresses get reused by the next
     model's weights, and its images must not be."""
+    if not PACKED_VALID:
+        return None
     ent = PACKED.get((w.data_ptr(), direction))
     if ent is None:
         return None
@@ -444,7 +449,7 @@ class StackedWeight(object):
 
     def tensor(self):
         buf = self.buffer()
-        if not self.managed:
+        if not (self.managed and PACKED_VALID):
             torch.cat([p.detach() for p in self.params], dim=self.dim, out=buf)
         return _StackFn.apply(buf, self.dim, *self.params)
 

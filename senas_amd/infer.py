@@ -81,7 +81,7 @@ class Evaluator(object):
         if self.graph is None:
             self.logits, self.mask = self._eager()
         else:
-            self.graph.replay()
+            self.graph.replay()                    # (reads its own packed images by address, whatever F.PACKED_VALID says)
             if self.y is not None:
                 self.metric._acc_n += 1             # the replay ran the captured update launch
         self.batches += 1

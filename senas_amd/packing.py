@@ -84,6 +84,7 @@ class WeightPacker(object):
         if self.n:
             _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
                        'senas_pack_batched')
+        F.PACKED_VALID = True
 
     def install(self):
         F.PACKED = self.images

@@ -9,6 +9,7 @@ capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
 """
 import torch
 
+from . import functional as F
 from . import optim
 from .arena import reset_arena
 from .packing import WeightPacker
@@ -75,6 +76,7 @@ class GraphedForwardBackward(object):
             self.loss = self._eager()
         else:
             self.graph.replay()
+            F.PACKED_VALID = True                  # the replay starts with the packer's refresh launches
             if self.reducer.world > 1:             # reduce_all() re-points p.grad at the flat buffer
                 for p, g in zip(self.reducer.params, self.graph_grads):
                     p.grad = g
@@ -126,10 +128,11 @@ class SearchStep(object):
         self.reducer.finish()
         if self.fused is not None:
             self.fused.step()
-            return loss
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-        self.opt_w.step()
+        else:
+            if self.grad_clip:
+                torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+            self.opt_w.step()
+        F.PACKED_VALID = False                     # the weights moved: the packed / stacked images are stale until the next pass
         return loss
 
 
@@ -149,8 +152,9 @@ class TrainStep(object):
         self.reducer.finish()
         if self.fused is not None:
             self.fused.step()
-            return loss
-        if self.grad_clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-        self.optimizer.step()
+        else:
+            if self.grad_clip:
+                torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+            self.optimizer.step()
+        F.PACKED_VALID = False                     # the weights moved: the packed images are stale until the next pass
         return loss

@@ -1108,3 +1108,43 @@ def test_full_size_supernet_batch_properties():
         assert np.abs(g0 - g1).max() <= 1e-2 * scale, 'architecture gradient %d moved under a batch permutation' % k
         assert np.abs(g0 - g2).max() <= 1e-5 * scale, 'architecture gradient %d differs with frozen weights' % k
     assert net.genotype() == geno
+
+
+@pytest.mark.parametrize('kind', ['derived', 'supernet'])
+def test_eager_forward_after_a_graphed_step_sees_the_new_weights(kind):
+    """A validation forward right after a training step (the drivers do exactly that): the step driver's cached weight
+    images -- MFMA fragment images, stacked search-cell weights -- are one optimizer step old at that point and must not
+    be used.  The eager forward has to agree with an independent copy of the model that never saw a packer."""
+    import copy
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import NAS
+    from senas_amd.step import SearchStep, TrainStep
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 1, 64, 64, generator=gen).to(dev())
+    y = torch.randint(0, 2, (2, 64, 64), generator=gen).to(dev())
+    crit = SegmentationLosses('dice_ce')
+    if kind == 'derived':
+        net = SenasModel(2, 1, c=32, depth=4, genotype=senas_node_4).to(dev()).train()
+        opt = torch.optim.SGD(net.parameters(), lr=5e-2, momentum=0.9)
+        step = TrainStep(net, crit, opt, x, y, use_graph=True)
+        run = step
+    else:
+        net = NAS(1, 32, 2, 3, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev()).to(dev()).train()
+        opt = torch.optim.SGD(net.parameters(), lr=5e-2, momentum=0.9)
+        opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-2)
+        step = SearchStep(net, crit, opt, opt_a, x, y, use_graph=True)
+
+        def run():
+            return step(x, y, x, y)
+    for _ in range(2):
+        run()
+    with torch.no_grad():
+        got = net(x)[-1]
+        twin = copy.deepcopy(net)                  # same weights at fresh addresses: no cached image can match
+        want = twin(x)[-1]
+    close(got, want.cpu().numpy(), 'eager forward after a graphed %s step' % kind, rel=1e-5)
+    run()                                          # and the driver keeps working after the interleaved eager pass
+    step.fb.packer.uninstall()

@@ -130,11 +130,12 @@ def _packed(w, direction):
     ent = PACKED.get((w.data_ptr(), direction))
     if ent is None:
         return None
-    ref, img = ent
-    owner = ref()
-    if owner is None or owner.data_ptr() != w.data_ptr():
+    owner = ent.ref()
+    # (torch's in-place updates -- any torch optimizer -- bump the version counter; the fused SGD kernel does not, which
+    # is what PACKED_VALID is for)
+    if owner is None or owner.data_ptr() != w.data_ptr() or owner._version != ent.version:
         return None
-    return img.data_ptr()
+    return ent.img.data_ptr()
 
 
 def _span(kind, g, x, w, y):
@@ -430,6 +431,13 @@ class StackedWeight(object):
         self.params, self.dim = list(params), dim
         self.buf = None
         self.managed = False
+        self.filled = None                     # the parameters' version counters when a packer last filled the buffer
+
+    def mark_filled(self):
+        self.filled = tuple(p._version for p in self.params)
+
+    def current(self):
+        return self.managed and PACKED_VALID and self.filled == tuple(p._version for p in self.params)
 
     def buffer(self):
         p0 = self.params[0]
@@ -449,7 +457,7 @@ class StackedWeight(object):
 
     def tensor(self):
         buf = self.buffer()
-        if not (self.managed and PACKED_VALID):
+        if not self.current():
             torch.cat([p.detach() for p in self.params], dim=self.dim, out=buf)
         return _StackFn.apply(buf, self.dim, *self.params)
 

@@ -26,6 +26,15 @@ class _CopyItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('row_len', C.c_int64), ('dst_stride', C.c_int64)]
 
 
+class _Image(object):
+    """One cached fragment image: weak reference to the tensor it was made from, the image, and that tensor's version
+    counter when the image was last refreshed on the host's watch."""
+    __slots__ = ('ref', 'img', 'version')
+
+    def __init__(self, w, img):
+        self.ref, self.img, self.version = weakref.ref(w), img, -1
+
+
 class WeightPacker(object):
     def __init__(self, model):
         L = _lib.lib()
@@ -73,7 +82,7 @@ class WeightPacker(object):
         if self.n:
             raw = bytes((_Item * self.n)(*items))
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.entries[0][0].device)
-        self.images = {(w.data_ptr(), d): (weakref.ref(w), img) for w, d, img in self.entries}
+        self.images = {(w.data_ptr(), d): _Image(w, img) for w, d, img in self.entries}
 
     def refresh(self):
         """Refill the stacked buffers (one launch) and repack every weight (one launch).  Call after the
@@ -84,6 +93,11 @@ class WeightPacker(object):
         if self.n:
             _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
                        'senas_pack_batched')
+        for ent in self.images.values():
+            w = ent.ref()
+            ent.version = w._version if w is not None else -1
+        for sw in self.stacks:
+            sw.mark_filled()
         F.PACKED_VALID = True
 
     def install(self):

@@ -1110,6 +1110,34 @@ def test_full_size_supernet_batch_properties():
     assert net.genotype() == geno
 
 
+def test_eager_training_beside_an_installed_packer_sees_the_new_weights():
+    """An Evaluator leaves its weight packer installed; a hand-written training loop (torch optimizer, no step driver)
+    on the same model must not be served the evaluator's images once the weights have moved."""
+    import copy
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.infer import Evaluator
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    torch.manual_seed(22)
+    x = torch.randn(2, 1, 64, 64, device=dev())
+    y = torch.randint(0, 2, (2, 64, 64), device=dev())
+    crit = SegmentationLosses('dice_ce')
+    net = SenasModel(2, 1, c=32, depth=4, genotype=senas_node_4).to(dev())
+    ev = Evaluator(net, 2, x, y, crit, use_graph=False)
+    ev(x, y)
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=5e-2, momentum=0.9)
+    for _ in range(2):
+        opt.zero_grad()
+        crit(net(x), y).backward()
+        opt.step()
+    with torch.no_grad():
+        got = net(x)[-1]
+        want = copy.deepcopy(net)(x)[-1]
+    close(got, want.cpu().numpy(), 'eager forward after eager steps beside an installed packer', rel=1e-5)
+    ev.packer.uninstall()
+
+
 @pytest.mark.parametrize('kind', ['derived', 'supernet'])
 def test_eager_forward_after_a_graphed_step_sees_the_new_weights(kind):
     """A validation forward right after a training step (the drivers do exactly that): the step driver's cached weight

@@ -219,6 +219,10 @@ template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st);
 
+// conv_stem.hip (stem forward: 1..4 input channels, (tap, channel) on the K axis of the fp32 MFMA)
+bool stem_mfma_ok(const GatherGeom& g);
+int launch_stem_mfma(const GatherGeom& g, const float* in, const float* w, float* out, int in_relu, double* stats, hipStream_t st);
+
 // conv_thin.hip (one side of the GEMM view has <= 4 channels: HBM-bound single-pass kernels; weights in torch layout)
 bool thin_k_ok(const GatherGeom& g);
 template <bool TG>

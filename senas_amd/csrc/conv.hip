@@ -463,6 +463,8 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
         }
         return launch_status("dwconv_fwd");
     }
+    // the stem (1..4 input channels, stride 1): (tap, channel) pairs on the K axis of the fp32 MFMA
+    if (!g->transposed && stem_mfma_ok(gg)) return launch_stem_mfma(gg, x, w, y, in_relu, stats, st);
     // thin shapes (stem, head): single-pass HBM-bound kernels that read the torch-layout weights directly
     if (thin_k_ok(gg)) {
         if (!g->transposed) return launch_thin_k<false>(gg, x, w, g->ci, 1, y, in_relu, nullptr, stats, st);
@@ -704,6 +706,13 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
     GatherGeom gg = which == 0 ? GatherGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil}
                                : GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
     const bool tg = (which == 0) == tr;                 // transposed gather: ConvTranspose2d forward, Conv2d data gradient
+    if (which == 0 && !tr && stem_mfma_ok(gg)) {
+        static char buf[8][48];
+        static int slot = 0;
+        char* b = buf[slot++ & 7];
+        snprintf(b, 48, "conv_stem_mfma_kernel<%d, %d>", gg.kh, gg.cin);
+        return b;
+    }
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && thin_n_ok(gg) && (gg.cout <= 4 || tr || !lds_gather_ok(gg))) {
         static char buf[8][48];

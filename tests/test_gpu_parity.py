@@ -460,6 +460,9 @@ _CONV_CASES = [
     (4, 32, 32, 64, 64, 5, 2, 3, False, False),     # 5x5 d3 stride 2, several tiles per block
     (4, 32, 32, 32, 32, 5, 2, 3, True, False),      # ConvTranspose2d 5x5 d3 (dy on the fine grid)
     (2, 32, 32, 8, 8, 5, 2, 2, True, False),        # ... on an 8x8 input (8-wide strided tiles)
+    (2, 3, 32, 40, 72, 7, 1, 1, False, False),      # RGB stem on the MFMA stem kernel (K = 147), ragged tiles
+    (2, 1, 64, 16, 32, 7, 1, 1, False, True),       # stem with 64 outputs (two channel tiles), ReLU on load
+    (2, 2, 32, 24, 40, 3, 1, 2, False, False),      # 2 input channels, dilated 3x3 (K = 18)
     (2, 8, 16, 24, 24, 5, 1, 2, False, False),      # stacked search candidates: two 8 -> 8 inner edges (c8 weight gradient, 16 columns)
     (2, 8, 12, 16, 16, 3, 1, 1, False, True),       # ... 12 columns (padded)
     (2, 32, 24, 32, 32, 5, 1, 3, False, False),     # three 32 -> 8 candidates stacked: 24 outputs; data gradient from 24 channels

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
 // fp64 partials folded over the pixel lanes by shuffles and over the 4 waves through LDS; one fp64 atomic
 // per (n, c) and term per block.  grid = (chunks of `chunk` pixels, n).
 template <int TT, int U>
-__global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, long chunk, int t0, int tt, int nimg, ZTable z,
+__global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, long chunk, int t0, int tt_all, int nimg, ZTable z,
                                                               const float* __restrict__ dy, int dys, const float* __restrict__ y,
                                                               const uint8_t* __restrict__ mask8, int relu, int do_p1,
                                                               double* __restrict__ p1, double* __restrict__ p2) {
@@ -392,6 +392,11 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
     const int n = blockIdx.y;
     long q0 = (long)blockIdx.x * chunk, q1 = q0 + chunk;
     if (q1 > hw) q1 = hw;
+    // `tt` terms starting at t0, TT at a time: nodes with more than TT terms (the search cell: 12 - 24) loop here instead
+    // of costing one launch per group -- the re-read of dy / the mask comes from L2
+    const int tend = t0 + tt_all;
+    for (; t0 < tend; t0 += TT, do_p1 = 0) {
+    const int tt = tend - t0 < TT ? tend - t0 : TT;
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[TT][4];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -464,6 +469,8 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
         for (int wv = 0; wv < nparts; ++wv) v += redv[((size_t)wv * (1 + TT) + k) * c + ch];
         if (k == 0) atomicAdd(p1 + (size_t)n * c + ch, v);
         else atomicAdd(p2 + ((size_t)(t0 + k - 1) * nimg + n) * c + ch, v);
+    }
+    __syncthreads();                                      // the fold scratch is reused by the next group
     }
 }
 
@@ -896,7 +903,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     int t0 = 0, first = 1;
     do {
         const int left = d.nterms - t0;
-        const int tt = left >= 8 ? 8 : left;
+        const int tt = (left >= 8 && !vec) ? 8 : left;          // the vectorised kernel loops over its 8-term groups itself
         if (vec) {
             // pixels per block: a few U-deep iterations of the 256/Q pixel lanes; <= 64 blocks per image so that
             // at most 64 blocks contend for one (n, c) accumulator

@@ -211,6 +211,17 @@ def main():
                 traffic = int((2 * rec['fetch_kb_avg'] + rec['write_kb_avg']) * 1024)
         except (OSError, ValueError, KeyError):
             pass
+        # the same kernel symbol serves several layer shapes: per-geometry rates of its launches (n,hi,wi,ci,ho,wo,co,kh,kw,s,p,d)
+        by_geo = {}
+        for rname, flops, nbytes, e0, e1, tag in timer.records:
+            if rname == name and tag is not None:
+                ms = e0.elapsed_time(e1)
+                b = by_geo.setdefault(tag[1:13], [0, 0.0, 0.0])
+                b[0] += 1
+                b[1] += max(ms - event_overhead_ms, 0.5 * ms)
+                b[2] += flops
+        geo_rows = [{'geometry': ','.join(str(v) for v in k), 'launches': v[0], 'avg_ms': round(v[1] / v[0], 4),
+                     'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(by_geo.items(), key=lambda kv: -kv[1][1])[:4]]
         roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(tflops, 3), 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'launches': a['launches'],
                 'algorithmic_bytes_per_launch': int(a['bytes'] / a['launches']),
@@ -219,6 +230,7 @@ def main():
                 'share_of_step': round((a['ms'] / probe_steps) / (1e3 * elapsed / args.steps), 3),
                 'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / probe_steps, 2),
                 'event_pair_overhead_us': round(1e3 * event_overhead_ms, 2),
+                'by_geometry': geo_rows,
                 'timing_source': 'HIP events around each launch, %d eager steps right after the timed region; every span '
                                  'less the reading of an empty event pair' % probe_steps}
 

@@ -50,17 +50,6 @@ __device__ __forceinline__ void fwd_stats(Stats4& a, double* stats, bool uniform
     }
 }
 
-template <int V>
-__device__ __forceinline__ void add_stats(double* stats, int n, int c, int ch, const float (&v)[V]) {
-    if (stats == nullptr) return;
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        double* st = stats + ((size_t)n * c + ch + j) * 2;
-        atomicAdd(st, (double)v[j]);
-        atomicAdd(st + 1, (double)v[j] * v[j]);
-    }
-}
-
 // ---------------------------------------------------------------- average pool, count_include_pad=False
 template <int V>
 __global__ __launch_bounds__(256) void avgpool3_fwd_kernel(PoolGeom g, const float* __restrict__ x, int in_relu,

@@ -7,10 +7,16 @@ per batch (the reference syncs for ``loss.item()`` and three times inside the me
 Eval mode changes what the kernels do: BatchNorm uses the running statistics, so no producer kernel accumulates
 channel sums (SE blocks excepted: their squeeze still needs the per-image mean), and no node keeps a ReLU mask.
 """
-import torch
+import ctypes as C
 
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import functional as F
 from .arena import reset_arena
 from .metrics import SegmentationMetric
+from .operations import AdapterBlock, BasicBlock, ConvBn, ConvBnSe, DepSepConv, RectifyBlock, ShrinkBlock, ZeroOp, _Rectify
 from .packing import WeightPacker
 
 
@@ -103,15 +109,6 @@ class Evaluator(object):
 # still pending), then op_b's convolution with the epilogue  ReLU(scale_b * acc + shift_b + shift_a + scale_a * z_a).
 # Terms that have no epilogue kernel (pooling, bilinear, transposed / strided / thin convolutions) stay raw and are
 # either the addend of the other term's convolution or, when neither term has one, go through senas_combine_fwd.
-import ctypes as C  # noqa: E402
-
-import torch.nn as nn  # noqa: E402
-
-from . import _lib  # noqa: E402
-from . import functional as F  # noqa: E402
-from .operations import (AdapterBlock, BasicBlock, ConvBn, ConvBnSe, DepSepConv, RectifyBlock, ShrinkBlock, ZeroOp,  # noqa: E402
-                         _Rectify)
-
 
 class _Raw(object):
     """A tensor whose per-(image, channel) affine is still pending: value = scale * z + shift."""

@@ -154,6 +154,38 @@ int senas_bn_finalize(int n, int64_t hw, int c, const double* stats, const float
                       float momentum, float eps, int training,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
 
+/* ---- batched BatchNorm2d + ReLU over k independent tensors of one shape -------------------------------------------
+ * DepSepConv's depthwise half (utils/operations.py:107-115: depthwise conv -> BatchNorm2d(c_in) -> ReLU).  The k
+ * depthwise outputs that leave one state of a search cell share ONE forward launch and TWO backward launches instead of
+ * 1 + 3 each.  Arithmetic as senas_node_fwd / _bwd with one term and relu.  items: HOST array of k descriptors
+ * (k <= SENAS_MAX_BNRELU); tensors [n][hw][c], c % 4 == 0, c <= 64.
+ *   forward : y = relu(BN(z)), mask8 (one byte per 16-byte piece of y), mean_invstd float[2][c] saved for backward;
+ *             training != 0: statistics from stats (double[n][c][2], producer-side sums), running buffers updated.
+ *   backward: dz, dgamma, dbeta from dy (pixel stride dy_pixel_stride floats, 0 = c), z, mask8, mean_invstd;
+ *             sums: double[n][c][2] scratch, zero on entry.                                                          */
+#define SENAS_MAX_BNRELU 8
+typedef struct senas_bnrelu_item {
+    const float* z;
+    float* y;
+    uint8_t* mask8;
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* mean_invstd;
+    const float* dy;
+    int64_t dy_pixel_stride;
+    float* dz;
+    float* dgamma;
+    float* dbeta;
+    double* sums;
+} senas_bnrelu_item;
+int senas_bnrelu_multi_fwd(const senas_bnrelu_item* items, int k, int n, int64_t hw, int c, int training, float momentum,
+                           float eps, void* stream);
+int senas_bnrelu_multi_bwd(const senas_bnrelu_item* items, int k, int n, int64_t hw, int c, void* stream);
+
 /* ---- fused "normalise, gate, mix, add, activate" ------------------------------------------------
  * y[n,p,c] = act( sum_t coef[t][n][c] * z_t[n,p,c] + bias[n][c] (+ residual[n,p,c]) )
  * This single pass replaces, per cell node, the BatchNorm2d of every candidate op, the SE channel

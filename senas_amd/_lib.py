@@ -26,6 +26,15 @@ class ConvEpilogue(C.Structure):
                 ('relu', C.c_int32)]
 
 
+class BnReluItem(C.Structure):
+    """senas_bnrelu_item (include/senas_hip.h)."""
+    _fields_ = [('z', C.c_void_p), ('y', C.c_void_p), ('mask8', C.c_void_p), ('stats', C.c_void_p), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p),
+                ('mean_invstd', C.c_void_p), ('dy', C.c_void_p), ('dy_pixel_stride', C.c_int64), ('dz', C.c_void_p),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('sums', C.c_void_p)]
+
+
+MAX_BNRELU = 8
 UNSUPPORTED = -3
 
 _T = MAX_TERMS
@@ -68,6 +77,8 @@ SIGNATURES = {
     'senas_relu_bwd': (_I, [_L, _P, _P, _P, _P]),
     'senas_chan_stats': (_I, [_I, _L, _I, _P, _P, _P]),
     'senas_bn_finalize': (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
+    'senas_bnrelu_multi_fwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _I, _F, _F, _P]),
+    'senas_bnrelu_multi_bwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _P]),
     'senas_combine_fwd': (_I, [_I, _L, _I, _I, _PP, _P, _P, _P, _I, _P, _P]),
     'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
     'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),

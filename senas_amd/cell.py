@@ -122,16 +122,40 @@ class Cell(nn.Module):
                         out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=False)
         return z
 
+    def _depsep_job(self, items):
+        """DepSepConv candidates (edge, position, module) that read one state: their depthwise convolutions, ONE batched
+        BatchNorm + ReLU over all the depthwise outputs (functional.bnrelu_multi), their pointwise convolutions."""
+        from .operations import run_conv
+
+        def job(xs):
+            zs, sts = [], []
+            for (_, _, m), x in zip(items, xs):
+                z, st = run_conv(m[0], x, want_stats=m[1].training)
+                zs.append(z)
+                sts.append(st)
+            bns = [m[1] for _, _, m in items]
+            if F.bnrelu_multi_ok(zs, bns):
+                mids = F.bnrelu_multi(zs, bns, sts)
+            else:
+                mids = [F.bn_combine([F.Term(z, bn, stats=st)], relu=True) for z, bn, st in zip(zs, bns, sts)]
+            out = []
+            for (e, p, m), mid in zip(items, mids):
+                z2, st2 = run_conv(m[3], mid, want_stats=m[4].training)
+                out.append((e, p, F.Term(z2, m[4], stats=st2)))
+            return out
+        return job
+
     def _plan(self, j):
-        """What has to run on state j: ``jobs`` -- callables ``fn(x) -> [(edge, op position, Term)]``, each consuming
-        its own alias of the state -- and ``fixed`` terms that read nothing ('none')."""
-        from .operations import AdapterBlock, ConvBn, ConvBnSe, ZeroOp
+        """What has to run on state j: ``jobs`` -- pairs ``(fn, a)`` with ``fn(list of a aliases of the state) ->
+        [(edge, op position, Term)]`` -- and ``fixed`` terms that read nothing ('none')."""
+        from .operations import AdapterBlock, ConvBn, ConvBnSe, DepSepConv, ZeroOp
         edges = self._out_edges(j)
         jobs, fixed = [], []
         if not edges:
             return jobs, fixed
         k = len(edges)
         nops = len(self._ops[edges[0]]._ops)
+        depsep = []
         for p in range(nops):
             mods = [self._ops[e]._ops[p] for e in edges]
             m0 = mods[0]
@@ -142,23 +166,28 @@ class Cell(nn.Module):
             if stack and isinstance(m0, (ConvBn, ConvBnSe)):
                 self._stack([m[0] for m in mods])
 
-                def job(x, mods=mods, p=p):
-                    z = self._stacked_conv([m[0] for m in mods], x)
+                def job(xs, mods=mods, p=p):
+                    z = self._stacked_conv([m[0] for m in mods], xs[0])
                     se = isinstance(mods[0], ConvBnSe)
                     parts = F.unstack(z, len(mods), want_stats=mods[0][1].training or se)
                     return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
-                jobs.append(job)
+                jobs.append((job, 1))
             elif stack and isinstance(m0, AdapterBlock) and m0.c_in != m0.c_ot:
                 self._stack([m.conv for m in mods])
 
-                def job(x, mods=mods, p=p):
-                    z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(x))     # resampled ONCE for the k edges
+                def job(xs, mods=mods, p=p):
+                    z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
                     parts = F.unstack(z, len(mods), want_stats=mods[0].norm.training)
                     return [(e, p, F.Term(zz, m.norm, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
-                jobs.append(job)
+                jobs.append((job, 1))
+            elif self.stacked and isinstance(m0, DepSepConv):
+                depsep += [(e, p, m) for e, m in zip(edges, mods)]
             else:
                 for e, m in zip(edges, mods):
-                    jobs.append(lambda x, e=e, m=m, p=p: [(e, p, m.raw(x))])
+                    jobs.append((lambda xs, e=e, m=m, p=p: [(e, p, m.raw(xs[0]))], 1))
+        for i in range(0, len(depsep), F.MAX_BNRELU):
+            chunk = depsep[i:i + F.MAX_BNRELU]
+            jobs.append((self._depsep_job(chunk), len(chunk)))
         return jobs, fixed
 
     def forward(self, in0, in1, weights_norm, weights_chg, betas):
@@ -172,12 +201,14 @@ class Cell(nn.Module):
             # it, so that the state's gradient is ONE n-ary sum (functional.fan_out)
             j = len(states)
             jobs, fixed = self._plan(j)
-            aliases = F.fan_out(h, len(jobs) + (1 if j >= nin else 0))
+            aliases = F.fan_out(h, sum(a for _, a in jobs) + (1 if j >= nin else 0))
             for e, p, t in fixed:
                 terms.setdefault(e, {})[p] = t
-            for job, x in zip(jobs, aliases):
-                for e, p, t in job(x):
+            taken = 0
+            for job, a in jobs:
+                for e, p, t in job(aliases[taken:taken + a]):
                     terms.setdefault(e, {})[p] = t
+                taken += a
             states.append(aliases[-1] if j >= nin else None)
 
         add_state(self.preprocess0(in0))

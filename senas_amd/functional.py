@@ -111,6 +111,7 @@ class _NoSpan(object):
 
 TIMER = None
 MAX_STACK = _lib.MAX_STACK
+MAX_BNRELU = _lib.MAX_BNRELU
 _NOSPAN = _NoSpan()
 
 # (weight data_ptr, direction) -> packed fragment image kept fresh by senas_amd.packing.WeightPacker;
@@ -401,6 +402,108 @@ class _FanOut(torch.autograd.Function):
 def fan_out(x, n):
     """n aliases of x (n > 1), or [x]."""
     return list(_FanOut.apply(x, n)) if n > 1 else [x]
+
+
+class _BnReluMulti(torch.autograd.Function):
+    """relu(BatchNorm2d_t(z_t)) for k independent tensors of one shape in ONE launch (backward: two) --
+    senas_bnrelu_multi_fwd / _bwd.  flat = [z_1..z_k, gamma_1..gamma_k, beta_1..beta_k]."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        k = meta['k']
+        zs = [nhwc(z) for z in flat[:k]]
+        gammas = [_dev(g).contiguous() for g in flat[k:2 * k]]
+        betas = [_dev(b).contiguous() for b in flat[2 * k:3 * k]]
+        n, c, h, w = zs[0].shape
+        dev = zs[0].device
+        tracked = any(ctx.needs_input_grad)
+        ys = [new_nhwc(n, c, h, w, zs[0]) for _ in range(k)]
+        masks = [torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if tracked else None for _ in range(k)]
+        saved = torch.empty((k, 2, c), device=dev, dtype=torch.float32)
+        items = (_lib.BnReluItem * k)()
+        for t in range(k):
+            if tuple(zs[t].shape) != (n, c, h, w):
+                raise SenasHipError('bnrelu_multi: tensors disagree in shape')
+            rm, rv, nbt = meta['buffers'][t]
+            it = items[t]
+            it.z, it.y, it.mask8 = zs[t].data_ptr(), ys[t].data_ptr(), _p(masks[t])
+            it.stats = _p(meta['stats'][t])
+            it.gamma, it.beta = gammas[t].data_ptr(), betas[t].data_ptr()
+            it.running_mean, it.running_var, it.num_batches_tracked = _p(rm), _p(rv), _p(nbt)
+            it.mean_invstd = saved[t].data_ptr()
+        _lib.check(_lib.lib().senas_bnrelu_multi_fwd(items, k, n, h * w, c, int(meta['training']), BN_MOMENTUM, BN_EPS, _stream()),
+                   'senas_bnrelu_multi_fwd')
+        ctx.k, ctx.shape = k, (n, c, h, w)
+        ctx.masks = masks
+        ctx.save_for_backward(saved, *zs, *gammas)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        k = ctx.k
+        n, c, h, w = ctx.shape
+        saved = ctx.saved_tensors[0]
+        zs, gammas = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:1 + 2 * k]
+        dev = saved.device
+        live = [t for t in range(k) if dys[t] is not None]
+        if not live:
+            return (None,) * (1 + 3 * k)
+        need = ctx.needs_input_grad
+        dzs = [torch.empty_like(zs[t], memory_format=CL) if need[1 + t] else None for t in range(k)]
+        dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(k)]
+        dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(k)]
+        sums = zeros64((k, n, c, 2), dev)
+        items = (_lib.BnReluItem * len(live))()
+        keep = []
+        for i, t in enumerate(live):
+            dy = _dev(dys[t])
+            ct = dy.stride(3) if dy.dim() == 4 else 0
+            if (tuple(dy.shape) == (n, c, h, w) and ct > c and ct % 4 == 0 and dy.stride() == (h * w * ct, 1, w * ct, ct) and
+                    dy.data_ptr() % 16 == 0):
+                stride = ct                                   # a channel slice of a wider NHWC tensor, read in place
+            else:
+                dy, stride = nhwc(dy), c
+            keep.append(dy)
+            it = items[i]
+            it.z, it.mask8, it.gamma = zs[t].data_ptr(), ctx.masks[t].data_ptr(), gammas[t].data_ptr()
+            it.mean_invstd = saved[t].data_ptr()
+            it.dy, it.dy_pixel_stride = dy.data_ptr(), stride
+            it.dz, it.dgamma, it.dbeta = _p(dzs[t]), dgs[t].data_ptr(), dbs[t].data_ptr()
+            it.sums = sums[t].data_ptr()
+        _lib.check(_lib.lib().senas_bnrelu_multi_bwd(items, len(live), n, h * w, c, _stream()), 'senas_bnrelu_multi_bwd')
+        dead = [t for t in range(k) if t not in live]
+        for t in dead:
+            dzs[t], dgs[t], dbs[t] = None, None, None
+        return (None,) + tuple(dzs) + tuple(dgs) + tuple(dbs)
+
+
+def bnrelu_multi_ok(zs, bns):
+    """Can these k tensors share the batched BatchNorm + ReLU launches?  (Same shape, 4..64 channels in quads, k <= 8;
+    eval-mode modules only without autograd -- the kernel pair has no eval-mode backward.)"""
+    if not 1 <= len(zs) <= _lib.MAX_BNRELU:
+        return False
+    n, c, h, w = zs[0].shape
+    if c % 4 != 0 or c > 64 or 256 % (c // 4) != 0:
+        return False
+    training = bns[0].training
+    if any(bn.training != training for bn in bns) or any(tuple(z.shape) != (n, c, h, w) for z in zs):
+        return False
+    return training or not (torch.is_grad_enabled() and any(z.requires_grad for z in zs))
+
+
+def bnrelu_multi(zs, bns, stats):
+    """[relu(bn_t(z_t))] for the k (tensor, BatchNorm2d, producer statistics) triples, one launch."""
+    k = len(zs)
+    training = bns[0].training
+    st = list(stats)
+    for t in range(k):
+        if training and st[t] is None:
+            st[t] = chan_stats(zs[t])
+    meta = {'k': k, 'training': training, 'stats': st,
+            'buffers': [(bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn in bns]}
+    flat = list(zs) + [bn.weight for bn in bns] + [bn.bias for bn in bns]
+    return list(_BnReluMulti.apply(meta, *flat))
 
 
 class _StackFn(torch.autograd.Function):

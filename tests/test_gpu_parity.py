@@ -1179,3 +1179,64 @@ def test_eager_forward_after_a_graphed_step_sees_the_new_weights(kind):
     close(got, want.cpu().numpy(), 'eager forward after a graphed %s step' % kind, rel=1e-5)
     run()                                          # and the driver keeps working after the interleaved eager pass
     step.fb.packer.uninstall()
+
+
+@pytest.mark.parametrize('case', [(3, 2, 32, 12, 20, True, False), (6, 4, 32, 16, 16, True, True), (2, 2, 8, 9, 7, True, False),
+                                  (8, 1, 64, 8, 8, True, True), (1, 3, 16, 5, 5, True, False), (4, 2, 32, 8, 12, False, False)])
+def test_bnrelu_multi_vs_torch(case):
+    """senas_bnrelu_multi_fwd / _bwd (k independent BatchNorm2d + ReLU in one launch) against float64 torch: outputs, running
+    buffers, dz / dgamma / dbeta; with the upstream gradient arriving as a channel slice of a wider tensor (strided)."""
+    from senas_amd import functional as F
+    k, n, c, h, w, training, strided = case
+    gen = torch.Generator().manual_seed(sum(case[:5]))
+    bns = [nn.BatchNorm2d(c) for _ in range(k)]
+    zs, refs = [], []
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.copy_(1.0 + 0.3 * torch.randn(c, generator=gen))
+            bn.bias.copy_(0.3 * torch.randn(c, generator=gen))
+            bn.running_mean.copy_(0.2 * torch.randn(c, generator=gen))
+            bn.running_var.copy_(0.5 + torch.rand(c, generator=gen))
+        bn.train(training)
+        z = (0.5 + torch.randn(n, c, h, w, generator=gen)) * 1.5
+        zs.append(z)
+        ref_bn = nn.BatchNorm2d(c).double()
+        ref_bn.load_state_dict({kk: (v.double() if v.is_floating_point() else v.clone()) for kk, v in bn.state_dict().items()})
+        ref_bn.train(training)
+        refs.append(ref_bn)
+    wide = [torch.randn(n, 3 * c, h, w, generator=gen) for _ in range(k)]
+    # float64 reference
+    want = []
+    for z, ref_bn, wd in zip(zs, refs, wide):
+        zz = z.double().requires_grad_(True)
+        y = torch.relu(ref_bn(zz))
+        (y * wd[:, c:2 * c].double()).sum().backward()
+        want.append((y.detach(), zz.grad, ref_bn.weight.grad, ref_bn.bias.grad, ref_bn.running_mean, ref_bn.running_var))
+    dbns = [bn.to(dev()) for bn in bns]
+    dz_in = [z.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for z in zs]
+    assert F.bnrelu_multi_ok(dz_in, dbns) == training          # eval-mode modules only without autograd
+    if not training:
+        with torch.no_grad():
+            ys = F.bnrelu_multi(dz_in, dbns, [None] * k)
+        for y, wnt in zip(ys, want):
+            close(y, wnt[0].numpy(), 'eval output', rel=2e-5)
+        return
+    ys = F.bnrelu_multi(dz_in, dbns, [None] * k)
+    loss = 0
+    for y, wd in zip(ys, wide):
+        wdev = wd.to(dev()).contiguous(memory_format=torch.channels_last)
+        if strided:
+            cat = torch.cat([torch.zeros_like(y), y, torch.zeros_like(y)], dim=1)        # dy of y = a channel slice of d cat
+            loss = loss + (cat * wdev).sum()
+        else:
+            loss = loss + (y * wdev[:, c:2 * c]).sum()
+    loss.backward()
+    for t in range(k):
+        y, dz, dg, db, rm, rv = want[t]
+        close(ys[t], y.numpy(), 'output %d' % t, rel=2e-5)
+        close(dz_in[t].grad, dz.numpy(), 'dz %d' % t, rel=2e-4)
+        close(dbns[t].weight.grad, dg.numpy(), 'dgamma %d' % t, rel=2e-4)
+        close(dbns[t].bias.grad, db.numpy(), 'dbeta %d' % t, rel=2e-4)
+        close(dbns[t].running_mean, rm.numpy(), 'running_mean %d' % t, rel=2e-5)
+        close(dbns[t].running_var, rv.numpy(), 'running_var %d' % t, rel=2e-5)
+        assert int(dbns[t].num_batches_tracked) == 1

@@ -154,6 +154,22 @@ int senas_bn_finalize(int n, int64_t hw, int c, const double* stats, const float
                       float momentum, float eps, int training,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
 
+/* ---- k depthwise convolutions of ONE input -----------------------------------------------------------------------
+ * The same-named DepSepConv candidates (utils/operations.py:107-115) of the edges that leave one state of a search
+ * cell: one input x, k depthwise weight sets w[p] ([c][1][kh][kw]), k outputs.  One launch forward; the data gradient
+ * dx = sum_p dgrad(dy[p], w[p]) in one launch; the k weight gradients in two.  w / y / stats / dy / dw: HOST arrays of
+ * k pointers, k <= SENAS_MAX_DWMULTI.  g describes ONE of the convolutions (groups == ci == co).  Returns
+ * SENAS_EUNSUPPORTED (nothing launched) off the fast path (channels not a power-of-two multiple of 4, taps not 3x3 / 5x5);
+ * ws: senas_dwconv_multi_ws_bytes(g, k) bytes of scratch (per-block partial sums, overwritten).                       */
+#define SENAS_MAX_DWMULTI 4
+int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
+                           double* const* stats, void* stream);
+int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
+                                void* stream);
+int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k);
+int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
+                                  void* ws, void* stream);
+
 /* ---- batched BatchNorm2d + ReLU over k independent tensors of one shape -------------------------------------------
  * DepSepConv's depthwise half (utils/operations.py:107-115: depthwise conv -> BatchNorm2d(c_in) -> ReLU).  The k
  * depthwise outputs that leave one state of a search cell share ONE forward launch and TWO backward launches instead of

@@ -126,13 +126,22 @@ class Cell(nn.Module):
         """DepSepConv candidates (edge, position, module) that read one state: their depthwise convolutions, ONE batched
         BatchNorm + ReLU over all the depthwise outputs (functional.bnrelu_multi), their pointwise convolutions."""
         from .operations import run_conv
+        # depthwise convolutions of the same geometry (dep_sep_conv_3 of every edge, dep_sep_conv_5 of every edge) read the
+        # same state: one batched launch per group (functional.dwconv_multi), one alias of the state per group
+        groups = {}
+        for idx, (_, p, _) in enumerate(items):
+            groups.setdefault(p, []).append(idx)
+        groups = list(groups.values())
 
         def job(xs):
-            zs, sts = [], []
-            for (_, _, m), x in zip(items, xs):
-                z, st = run_conv(m[0], x, want_stats=m[1].training)
-                zs.append(z)
-                sts.append(st)
+            zs, sts = [None] * len(items), [None] * len(items)
+            for idxs, x in zip(groups, xs):
+                mods = [items[i][2] for i in idxs]
+                parts = F.dwconv_multi(x, [m[0] for m in mods], mods[0][1].training) if len(idxs) > 1 else None
+                if parts is None:                            # off the batched path: one by one (x is read-only: sharing it is fine)
+                    parts = [run_conv(m[0], x, want_stats=m[1].training) for m in mods]
+                for i, (z, st) in zip(idxs, parts):
+                    zs[i], sts[i] = z, st
             bns = [m[1] for _, _, m in items]
             if F.bnrelu_multi_ok(zs, bns):
                 mids = F.bnrelu_multi(zs, bns, sts)
@@ -143,7 +152,7 @@ class Cell(nn.Module):
                 z2, st2 = run_conv(m[3], mid, want_stats=m[4].training)
                 out.append((e, p, F.Term(z2, m[4], stats=st2)))
             return out
-        return job
+        return job, len(groups)
 
     def _plan(self, j):
         """What has to run on state j: ``jobs`` -- pairs ``(fn, a)`` with ``fn(list of a aliases of the state) ->
@@ -187,7 +196,7 @@ class Cell(nn.Module):
                     jobs.append((lambda xs, e=e, m=m, p=p: [(e, p, m.raw(xs[0]))], 1))
         for i in range(0, len(depsep), F.MAX_BNRELU):
             chunk = depsep[i:i + F.MAX_BNRELU]
-            jobs.append((self._depsep_job(chunk), len(chunk)))
+            jobs.append(self._depsep_job(chunk))
         return jobs, fixed
 
     def forward(self, in0, in1, weights_norm, weights_chg, betas):

@@ -170,10 +170,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGeom g, const floa
 // depthwise.  w: torch layout [c][1][kh][kw] (same indexing for Conv2d and ConvTranspose2d).
 // one thread = 4 channels of one output pixel (c % 4 == 0) or 1 channel.
 template <bool TG, int V, bool EPI = false>
-__global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
-                                                     const float* __restrict__ w, float* __restrict__ out,
-                                                     int in_relu, const float* __restrict__ mask,
-                                                     double* __restrict__ stats, long total, int P, Epi epi = Epi{}) {
+__device__ __forceinline__ void dwconv_body(const GatherGeom& g, const float* __restrict__ in,
+                                            const float* __restrict__ w, float* __restrict__ out,
+                                            int in_relu, const float* __restrict__ mask,
+                                            double* __restrict__ stats, long total, int P, const Epi& epi) {
     // block b owns P chunks of 256 flat elements; P > 0 means the launcher guarantees the block lies inside one image,
     // so the batch-norm statistics are kept in registers and flushed once per block (common.h)
     extern __shared__ __attribute__((aligned(16))) float wl[];      // weights as [tap][C]: one 16-byte LDS read per tap
@@ -249,6 +249,67 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
     if constexpr (V == 4) stats_flush4(acc_st, stats, uniform, n_blk, g.cout, c_thr);
 }
 
+template <bool TG, int V, bool EPI = false>
+__global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
+                                                     const float* __restrict__ w, float* __restrict__ out,
+                                                     int in_relu, const float* __restrict__ mask,
+                                                     double* __restrict__ stats, long total, int P, Epi epi = Epi{}) {
+    dwconv_body<TG, V, EPI>(g, in, w, out, in_relu, mask, stats, total, P, epi);
+}
+
+// k depthwise convolutions of ONE input with k weight sets (the same-named DepSepConv candidates of the edges leaving
+// a search-cell state): blockIdx.y = problem
+struct DwTab {
+    const float* a[SENAS_MAX_DWMULTI];      // per-problem operand (forward: unused; weight gradient: the per-problem side)
+    const float* w[SENAS_MAX_DWMULTI];
+    float* out[SENAS_MAX_DWMULTI];
+    double* stats[SENAS_MAX_DWMULTI];
+};
+
+template <bool TG>
+__global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom g, const float* __restrict__ in, DwTab tab, long total, int P) {
+    const int p = blockIdx.y;
+    dwconv_body<TG, 4, false>(g, in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
+}
+
+// data gradient of the same: dx = sum over problems of the (transposed / plain) gather of dy_p with w_p, one pass
+template <bool TG>
+__global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom g, DwTab tab, int k, float* __restrict__ out, long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C]
+    const int taps = g.kh * g.kw, C = g.cout;
+    for (int i = threadIdx.x; i < k * taps * C; i += 256) {
+        const int p = i / (taps * C), r = i - p * taps * C, t = r / C, cc = r - t * C;
+        wl[i] = tab.w[p][cc * taps + t];
+    }
+    __syncthreads();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / 4;
+    const int c = (int)(idx % cv) * 4;
+    long pix = idx / cv;
+    const int ox = (int)(pix % g.wout);
+    pix /= g.wout;
+    const int oy = (int)(pix % g.hout), n = (int)(pix / g.hout);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < g.kh; ++ky) {
+        int iy;
+        if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
+        for (int kx = 0; kx < g.kw; ++kx) {
+            int ix;
+            if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
+            const size_t off = ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
+            for (int p = 0; p < k; ++p) {
+                float v[4], wt[4];
+                ldv<4>(tab.a[p] + off, v);
+                ldv<4>(wl + ((size_t)p * taps + ky * g.kw + kx) * C + c, wt);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
+            }
+        }
+    }
+    stv<4>(out + (((size_t)n * g.hout + oy) * g.wout + ox) * C + c, acc);
+}
+
 // depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
 // grid = pixel chunks; block = rows x C lanes (C <= 256); every thread keeps one partial per tap, so
 // G is read once and the taps' I reads hit L1.
@@ -308,9 +369,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const fl
 //          pixel lanes of the wave by shuffles and over the 4 waves through LDS -> part[block][c][tap]
 // stage 2: dw[c][tap] = sum over blocks (fixed order: bitwise reproducible)
 template <int KS>
-__global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, const float* __restrict__ I,
-                                                                const float* __restrict__ G, float* __restrict__ part,
-                                                                int i_relu, int g_relu) {
+__device__ __forceinline__ void dwconv_wgrad_part_body(const WgradGeom& g, const float* __restrict__ I,
+                                                       const float* __restrict__ G, float* __restrict__ part,
+                                                       int i_relu, int g_relu) {
     constexpr int TAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves x row slots][c4 groups][TAPS][4]
     const int C = g.A, C4 = C >> 2;
@@ -383,9 +444,41 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, con
     SENAS_PHASE(4);
 }
 
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_part_kernel(WgradGeom g, const float* __restrict__ I,
+                                                                const float* __restrict__ G, float* __restrict__ part,
+                                                                int i_relu, int g_relu) {
+    dwconv_wgrad_part_body<KS>(g, I, G, part, i_relu, g_relu);
+}
+
+// k problems that share one side (x) and differ in the other (dy_p): blockIdx.y = problem
+struct DwWgradTab {
+    const float* I[SENAS_MAX_DWMULTI];
+    const float* G[SENAS_MAX_DWMULTI];
+    float* part[SENAS_MAX_DWMULTI];
+    float* dw[SENAS_MAX_DWMULTI];
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void dwconv_wgrad_part_multi_kernel(WgradGeom g, DwWgradTab tab) {
+    const int p = blockIdx.y;
+    dwconv_wgrad_part_body<KS>(g, tab.I[p], tab.G[p], tab.part[p], 0, 0);
+}
+
 // one wave per output element: lanes stride over the blocks' partials, fixed-order shuffle tree at the end
 __global__ __launch_bounds__(256) void dwconv_wgrad_sum_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                int n_elem, int n_blocks) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_elem) return;
+    float v = 0.f;
+    for (int b = lane; b < n_blocks; b += 64) v += part[(size_t)b * n_elem + i];
+    v = wave_sum(v);
+    if (lane == 0) dw[i] = v;
+}
+
+__global__ __launch_bounds__(256) void dwconv_wgrad_sum_multi_kernel(DwWgradTab tab, int n_elem, int n_blocks) {
+    const float* __restrict__ part = tab.part[blockIdx.y];
+    float* __restrict__ dw = tab.dw[blockIdx.y];
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_elem) return;
     float v = 0.f;
@@ -744,4 +837,101 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         return tg ? "conv_mfma_kernel<true, 1, 1>" : "conv_mfma_kernel<false, 1, 1>";
     }
     return tg ? "conv_direct_kernel<TG>" : "conv_direct_kernel";
+}
+
+// ---- k depthwise convolutions of one input (the same-named DepSepConv candidates of the edges leaving a state) ------------
+namespace {
+bool dw_multi_ok(const senas_conv_geom* g, int k) {
+    if (!senas::geom_ok(g) || g->groups == 1 || k < 1 || k > SENAS_MAX_DWMULTI) return false;
+    const int c4 = g->ci / 4, taps = g->kh * g->kw;
+    if (g->ci % 4 != 0 || (c4 & (c4 - 1)) != 0 || c4 > 64) return false;
+    if (g->kh != g->kw || (g->kh != 3 && g->kh != 5)) return false;
+    return (size_t)k * taps * g->ci * sizeof(float) <= 60 * 1024 && (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 16 <= 64 * 1024;
+}
+
+long dw_multi_wgrad_blocks(const senas_conv_geom* g, int* chunk) {
+    const long total = (long)g->n * (g->transposed ? (long)g->hi * g->wi : (long)g->ho * g->wo);
+    const long lanes = 256 / (g->ci / 4);
+    long nblk = (total + 2 * lanes - 1) / (2 * lanes);
+    if (nblk > 2048) nblk = 2048;
+    *chunk = (int)((total + nblk - 1) / nblk);
+    return (total + *chunk - 1) / *chunk;
+}
+}  // namespace
+
+extern "C" int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
+                                      double* const* stats, void* stream) {
+    using namespace senas;
+    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && w && y, "dwconv_multi_fwd: null pointer");
+    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    DwTab tab{};
+    bool want = stats != nullptr;
+    for (int p = 0; p < k; ++p) {
+        SENAS_REQUIRE(w[p] && y[p], "dwconv_multi_fwd: null pointer");
+        tab.w[p] = w[p]; tab.out[p] = y[p]; tab.stats[p] = want ? stats[p] : nullptr;
+        want = want && tab.stats[p] != nullptr;
+    }
+    const long per_img = (long)g->ho * g->wo * (g->co / 4);
+    const long total = per_img * g->n;
+    const int P = want ? stats_chunks_per_block(per_img, g->co, total) : 0;
+    dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))), k);
+    const size_t lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
+    if (g->transposed) hipLaunchKernelGGL((dwconv_multi_fwd_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
+    else hipLaunchKernelGGL((dwconv_multi_fwd_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
+    return launch_status("dwconv_multi_fwd");
+}
+
+extern "C" int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
+                                           void* stream) {
+    using namespace senas;
+    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(dy && w && dx, "dwconv_multi_bwd_data: null pointer");
+    GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    DwTab tab{};
+    for (int p = 0; p < k; ++p) {
+        SENAS_REQUIRE(dy[p] && w[p], "dwconv_multi_bwd_data: null pointer");
+        tab.a[p] = dy[p]; tab.w[p] = w[p];
+    }
+    const long total = (long)g->n * g->hi * g->wi * (g->ci / 4);
+    const size_t lds = (size_t)k * g->kh * g->kw * g->ci * sizeof(float);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (!g->transposed) hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);
+    else hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);
+    return launch_status("dwconv_multi_bwd_data");
+}
+
+extern "C" int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k) {
+    if (!dw_multi_ok(g, k)) return 0;
+    int chunk;
+    return (int64_t)k * dw_multi_wgrad_blocks(g, &chunk) * g->ci * g->kh * g->kw * sizeof(float) + 256;
+}
+
+extern "C" int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
+                                             void* ws, void* stream) {
+    using namespace senas;
+    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && dy && dw && ws, "dwconv_multi_bwd_weight: null pointer");
+    const int taps = g->kh * g->kw, c4 = g->ci / 4;
+    WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
+                                  : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    int chunk;
+    const long nblk = dw_multi_wgrad_blocks(g, &chunk);
+    wg.chunk = chunk;
+    DwWgradTab tab{};
+    const size_t per = (size_t)nblk * g->ci * taps;
+    for (int p = 0; p < k; ++p) {
+        SENAS_REQUIRE(dy[p] && dw[p], "dwconv_multi_bwd_weight: null pointer");
+        tab.I[p] = g->transposed ? dy[p] : x;              // fine-grid operand
+        tab.G[p] = g->transposed ? x : dy[p];              // coarse-grid operand
+        tab.part[p] = reinterpret_cast<float*>(ws) + (size_t)p * per;
+        tab.dw[p] = dw[p];
+    }
+    hipStream_t st = as_stream(stream);
+    const size_t lds = (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 4 * sizeof(float);
+    if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<3>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
+    else hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<5>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
+    const int n_elem = g->ci * taps;
+    hipLaunchKernelGGL(dwconv_wgrad_sum_multi_kernel, dim3((n_elem + 3) / 4, k), dim3(256), 0, st, tab, n_elem, (int)nblk);
+    return launch_status("dwconv_multi_bwd_weight");
 }

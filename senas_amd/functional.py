@@ -404,6 +404,75 @@ def fan_out(x, n):
     return list(_FanOut.apply(x, n)) if n > 1 else [x]
 
 
+class _DwMulti(torch.autograd.Function):
+    """k depthwise convolutions of ONE input (senas_dwconv_multi_*): outputs z_1..z_k (+ their statistics); the backward
+    pass produces dx = sum_p dgrad_p in one launch and the k weight gradients in two."""
+
+    @staticmethod
+    def forward(ctx, x, geom, want_stats, *ws):
+        k = len(ws)
+        x = nhwc(x)
+        ws = [_dev(w).contiguous() for w in ws]
+        g = geom
+        ys = [new_nhwc(g.n, g.co, g.ho, g.wo, x) for _ in range(k)]
+        stats = [new_stats(g.n, g.co, x) for _ in range(k)] if want_stats else []
+        wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
+        yp = (C.c_void_p * k)(*[y.data_ptr() for y in ys])
+        sp = (C.c_void_p * k)(*[s.data_ptr() for s in stats]) if want_stats else None
+        _lib.check(_lib.lib().senas_dwconv_multi_fwd(C.byref(g), k, x.data_ptr(), wp, yp, sp, _stream()), 'senas_dwconv_multi_fwd')
+        ctx.g, ctx.k = g, k
+        ctx.save_for_backward(x, *ws)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*stats)
+        return tuple(ys) + tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g, k, L = ctx.g, ctx.k, _lib.lib()
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dys = list(grads[:k])
+        if all(d is None for d in dys):
+            return (None,) * (3 + k)
+        dys = [nhwc(d) if d is not None else torch.zeros((g.n, g.co, g.ho, g.wo), device=x.device).contiguous(memory_format=CL) for d in dys]
+        dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=CL)
+            wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
+            _lib.check(L.senas_dwconv_multi_bwd_data(C.byref(g), k, dyp, wp, dx.data_ptr(), _stream()), 'senas_dwconv_multi_bwd_data')
+        dws = [None] * k
+        if any(ctx.needs_input_grad[3:]):
+            dws = [torch.empty_like(w) for w in ws]
+            scratch = torch.empty(int(L.senas_dwconv_multi_ws_bytes(C.byref(g), k)), device=x.device, dtype=torch.uint8)
+            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dws])
+            _lib.check(L.senas_dwconv_multi_bwd_weight(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), _stream()),
+                       'senas_dwconv_multi_bwd_weight')
+        return (dx, None, None) + tuple(dws)
+
+
+def dwconv_multi(x, convs, want_stats):
+    """[(z_p, stats_p)] of k same-geometry depthwise convolutions of one tensor, or None when the shape is off the
+    batched path (the caller then runs them one by one)."""
+    k = len(convs)
+    c0 = convs[0]
+    if not 2 <= k <= _lib.MAX_DWMULTI or c0.groups != c0.in_channels or c0.in_channels != c0.out_channels:
+        return None
+    tr = isinstance(c0, torch.nn.ConvTranspose2d)
+    for c in convs[1:]:
+        if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride, c0.padding,
+                                                                                 c0.dilation, c0.groups):
+            return None
+    n, ci, hi, wi = x.shape
+    kk, s, p, d = c0.kernel_size[0], c0.stride[0], c0.padding[0], c0.dilation[0]
+    op = c0.output_padding[0] if tr else 0
+    ho, wo = conv_out_size(hi, kk, s, p, d, tr, op), conv_out_size(wi, kk, s, p, d, tr, op)
+    g = ConvGeom(n, hi, wi, ci, ho, wo, ci, kk, kk, s, p, d, int(tr), ci)
+    if _lib.lib().senas_dwconv_multi_ws_bytes(C.byref(g), k) == 0:
+        return None
+    out = _DwMulti.apply(x, g, bool(want_stats), *[c.weight for c in convs])
+    return [(out[i], out[k + i] if want_stats else None) for i in range(k)]
+
+
 class _BnReluMulti(torch.autograd.Function):
     """relu(BatchNorm2d_t(z_t)) for k independent tensors of one shape in ONE launch (backward: two) --
     senas_bnrelu_multi_fwd / _bwd.  flat = [z_1..z_k, gamma_1..gamma_k, beta_1..beta_k]."""

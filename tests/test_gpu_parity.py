@@ -1240,3 +1240,43 @@ def test_bnrelu_multi_vs_torch(case):
         close(dbns[t].running_mean, rm.numpy(), 'running_mean %d' % t, rel=2e-5)
         close(dbns[t].running_var, rv.numpy(), 'running_var %d' % t, rel=2e-5)
         assert int(dbns[t].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('case', [(3, 2, 32, 16, 20, 5, 1, False), (2, 2, 32, 16, 16, 3, 2, False), (3, 2, 32, 8, 12, 5, 2, True),
+                                  (4, 1, 8, 12, 12, 3, 1, False), (2, 4, 16, 9, 11, 5, 1, False), (3, 2, 32, 12, 12, 3, 2, True)])
+def test_dwconv_multi_vs_single(case):
+    """senas_dwconv_multi_* (k depthwise convolutions of one input: one forward launch, one data-gradient launch summing
+    over the problems, two weight-gradient launches) against the same convolutions run one by one through torch (float64)."""
+    from senas_amd import functional as F
+    k, n, c, h, w, ks, stride, tr = case
+    gen = torch.Generator().manual_seed(sum(case[:7]))
+    mk = (lambda: nn.ConvTranspose2d(c, c, ks, stride=stride, padding=ks // 2, output_padding=stride - 1, groups=c, bias=False)) if tr else \
+         (lambda: nn.Conv2d(c, c, ks, stride=stride, padding=ks // 2, groups=c, bias=False))
+    convs = [mk() for _ in range(k)]
+    for cv in convs:
+        with torch.no_grad():
+            cv.weight.copy_(torch.randn(cv.weight.shape, generator=gen) * 0.3)
+    x = torch.randn(n, c, h, w, generator=gen)
+    x64 = x.double().requires_grad_(True)
+    refs = [copy_module64(cv) for cv in convs]
+    outs64 = [r(x64) for r in refs]
+    gs = [torch.randn(o.shape, generator=gen) for o in outs64]
+    sum((o * g.double()).sum() for o, g in zip(outs64, gs)).backward()
+    dconvs = [cv.to(dev()) for cv in convs]
+    xd = x.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    parts = F.dwconv_multi(xd, dconvs, True)
+    assert parts is not None
+    sum((z * g.to(dev())).sum() for (z, _), g in zip(parts, gs)).backward()
+    for t in range(k):
+        z, st = parts[t]
+        o = outs64[t].detach()
+        close(z, o.numpy(), 'output %d' % t, rel=5e-5)
+        want_st = torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], dim=-1)
+        close(st.float(), want_st.numpy(), 'statistics %d' % t, rel=1e-4)
+        close(dconvs[t].weight.grad, refs[t].weight.grad.numpy(), 'dw %d' % t, rel=2e-4)
+    close(xd.grad, x64.grad.numpy(), 'dx (sum over the problems)', rel=2e-4)
+
+
+def copy_module64(m):
+    import copy
+    return copy.deepcopy(m).double()

@@ -170,6 +170,21 @@ int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k);
 int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
                                   void* ws, void* stream);
 
+/* ---- k independent pointwise convolutions of one shape ------------------------------------------------------------
+ * The 1x1 halves of the DepSepConv candidates (utils/operations.py:107-115) of the edges that leave one state: each
+ * has its own input x[p] [n][hw][cin], weights w[p] [cout][cin] and output y[p] [n][hw][cout]; one launch forward (stats[p]:
+ * producer-side statistics as in senas_conv2d_fwd, may be NULL), one for all data gradients (dx[p] NULL: skipped), two
+ * for all weight gradients.  HOST arrays of k pointers, k <= SENAS_MAX_PWMULTI; cin in {4..64} a power-of-two multiple
+ * of 4, cout 4 or 8; otherwise SENAS_EUNSUPPORTED and nothing is launched.                                            */
+#define SENAS_MAX_PWMULTI 8
+int senas_pw_multi_fwd(int k, int n, int64_t hw, int cin, int cout, const float* const* x, const float* const* w,
+                       float* const* y, double* const* stats, void* stream);
+int senas_pw_multi_bwd_data(int k, int n, int64_t hw, int cin, int cout, const float* const* dy, const float* const* w,
+                            float* const* dx, void* stream);
+int64_t senas_pw_multi_ws_bytes(int k, int n, int64_t hw, int cin, int cout);
+int senas_pw_multi_bwd_weight(int k, int n, int64_t hw, int cin, int cout, const float* const* x, const float* const* dy,
+                              float* const* dw, void* ws, void* stream);
+
 /* ---- batched BatchNorm2d + ReLU over k independent tensors of one shape -------------------------------------------
  * DepSepConv's depthwise half (utils/operations.py:107-115: depthwise conv -> BatchNorm2d(c_in) -> ReLU).  The k
  * depthwise outputs that leave one state of a search cell share ONE forward launch and TWO backward launches instead of

@@ -36,6 +36,7 @@ class BnReluItem(C.Structure):
 
 MAX_BNRELU = 8
 MAX_DWMULTI = 4
+MAX_PWMULTI = 8
 UNSUPPORTED = -3
 
 _T = MAX_TERMS
@@ -82,6 +83,10 @@ SIGNATURES = {
     'senas_dwconv_multi_bwd_data': (_I, [_G, _I, _PP, _PP, _P, _P]),
     'senas_dwconv_multi_ws_bytes': (C.c_int64, [_G, _I]),
     'senas_dwconv_multi_bwd_weight': (_I, [_G, _I, _P, _PP, _PP, _P, _P]),
+    'senas_pw_multi_fwd': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _PP, _P]),
+    'senas_pw_multi_bwd_data': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _P]),
+    'senas_pw_multi_ws_bytes': (C.c_int64, [_I, _I, _L, _I, _I]),
+    'senas_pw_multi_bwd_weight': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _P, _P]),
     'senas_bnrelu_multi_fwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _I, _F, _F, _P]),
     'senas_bnrelu_multi_bwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _P]),
     'senas_combine_fwd': (_I, [_I, _L, _I, _I, _PP, _P, _P, _P, _I, _P, _P]),

@@ -147,11 +147,10 @@ class Cell(nn.Module):
                 mids = F.bnrelu_multi(zs, bns, sts)
             else:
                 mids = [F.bn_combine([F.Term(z, bn, stats=st)], relu=True) for z, bn, st in zip(zs, bns, sts)]
-            out = []
-            for (e, p, m), mid in zip(items, mids):
-                z2, st2 = run_conv(m[3], mid, want_stats=m[4].training)
-                out.append((e, p, F.Term(z2, m[4], stats=st2)))
-            return out
+            pws = F.pw_multi(mids, [m[3] for _, _, m in items], items[0][2][4].training)      # the pointwise halves, batched
+            if pws is None:
+                pws = [run_conv(m[3], mid, want_stats=m[4].training) for (_, _, m), mid in zip(items, mids)]
+            return [(e, p, F.Term(z2, m[4], stats=st2)) for (e, p, m), (z2, st2) in zip(items, pws)]
         return job, len(groups)
 
     def _plan(self, j):

@@ -473,6 +473,67 @@ def dwconv_multi(x, convs, want_stats):
     return [(out[i], out[k + i] if want_stats else None) for i in range(k)]
 
 
+class _PwMulti(torch.autograd.Function):
+    """k independent 1x1 convolutions of one shape (senas_pw_multi_*).  flat = [x_1..x_k, w_1..w_k]; outputs
+    z_1..z_k (+ their statistics)."""
+
+    @staticmethod
+    def forward(ctx, k, want_stats, *flat):
+        xs = [nhwc(x) for x in flat[:k]]
+        ws = [_dev(w).contiguous() for w in flat[k:2 * k]]
+        n, cin, h, w_ = xs[0].shape
+        cout = ws[0].shape[0]
+        ys = [new_nhwc(n, cout, h, w_, xs[0]) for _ in range(k)]
+        stats = [new_stats(n, cout, xs[0]) for _ in range(k)] if want_stats else []
+        arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+        _lib.check(_lib.lib().senas_pw_multi_fwd(k, n, h * w_, cin, cout, arr(xs), arr(ws), arr(ys), arr(stats) if want_stats else None,
+                                                 _stream()), 'senas_pw_multi_fwd')
+        ctx.k, ctx.dims = k, (n, cin, cout, h, w_)
+        ctx.save_for_backward(*xs, *ws)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*stats)
+        return tuple(ys) + tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k, L = ctx.k, _lib.lib()
+        n, cin, cout, h, w_ = ctx.dims
+        xs, ws = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        dev = xs[0].device
+        dys = [nhwc(d) if d is not None else torch.zeros((n, cout, h, w_), device=dev).contiguous(memory_format=CL) for d in grads[:k]]
+        arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+        need = ctx.needs_input_grad
+        dxs = [torch.empty_like(xs[t], memory_format=CL) if need[2 + t] else None for t in range(k)]
+        if any(d is not None for d in dxs):
+            _lib.check(L.senas_pw_multi_bwd_data(k, n, h * w_, cin, cout, arr(dys), arr(ws), arr(dxs), _stream()), 'senas_pw_multi_bwd_data')
+        dws = [None] * k
+        if any(need[2 + k:]):
+            dws = [torch.empty_like(w) for w in ws]
+            scratch = torch.empty(int(L.senas_pw_multi_ws_bytes(k, n, h * w_, cin, cout)), device=dev, dtype=torch.uint8)
+            _lib.check(L.senas_pw_multi_bwd_weight(k, n, h * w_, cin, cout, arr(xs), arr(dys), arr(dws), scratch.data_ptr(), _stream()),
+                       'senas_pw_multi_bwd_weight')
+        return (None, None) + tuple(dxs) + tuple(dws)
+
+
+def pw_multi(xs, convs, want_stats):
+    """[(z_p, stats_p)] of k same-shape 1x1 convolutions with their own inputs, or None off the batched path."""
+    k = len(convs)
+    c0 = convs[0]
+    if not 2 <= k <= _lib.MAX_PWMULTI or isinstance(c0, torch.nn.ConvTranspose2d):
+        return None
+    for c in convs:
+        if (c.kernel_size, c.stride, c.padding, c.groups, c.weight.shape) != ((1, 1), (1, 1), (0, 0), 1, c0.weight.shape) or c.bias is not None:
+            return None
+    n, cin, h, w_ = xs[0].shape
+    if any(tuple(x.shape) != (n, cin, h, w_) for x in xs):
+        return None
+    cout = c0.weight.shape[0]
+    if _lib.lib().senas_pw_multi_ws_bytes(k, n, h * w_, cin, cout) == 0:
+        return None
+    out = _PwMulti.apply(k, bool(want_stats), *xs, *[c.weight for c in convs])
+    return [(out[i], out[k + i] if want_stats else None) for i in range(k)]
+
+
 class _BnReluMulti(torch.autograd.Function):
     """relu(BatchNorm2d_t(z_t)) for k independent tensors of one shape in ONE launch (backward: two) --
     senas_bnrelu_multi_fwd / _bwd.  flat = [z_1..z_k, gamma_1..gamma_k, beta_1..beta_k]."""

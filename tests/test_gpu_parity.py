@@ -1280,3 +1280,34 @@ def test_dwconv_multi_vs_single(case):
 def copy_module64(m):
     import copy
     return copy.deepcopy(m).double()
+
+
+@pytest.mark.parametrize('case', [(6, 4, 32, 8, 16, 16), (4, 2, 8, 8, 12, 20), (2, 2, 32, 8, 8, 8), (8, 1, 16, 4, 9, 7), (3, 4, 64, 8, 32, 32)])
+def test_pw_multi_vs_torch(case):
+    """senas_pw_multi_* (k independent 1x1 convolutions sharing their launches) against float64 torch: outputs, producer-side
+    statistics, every dx and dw."""
+    from senas_amd import functional as F
+    k, n, cin, cout, h, w = case
+    gen = torch.Generator().manual_seed(sum(case))
+    convs = [nn.Conv2d(cin, cout, 1, bias=False) for _ in range(k)]
+    for cv in convs:
+        with torch.no_grad():
+            cv.weight.copy_(torch.randn(cv.weight.shape, generator=gen) * 0.3)
+    xs = [torch.randn(n, cin, h, w, generator=gen) for _ in range(k)]
+    gs = [torch.randn(n, cout, h, w, generator=gen) for _ in range(k)]
+    x64 = [x.double().requires_grad_(True) for x in xs]
+    refs = [copy_module64(cv) for cv in convs]
+    outs = [r(x) for r, x in zip(refs, x64)]
+    sum((o * g.double()).sum() for o, g in zip(outs, gs)).backward()
+    dconvs = [cv.to(dev()) for cv in convs]
+    xd = [x.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in xs]
+    parts = F.pw_multi(xd, dconvs, True)
+    assert parts is not None
+    sum((z * g.to(dev())).sum() for (z, _), g in zip(parts, gs)).backward()
+    for t in range(k):
+        z, st = parts[t]
+        o = outs[t].detach()
+        close(z, o.numpy(), 'output %d' % t, rel=5e-5)
+        close(st.float(), torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], dim=-1).numpy(), 'statistics %d' % t, rel=1e-4)
+        close(xd[t].grad, x64[t].grad.numpy(), 'dx %d' % t, rel=2e-4)
+        close(dconvs[t].weight.grad, refs[t].weight.grad.numpy(), 'dw %d' % t, rel=2e-4)

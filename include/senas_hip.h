@@ -288,7 +288,8 @@ int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const flo
 int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
                    const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
-                   float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream);
+                   float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride, float* ds_out,
+                   void* stream);
 
 /* out = sum of n dense fp32 tensors of numel elements (n <= SENAS_MAX_TERMS, 16-byte aligned): the gradient of a
  * tensor with n consumers (a cell state feeding several edges) in one pass instead of n-1 binary accumulations.  */

@@ -178,7 +178,8 @@ class Cell(nn.Module):
                     z = self._stacked_conv([m[0] for m in mods], xs[0])
                     se = isinstance(mods[0], ConvBnSe)
                     parts = F.unstack(z, len(mods), want_stats=mods[0][1].training or se)
-                    return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
+                    return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
+                            for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
             elif stack and isinstance(m0, AdapterBlock) and m0.c_in != m0.c_ot:
                 self._stack([m.conv for m in mods])
@@ -186,7 +187,7 @@ class Cell(nn.Module):
                 def job(xs, mods=mods, p=p):
                     z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
                     parts = F.unstack(z, len(mods), want_stats=mods[0].norm.training)
-                    return [(e, p, F.Term(zz, m.norm, stats=st)) for e, m, (zz, st) in zip(edges, mods, parts)]
+                    return [(e, p, F.Term(zz, m.norm, stats=st, grad_slot=slot)) for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
             elif self.stacked and isinstance(m0, DepSepConv):
                 depsep += [(e, p, m) for e, m in zip(edges, mods)]

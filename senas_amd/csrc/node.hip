@@ -37,6 +37,7 @@ struct ZTable {
 };
 struct DzTable {
     float* p[SENAS_MAX_TERMS];
+    int s[SENAS_MAX_TERMS];       // pixel stride of dz_t in floats (c when dense; wider: a channel slice of a stacked tensor)
 };
 struct SeGradTable {            // per-term gradient destinations (each its own tensor on the host side)
     float* w1[SENAS_MAX_TERMS];
@@ -775,7 +776,7 @@ __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, 
             ldv<V>(K + ko, kv);
 #pragma unroll
             for (int j = 0; j < V; ++j) zv[j] = fmaf(av[j], ds[j], fmaf(bv[j], zv[j], kv[j]));
-            stv<V>(out + off, zv);
+            stv<V>(out + ((size_t)n * hw + (size_t)(i / cv)) * dz.s[t] + ch, zv);
         }
     }
 }
@@ -868,7 +869,8 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
 extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
                               const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                               double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
-                              float* const* dse_w2, float* abk, float* const* dz, float* ds_out, void* stream) {
+                              float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride, float* ds_out,
+                              void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
     SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y || mask8), "node_bwd: null pointer");
@@ -885,6 +887,10 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     for (int t = 0; t < d.nterms; ++t) {
         zt.p[t] = z[t];
         dzt.p[t] = dz[t];
+        dzt.s[t] = (dz_pixel_stride != nullptr && dz_pixel_stride[t] > 0) ? dz_pixel_stride[t] : d.c;
+        SENAS_REQUIRE(dzt.s[t] >= d.c && (d.c % 4 != 0 || dzt.s[t] == d.c ||
+                                          (dzt.s[t] % 4 == 0 && (reinterpret_cast<uintptr_t>(dz[t]) & 15) == 0)),
+                      "node_bwd: a strided dz must keep 16-byte alignment");
         SENAS_REQUIRE(dgamma[t] && dbeta[t], "node_bwd: null batch-norm gradient destination");
         seg.dgamma[t] = dgamma[t];
         seg.dbeta[t] = dbeta[t];

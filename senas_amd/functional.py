@@ -695,12 +695,39 @@ class StackedWeight(object):
         return _StackFn.apply(buf, self.dim, *self.params)
 
 
+class GradLanding(object):
+    """The stacked gradient buffer [n, k*c, h, w] of an un-stacked tensor, allocated by the first consumer that writes its
+    part during a backward pass; when every part was written in place the un-stacking's backward pass hands the buffer
+    on as it is (no concatenation launch)."""
+
+    def __init__(self, k, shape):
+        self.k, self.shape = k, shape                      # shape of ONE part (n, c, h, w)
+        self.buf = None
+
+    def part(self, e, like):
+        n, c, h, w = self.shape
+        if self.buf is None:
+            self.buf = torch.empty((n, self.k * c, h, w), device=like.device, dtype=torch.float32, memory_format=CL)
+        return self.buf[:, e * c:(e + 1) * c]
+
+    def take(self, grads):
+        """The buffer if ``grads`` are exactly its parts, else None; either way the buffer is released."""
+        buf, self.buf = self.buf, None
+        if buf is None:
+            return None
+        n, c, h, w = self.shape
+        for e, g in enumerate(grads):
+            if g is None or g.data_ptr() != buf.data_ptr() + 4 * e * c or tuple(g.shape) != self.shape or g.stride() != buf[:, :c].stride():
+                return None
+        return buf
+
+
 class _Unstack(torch.autograd.Function):
     """[n, k*c, h, w] -> k tensors [n, c, h, w] (+ their producer-side batch-norm statistics); the backward pass is the
     channel concatenation of the k gradients."""
 
     @staticmethod
-    def forward(ctx, z, k, want_stats):
+    def forward(ctx, z, k, want_stats, landing):
         z = nhwc(z)
         n, kc, h, w = z.shape
         if kc % k != 0 or not 1 <= k <= _lib.MAX_STACK:
@@ -712,6 +739,7 @@ class _Unstack(torch.autograd.Function):
         sp = (C.c_void_p * k)(*[t.data_ptr() for t in stats]) if want_stats else None
         _lib.check(_lib.lib().senas_unstack_fwd(n, h * w, c, k, z.data_ptr(), dp, sp, _stream()), 'senas_unstack_fwd')
         ctx.k, ctx.shape = k, (n, c, h, w)
+        ctx.landing = landing
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*stats)
         return tuple(parts) + tuple(stats)
@@ -720,16 +748,22 @@ class _Unstack(torch.autograd.Function):
     def backward(ctx, *grads):
         gs = list(grads[:ctx.k])
         if all(g is None for g in gs):
-            return None, None, None
+            return None, None, None, None
+        if ctx.landing is not None:
+            whole = ctx.landing.take(gs)
+            if whole is not None:                          # every consumer wrote its part in place
+                return whole, None, None, None
         ref = next(g for g in gs if g is not None)
         gs = [g if g is not None else torch.zeros(ctx.shape, device=ref.device, dtype=ref.dtype).contiguous(memory_format=CL) for g in gs]
-        return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None
+        return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None, None
 
 
 def unstack(z, k, want_stats=True):
-    """The k per-edge parts of a stacked convolution output: [(z_e, stats_e or None)]."""
-    out = _Unstack.apply(z, k, want_stats)
-    return [(out[e], out[k + e] if want_stats else None) for e in range(k)]
+    """The k per-edge parts of a stacked convolution output: [(z_e, stats_e or None, grad_slot_e)]."""
+    n, kc, h, w = z.shape
+    landing = GradLanding(k, (n, kc // k, h, w)) if (kc // k) % 4 == 0 else None
+    out = _Unstack.apply(z, k, want_stats, landing)
+    return [(out[e], out[k + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(k)]
 
 
 def chan_stats(z):
@@ -749,10 +783,13 @@ class Term(object):
     ``passengers`` are parameters that must receive an exactly-zero gradient (the 1x1 adapter
     conv behind a zero input), as autograd gives them in the reference."""
 
-    __slots__ = ('z', 'bn', 'se', 'stats', 'passengers')
+    __slots__ = ('z', 'bn', 'se', 'stats', 'passengers', 'grad_slot')
 
-    def __init__(self, z, bn, se=None, stats=None, passengers=()):
+    def __init__(self, z, bn, se=None, stats=None, passengers=(), grad_slot=None):
         self.z, self.bn, self.se, self.stats, self.passengers = z, bn, se, stats, tuple(passengers)
+        # (GradLanding, part): where the consumer should WRITE d loss / d z -- a channel slice of the stacked gradient
+        # buffer the producer's backward pass needs anyway (functional.unstack); None: a tensor of its own
+        self.grad_slot = grad_slot
 
 
 def bn_combine(terms, mix=None, residual=None, relu=False):

@@ -133,10 +133,16 @@ class _Node(torch.autograd.Function):
         for k, t in enumerate(real):
             zfull[t] = zs[k]
         need = ctx.needs_input_grad
-        dzs = [None] * T
+        dzs, dz_strides = [None] * T, (C.c_int32 * T)()
+        slots = meta.get('slots') or [None] * T
         for k, t in enumerate(real):
             if need[3 + k]:
-                dzs[t] = torch.empty_like(zs[k], memory_format=CL)
+                if slots[t] is not None and c % 4 == 0:
+                    landing, part = slots[t]               # write straight into the producer's stacked gradient buffer
+                    dzs[t] = landing.part(part, zs[k])
+                    dz_strides[t] = dzs[t].stride(3)
+                else:
+                    dzs[t] = torch.empty_like(zs[k], memory_format=CL)
         ds_out = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
         dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # own tensors: autograd adopts them
@@ -154,7 +160,7 @@ class _Node(torch.autograd.Function):
         _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), dy_stride, yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
                                     F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
                                     _arr([t_.data_ptr() for t_ in dgs]), _arr([t_.data_ptr() for t_ in dbs]),
-                                    F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, F._p(ds_out),
+                                    F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, dz_strides, F._p(ds_out),
                                     F._stream()), 'senas_node_bwd')
         grads = [dzs[t] for t in real]
         grads += dgs + dbs
@@ -184,6 +190,7 @@ def bn_combine(terms, mix=None, residual=None, relu=False):
         'stats': [tm.stats for tm in terms],
         'buffers': [(tm.bn.running_mean, tm.bn.running_var, tm.bn.num_batches_tracked) for tm in terms],
         'passengers': passengers,
+        'slots': [tm.grad_slot for tm in terms],
     }
     flat = [terms[t].z for t in real]
     flat += [tm.bn.weight for tm in terms] + [tm.bn.bias for tm in terms]

@@ -8,8 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _library_is_current():
+    import glob
+    lib = os.path.join(ROOT, 'senas_amd', 'libsenas_hip.so')
+    if not os.path.exists(lib):
+        return False
+    srcs = glob.glob(os.path.join(ROOT, 'senas_amd', 'csrc', '*.hip')) + [os.path.join(ROOT, 'senas_amd', 'csrc', 'common.h'),
+                                                                            os.path.join(ROOT, 'include', 'senas_hip.h')]
+    return os.path.getmtime(lib) >= max(os.path.getmtime(f) for f in srcs)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the C-ABI library is built in-tree and git-ignored: build it when a fresh checkout (or an edited source) needs it
+    if not _library_is_current():
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'senas_amd', 'csrc'), '-j8'], check=True, stdout=subprocess.DEVNULL)
 
 
 def pytest_collection_modifyitems(config, items):

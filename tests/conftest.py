@@ -23,7 +23,10 @@ def pytest_configure(config):
     # the C-ABI library is built in-tree and git-ignored: build it when a fresh checkout (or an edited source) needs it
     if not _library_is_current():
         import subprocess
-        subprocess.run(['make', '-C', os.path.join(ROOT, 'senas_amd', 'csrc'), '-j8'], check=True, stdout=subprocess.DEVNULL)
+        missing = not os.path.exists(os.path.join(ROOT, 'senas_amd', 'libsenas_hip.so'))
+        done = subprocess.run(['make', '-C', os.path.join(ROOT, 'senas_amd', 'csrc'), '-j8'], stdout=subprocess.DEVNULL)
+        if done.returncode != 0 and missing:               # a stale-looking copy (file times do not survive every transfer) is still used
+            raise RuntimeError('could not build senas_amd/libsenas_hip.so (make -C senas_amd/csrc)')
 
 
 def pytest_collection_modifyitems(config, items):

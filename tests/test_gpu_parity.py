@@ -1311,3 +1311,51 @@ def test_pw_multi_vs_torch(case):
         close(st.float(), torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], dim=-1).numpy(), 'statistics %d' % t, rel=1e-4)
         close(xd[t].grad, x64[t].grad.numpy(), 'dx %d' % t, rel=2e-4)
         close(dconvs[t].weight.grad, refs[t].weight.grad.numpy(), 'dw %d' % t, rel=2e-4)
+
+
+@pytest.mark.parametrize('nodes,stacked', [(4, True), (2, True), (3, False)])
+def test_supernet_other_node_counts_vs_oracle(nodes, stacked):
+    """The search cell with 4 nodes (states 0 and 1 feed FOUR edges: the widest stacks and batched launches: 32 -> 32
+    stacked candidates, 8 DepSepConv candidates per state, 30 terms on the last node), with 2 nodes, and with the
+    state-major execution switched off (every candidate launched on its own): forward + backward + architecture gradients
+    against the CPU oracle, c=32, depth 3, 2x1x32x32."""
+    from oracle import senas_ref as R
+    from senas_amd.cell import Cell
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    kw = dict(input_c=1, c=32, num_classes=2, depth=3, meta_node_num=nodes)
+    net = NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+    _randomize(net, 19 + nodes)
+    with torch.no_grad():
+        for p in net.arch_parameters():
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel() + nodes)) * 0.5)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    gio.share_stem(sd, 'net.')
+    gen = torch.Generator().manual_seed(20 + nodes)
+    x = torch.randn(2, 1, 32, 32, generator=gen)
+    y = torch.randint(0, 2, (2, 32, 32), generator=gen)
+    ref = R.nas_forward(sd, x, depth=3, nodes=nodes)[-1]
+    ref_loss = R.dice_ce_loss(ref, y)
+    ref_loss.backward()
+    net = net.to(dev()).train()
+    was = Cell.stacked
+    Cell.stacked = stacked
+    try:
+        out = net(x.to(dev()))
+        loss = SegmentationLosses('dice_ce')(out, y.to(dev()))
+        loss.backward()
+    finally:
+        Cell.stacked = was
+    close(out[-1], ref.detach().numpy(), 'logits', rel=1e-3)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    got = grads_of(net)
+    for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'net.stem0.0.weight'):
+        e = sd[k].grad.numpy().astype(np.float64)
+        err = float(np.sqrt(((got[k] - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
+        assert err <= 1e-2, 'grad %s: L2 rel err %.2e' % (k, err)
+    ref_geno = R.derive_genotype(sd, depth=3, nodes=nodes)
+    got_geno = net.genotype()
+    assert (list(got_geno.down), list(got_geno.up)) == (list(ref_geno.down), list(ref_geno.up))

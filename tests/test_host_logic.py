@@ -231,3 +231,61 @@ def test_train_checkpoint_layout(tmp_path):
     assert ck.load_train_state(net.state_dict(), other) == 0            # bare state_dict (testing_model.py)
     for (ka, va), (kb, vb) in zip(net.state_dict().items(), other.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+# ------------------------------------------------------------------ state-major search cell (host-side pieces)
+def test_stacked_weight_assembles_and_routes_gradients():
+    """functional.StackedWeight: the stacked buffer is the concatenation of the per-edge parameters (dim 0 for Conv2d,
+    dim 1 for ConvTranspose2d) and every parameter receives exactly its slice of the gradient of the buffer."""
+    import torch
+    from senas_amd import functional as F
+    for dim, shape in ((0, (8, 32, 3, 3)), (1, (32, 8, 5, 5))):
+        params = [torch.nn.Parameter(torch.randn(shape)) for _ in range(3)]
+        sw = F.StackedWeight(params, dim)
+        w = sw.tensor()
+        assert torch.equal(w.detach(), torch.cat([p.detach() for p in params], dim=dim))
+        g = torch.randn(w.shape)
+        (w * g).sum().backward()
+        for i, p in enumerate(params):
+            assert torch.equal(p.grad, g.narrow(dim, i * shape[dim], shape[dim]))
+        with torch.no_grad():
+            params[1].add_(1.0)                       # unmanaged: the next use sees the new value
+        assert torch.equal(sw.tensor().detach(), torch.cat([p.detach() for p in params], dim=dim))
+
+
+def test_grad_landing_hands_the_buffer_on_only_when_every_part_was_written_in_place():
+    import torch
+    from senas_amd import functional as F
+    land = F.GradLanding(3, (2, 8, 4, 4))
+    like = torch.zeros(1)
+    parts = [land.part(e, like) for e in range(3)]
+    assert parts[1].data_ptr() == parts[0].data_ptr() + 4 * 8 and parts[0].shape == (2, 8, 4, 4)
+    assert parts[0].stride(3) == 24                    # pixel stride of a part = channels of the whole buffer
+    whole = land.take(parts)
+    assert whole is not None and whole.shape == (2, 24, 4, 4) and land.buf is None
+    parts = [land.part(e, like) for e in range(3)]
+    assert land.take([parts[0], parts[1].clone(), parts[2]]) is None      # a foreign tensor: fall back to concatenation
+    assert land.take([None, None, None]) is None
+
+
+def test_search_cell_plan_covers_every_candidate_once():
+    """Cell._plan: per state, the jobs (stacked convolutions, batched DepSepConv groups, per-edge leftovers) together with
+    the 'none' terms account for every candidate of every edge that reads the state, with one alias per reader."""
+    from senas_amd.cell import Cell
+    for nodes in (2, 3, 4):
+        for kind in ('down', 'up'):
+            cell = Cell(nodes, 1, 32, 32, 32, kind)
+            seen = set()
+            for j in range(2 + nodes):
+                edges = cell._out_edges(j)
+                assert len(edges) == sum(1 for i in range(nodes) if j < 2 + i)
+                jobs, fixed = cell._plan(j)
+                assert all(a >= 1 for _, a in jobs)
+                for e, p, t in fixed:
+                    assert t.z is None and (e, p) not in seen
+                    seen.add((e, p))
+                if not edges:
+                    assert not jobs and not fixed
+            # every stacked group: same-geometry weights, k = number of edges leaving the state
+            for sw in cell.stacked_weights():
+                assert 2 <= len(sw.params) <= 4 and len({tuple(p.shape) for p in sw.params}) == 1

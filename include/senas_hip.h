@@ -140,6 +140,14 @@ int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* 
 int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream);
 int senas_relu_bwd(int64_t numel, const float* dy, const float* y, float* dx, void* stream);
 
+/* ---- gamma-gated blend of two skip candidates (search/senas_search.py:98-102) ---------------------------------------
+ * y = g[0] * x1 + g[1] * x2 with g a DEVICE float[2] (a row of softmax(gamma)); backward: dx1 = g[0] * dy,
+ * dx2 = g[1] * dy (either may be NULL), dg[0] += sum dy * x1, dg[1] += sum dy * x2 (double[2], caller zeroes).
+ * numel % 4 == 0, tensors 16-byte aligned and identically laid out.                                             */
+int senas_blend2_fwd(int64_t numel, const float* x1, const float* x2, const float* g, float* y, void* stream);
+int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1, const float* x2, const float* g, float* dx1,
+                     float* dx2, double* dg, void* stream);
+
 /* ---- batch-norm statistics --------------------------------------------------------------------
  * Per-image per-channel sum / sum-of-squares of x [n][hw][c] ADDED into stats double[n][c][2].   */
 int senas_chan_stats(int n, int64_t hw, int c, const float* x, double* stats, void* stream);

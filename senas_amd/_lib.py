@@ -77,6 +77,8 @@ SIGNATURES = {
     'senas_unstack_fwd': (_I, [_I, _L, _I, _I, _P, _PP, _PP, _P]),
     'senas_relu_fwd': (_I, [_L, _P, _P, _P]),
     'senas_relu_bwd': (_I, [_L, _P, _P, _P, _P]),
+    'senas_blend2_fwd': (_I, [_L, _P, _P, _P, _P, _P]),
+    'senas_blend2_bwd': (_I, [_L, _P, _P, _P, _P, _P, _P, _P, _P]),
     'senas_chan_stats': (_I, [_I, _L, _I, _P, _P, _P]),
     'senas_bn_finalize': (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
     'senas_dwconv_multi_fwd': (_I, [_G, _I, _P, _PP, _PP, _PP, _P]),

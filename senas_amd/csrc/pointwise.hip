@@ -253,9 +253,67 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumTable t, int n, long n4, 
     }
 }
 
+// ---- gamma-gated blend of two skip candidates (search/senas_search.py:98-102): y = g[0] * x1 + g[1] * x2, g on the device
+__global__ __launch_bounds__(256) void blend2_fwd_kernel(const float4* __restrict__ x1, const float4* __restrict__ x2,
+                                                         const float* __restrict__ g, float4* __restrict__ y, long n4) {
+    const float a = g[0], b = g[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 u = x1[i], v = x2[i];
+        y[i] = make_float4(fmaf(a, u.x, b * v.x), fmaf(a, u.y, b * v.y), fmaf(a, u.z, b * v.z), fmaf(a, u.w, b * v.w));
+    }
+}
+
+// dx1 = g[0] * dy, dx2 = g[1] * dy (either may be NULL), dg[0] += sum dy * x1, dg[1] += sum dy * x2 (fp64, caller zeroes)
+__global__ __launch_bounds__(256) void blend2_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ x1,
+                                                         const float4* __restrict__ x2, const float* __restrict__ g,
+                                                         float4* __restrict__ dx1, float4* __restrict__ dx2,
+                                                         double* __restrict__ dg, long n4) {
+    __shared__ double red[2][256];
+    const float a = g[0], b = g[1];
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 d = dy[i], u = x1[i], v = x2[i];
+        if (dx1 != nullptr) dx1[i] = make_float4(a * d.x, a * d.y, a * d.z, a * d.w);
+        if (dx2 != nullptr) dx2[i] = make_float4(b * d.x, b * d.y, b * d.z, b * d.w);
+        s1 += (double)d.x * u.x + (double)d.y * u.y + (double)d.z * u.z + (double)d.w * u.w;
+        s2 += (double)d.x * v.x + (double)d.y * v.y + (double)d.z * v.z + (double)d.w * v.w;
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(dg, red[0][0]); atomicAdd(dg + 1, red[1][0]); }
+}
+
 }  // namespace senas
 
 using namespace senas;
+
+extern "C" int senas_blend2_fwd(int64_t numel, const float* x1, const float* x2, const float* g, float* y, void* stream) {
+    SENAS_REQUIRE(x1 && x2 && g && y && numel > 0 && numel % 4 == 0, "blend2_fwd: bad argument (numel % 4 == 0)");
+    SENAS_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0, "blend2_fwd: tensors must be 16-byte aligned");
+    const long n4 = numel / 4;
+    hipLaunchKernelGGL(blend2_fwd_kernel, dim3(stream_grid(n4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(x1),
+                       reinterpret_cast<const float4*>(x2), g, reinterpret_cast<float4*>(y), n4);
+    return launch_status("blend2_fwd");
+}
+
+extern "C" int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1, const float* x2, const float* g, float* dx1,
+                                float* dx2, double* dg, void* stream) {
+    SENAS_REQUIRE(dy && x1 && x2 && g && dg && numel > 0 && numel % 4 == 0, "blend2_bwd: bad argument (numel % 4 == 0)");
+    SENAS_REQUIRE(((uintptr_t)dy | (uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dx1 | (uintptr_t)dx2) % 16 == 0,
+                  "blend2_bwd: tensors must be 16-byte aligned");
+    const long n4 = numel / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 512) blocks = 512;                                    // every block ends in two fp64 atomics
+    hipLaunchKernelGGL(blend2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(dy),
+                       reinterpret_cast<const float4*>(x1), reinterpret_cast<const float4*>(x2), g, reinterpret_cast<float4*>(dx1),
+                       reinterpret_cast<float4*>(dx2), dg, n4);
+    return launch_status("blend2_bwd");
+}
 
 extern "C" int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream) {
     SENAS_REQUIRE(x && y && numel >= 0, "relu_fwd: bad argument");

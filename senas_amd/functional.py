@@ -366,6 +366,39 @@ def relu(x):
     return _ReLU.apply(x)
 
 
+class _Blend2(torch.autograd.Function):
+    """g[0] * x1 + g[1] * x2 (the gamma-gated skip blend of the supernet, search/senas_search.py:98-102) in one launch;
+    the backward pass produces both input gradients and d g in one more (plus the fp64 -> fp32 hand-over of d g)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, g):
+        x1, x2 = nhwc(x1), nhwc(x2)
+        if x1.shape != x2.shape or x1.numel() % 4 != 0 or g.numel() != 2:
+            raise SenasHipError('blend2: shapes %s / %s / %s' % (tuple(x1.shape), tuple(x2.shape), tuple(g.shape)))
+        gc = _dev(g).contiguous()
+        y = torch.empty_like(x1, memory_format=CL)
+        _lib.check(_lib.lib().senas_blend2_fwd(x1.numel(), x1.data_ptr(), x2.data_ptr(), gc.data_ptr(), y.data_ptr(), _stream()),
+                   'senas_blend2_fwd')
+        ctx.save_for_backward(x1, x2, gc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, gc = ctx.saved_tensors
+        dy = nhwc(dy)
+        need = ctx.needs_input_grad
+        dx1 = torch.empty_like(x1, memory_format=CL) if need[0] else None
+        dx2 = torch.empty_like(x2, memory_format=CL) if need[1] else None
+        dg = zeros64((2,), x1.device)
+        _lib.check(_lib.lib().senas_blend2_bwd(x1.numel(), dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), gc.data_ptr(), _p(dx1), _p(dx2),
+                                               dg.data_ptr(), _stream()), 'senas_blend2_bwd')
+        return dx1, dx2, (dg.float() if need[2] else None)
+
+
+def blend2(x1, x2, g):
+    return _Blend2.apply(x1, x2, g)
+
+
 class _FanOut(torch.autograd.Function):
     """n aliases of x for n consumers; the backward pass adds the incoming gradients in ONE launch (senas_sum_n)
     instead of leaving n-1 binary accumulations to autograd."""

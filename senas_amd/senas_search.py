@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as tf
 
+from . import functional as F
 from .cell import Cell
 from .genotype import GenoParser, Genotype
 from .grid import MacroGrid, gamma_index
@@ -43,7 +44,7 @@ class SenasSearch(MacroGrid):
                 skips = [outs[j]]
                 for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
                     g = gamma[gamma_index(k, j)]
-                    skips.append(outs[j + k - 1] * g[0] + outs[j + k] * g[1])
+                    skips.append(F.blend2(outs[j + k - 1], outs[j + k], g))
                 outs[i + j] = self.blocks[i][j](torch.cat(skips, dim=1), outs[i + j], alpha_up_nm, alpha_up, beta_up)
         head = self.head_block[-1]
         tails = outs if self._supervision else outs[-1:]

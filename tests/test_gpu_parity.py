@@ -1359,3 +1359,25 @@ def test_supernet_other_node_counts_vs_oracle(nodes, stacked):
     ref_geno = R.derive_genotype(sd, depth=3, nodes=nodes)
     got_geno = net.genotype()
     assert (list(got_geno.down), list(got_geno.up)) == (list(ref_geno.down), list(ref_geno.up))
+
+
+def test_blend2_vs_torch():
+    """senas_blend2_fwd / _bwd (gamma-gated blend of two skip candidates) against float64 torch."""
+    from senas_amd import functional as F
+    gen = torch.Generator().manual_seed(31)
+    x1, x2, w = (torch.randn(3, 32, 20, 12, generator=gen) for _ in range(3))
+    gam = torch.randn(6, 2, generator=gen)
+    a64, b64, g64 = x1.double().requires_grad_(True), x2.double().requires_grad_(True), gam.double().requires_grad_(True)
+    row = torch.softmax(g64, -1)[4]
+    ((a64 * row[0] + b64 * row[1]) * w.double()).sum().backward()
+    cl = torch.channels_last
+    a, b = (t.to(dev()).contiguous(memory_format=cl).requires_grad_(True) for t in (x1, x2))
+    g = gam.to(dev()).requires_grad_(True)
+    y = F.blend2(a, b, torch.softmax(g, -1)[4])
+    (y * w.to(dev())).sum().backward()
+    with torch.no_grad():
+        r = torch.softmax(g64, -1)[4]
+        close(y, (x1.double() * r[0] + x2.double() * r[1]).numpy(), 'blend', rel=1e-5)
+    close(a.grad, a64.grad.numpy(), 'dx1', rel=1e-5)
+    close(b.grad, b64.grad.numpy(), 'dx2', rel=1e-5)
+    close(g.grad, g64.grad.numpy(), 'dgamma', rel=1e-4)

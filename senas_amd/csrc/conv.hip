@@ -249,6 +249,83 @@ __device__ __forceinline__ void dwconv_body(const GatherGeom& g, const float* __
     if constexpr (V == 4) stats_flush4(acc_st, stats, uniform, n_blk, g.cout, c_thr);
 }
 
+// Plain-gather depthwise convolution, dilation 1, 4 channels x FOUR consecutive output columns per thread: a row of the
+// window is loaded once (4*S + KS - S float4 loads: 8 for 5x5 stride 1 instead of 20) and serves the four outputs --
+// the one-pixel-per-thread form above is bound by L1 requests (25 per output), not by HBM.
+// flip: use the taps mirrored (the data gradient of a stride-1 depthwise convolution is the same gather with the
+// kernel turned by 180 degrees).  Requires wout % 4 == 0.  Thread order: channel quad fastest, then column group.
+template <int KS, int S>
+__device__ __forceinline__ void dwconv_x4_body(const GatherGeom& g, const float* __restrict__ in,
+                                               const float* __restrict__ w, float* __restrict__ out, int flip,
+                                               double* __restrict__ stats, long total, int P) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [tap][C]
+    constexpr int TAPS = KS * KS, COLS = 3 * S + KS;
+    const int C = g.cout;
+    for (int i = threadIdx.x; i < TAPS * C; i += 256) {
+        const int t = i / C, cc = i - t * C;
+        wl[i] = w[cc * TAPS + (flip ? TAPS - 1 - t : t)];
+    }
+    __syncthreads();
+    Stats4 acc_st;
+    stats_init4(acc_st);
+    const bool uniform = P > 0;
+    const int chunks = uniform ? P : 1;
+    const int cv = C >> 2, wq = g.wout >> 2;
+    int n_blk = 0, c_thr = 0;
+    for (int kk = 0; kk < chunks; ++kk) {
+        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        const bool active = idx < total;
+        if (!active) idx = total - 1;
+        const int c = (int)(idx % cv) * 4;
+        long r = idx / cv;
+        const int ox0 = (int)(r % wq) * 4;
+        r /= wq;
+        const int oy = (int)(r % g.hout), n = (int)(r / g.hout);
+        n_blk = n; c_thr = c;
+        float acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
+        const int ix0 = ox0 * S - g.pad;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy * S - g.pad + ky;
+            if (iy < 0 || iy >= g.hin) continue;
+            const float* row = in + ((size_t)(n * g.hin + iy) * g.win) * g.cin + c;
+            float4 col[COLS];
+#pragma unroll
+            for (int x = 0; x < COLS; ++x) {
+                const int ix = ix0 + x;
+                col[x] = (ix >= 0 && ix < g.win) ? *reinterpret_cast<const float4*>(row + (size_t)ix * g.cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const float4 wt = *reinterpret_cast<const float4*>(wl + (ky * KS + kx) * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = col[j * S + kx];
+                    acc[j][0] = fmaf(v.x, wt.x, acc[j][0]); acc[j][1] = fmaf(v.y, wt.y, acc[j][1]);
+                    acc[j][2] = fmaf(v.z, wt.z, acc[j][2]); acc[j][3] = fmaf(v.w, wt.w, acc[j][3]);
+                }
+            }
+        }
+        const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox0) * C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (active) stv<4>(out + o + (size_t)j * C, acc[j]);
+            stats_accumulate4(acc_st, stats, uniform, n, C, c, acc[j], active);
+        }
+    }
+    stats_flush4(acc_st, stats, uniform, n_blk, C, c_thr);
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void dwconv_x4_kernel(GatherGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                                        float* __restrict__ out, int flip, double* __restrict__ stats, long total, int P) {
+    dwconv_x4_body<KS, S>(g, in, w, out, flip, stats, total, P);
+}
+
 template <bool TG, int V, bool EPI = false>
 __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* __restrict__ in,
                                                      const float* __restrict__ w, float* __restrict__ out,
@@ -270,6 +347,12 @@ template <bool TG>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom g, const float* __restrict__ in, DwTab tab, long total, int P) {
     const int p = blockIdx.y;
     dwconv_body<TG, 4, false>(g, in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom g, const float* __restrict__ in, DwTab tab, long total, int P) {
+    const int p = blockIdx.y;
+    dwconv_x4_body<KS, S>(g, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
 }
 
 // data gradient of the same: dx = sum over problems of the (transposed / plain) gather of dy_p with w_p, one pass
@@ -533,6 +616,12 @@ extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* byt
     return SENAS_OK;
 }
 
+// the 4-columns-per-thread depthwise form: plain gather (Conv2d forward), dilation 1, 3x3 / 5x5, c % 4 == 0, output width % 4 == 0
+static bool dw_x4_ok(const GatherGeom& gg, int transposed) {
+    return !transposed && gg.dil == 1 && gg.kh == gg.kw && (gg.kh == 3 || gg.kh == 5) && gg.cout % 4 == 0 && gg.cin == gg.cout &&
+           gg.wout % 4 == 0 && (gg.stride == 1 || gg.stride == 2);
+}
+
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
 extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
                                 double* stats, void* ws, const float* packed, void* stream) {
@@ -543,6 +632,16 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     if (g->groups != 1) {
         const int V = (g->co % 4 == 0) ? 4 : 1;
         const size_t dw_lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
+        if (!in_relu && dw_x4_ok(gg, g->transposed)) {              // 4 output columns per thread (L1 requests / 2.5)
+            const long per_img4 = (long)g->ho * (g->wo / 4) * (g->co / 4), total4 = per_img4 * g->n;
+            const int P4 = stats != nullptr ? stats_chunks_per_block(per_img4, g->co, total4) : 0;
+            dim3 grid4((unsigned)((total4 + 256L * (P4 > 0 ? P4 : 1) - 1) / (256L * (P4 > 0 ? P4 : 1))));
+#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_x4_kernel<KS_, S_>), grid4, dim3(256), dw_lds, st, gg, x, w, y, 0, stats, total4, P4)
+            if (g->kh == 3) { if (g->stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
+            else { if (g->stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#undef SENAS_X4
+            return launch_status("dwconv_fwd (x4)");
+        }
         const long per_img = (long)g->ho * g->wo * (g->co / V);
         long total = per_img * g->n;
         const int P = (V == 4 && stats != nullptr) ? stats_chunks_per_block(per_img, g->co, total) : 0;
@@ -636,6 +735,18 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     if (g->groups != 1) {
         const int V = (g->ci % 4 == 0) ? 4 : 1;
         const size_t dw_lds = (size_t)g->kh * g->kw * g->ci * sizeof(float);
+        // the 4-columns-per-thread plain gather where the data gradient is one: ConvTranspose2d (gather over dy at the conv's
+        // stride), and a stride-1 "same" Conv2d (the same gather with the kernel turned by 180 degrees)
+        const bool flip = !g->transposed && g->stride == 1 && g->hi == g->ho && g->wi == g->wo && g->pad == g->dil * (g->kh / 2);
+        if (mask == nullptr && (g->transposed || flip) && dw_x4_ok(gg, 0)) {
+            const long total4 = (long)g->n * g->hi * (g->wi / 4) * (g->ci / 4);
+            dim3 grid4((unsigned)((total4 + 255) / 256));
+#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_x4_kernel<KS_, S_>), grid4, dim3(256), dw_lds, st, gg, dy, w, dx, flip ? 1 : 0, (double*)nullptr, total4, 0)
+            if (g->kh == 3) { if (gg.stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
+            else { if (gg.stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#undef SENAS_X4
+            return launch_status("dwconv_bwd_data (x4)");
+        }
         long total = (long)g->n * g->hi * g->wi * (g->ci / V);
         dim3 grid((unsigned)((total + 255) / 256));
         if (!g->transposed) {
@@ -872,11 +983,21 @@ extern "C" int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const flo
         tab.w[p] = w[p]; tab.out[p] = y[p]; tab.stats[p] = want ? stats[p] : nullptr;
         want = want && tab.stats[p] != nullptr;
     }
+    const size_t lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
+    if (dw_x4_ok(gg, g->transposed)) {
+        const long per_img4 = (long)g->ho * (g->wo / 4) * (g->co / 4), total4 = per_img4 * g->n;
+        const int P4 = want ? stats_chunks_per_block(per_img4, g->co, total4) : 0;
+        dim3 grid4((unsigned)((total4 + 256L * (P4 > 0 ? P4 : 1) - 1) / (256L * (P4 > 0 ? P4 : 1))), k);
+#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_multi_fwd_x4_kernel<KS_, S_>), grid4, dim3(256), lds, as_stream(stream), gg, x, tab, total4, P4)
+        if (g->kh == 3) { if (g->stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
+        else { if (g->stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#undef SENAS_X4
+        return launch_status("dwconv_multi_fwd (x4)");
+    }
     const long per_img = (long)g->ho * g->wo * (g->co / 4);
     const long total = per_img * g->n;
     const int P = want ? stats_chunks_per_block(per_img, g->co, total) : 0;
     dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))), k);
-    const size_t lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
     if (g->transposed) hipLaunchKernelGGL((dwconv_multi_fwd_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
     else hipLaunchKernelGGL((dwconv_multi_fwd_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
     return launch_status("dwconv_multi_fwd");

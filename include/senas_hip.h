@@ -130,7 +130,8 @@ int senas_bilinear2x_bwd(int n, int h, int w, int c, const float* dy, float* dx,
  * The edges that LEAVE one state of a search cell (search/cell.py:100-106) read the same tensor with the same
  * geometry, so their same-named candidates run as ONE convolution with the weights stacked along c_out; this splits
  * its output src [n][hw][k*c] into the k per-edge tensors dst[e] [n][hw][c] the nodes consume, adding the per-image
- * channel sums of every part into stats[e] (double[n][c][2], caller zeroes; stats or any stats[e] may be NULL).
+ * channel sums of every part into stats[e] (double[n][c][2], caller zeroes; stats or any stats[e] may be NULL).  A NULL
+ * dst[e] (e > 0) skips part e -- the zero-weight padding part that fills a stack of three to a full 32-channel tile.
  * dst / stats: HOST arrays of k device pointers, k <= SENAS_MAX_STACK.                                          */
 #define SENAS_MAX_STACK 4
 int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* const* dst, double* const* stats,

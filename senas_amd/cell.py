@@ -103,7 +103,11 @@ class Cell(nn.Module):
                 if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride,
                                                                                          c0.padding, c0.dilation, c0.groups):
                     raise F.SenasHipError('stacked candidates disagree in geometry')
-            stacks[key] = F.StackedWeight([c.weight for c in convs], 1 if isinstance(c0, nn.ConvTranspose2d) else 0)
+            tr = isinstance(c0, nn.ConvTranspose2d)
+            # three transposed 32 -> 8 candidates: a zero-weight fourth part makes the stack a full 32-channel tile, which
+            # puts its weight gradient and data gradient on the LDS kernels (24 fine-grid channels fall off them)
+            pad = 1 if (tr and len(convs) == 3 and c0.out_channels * 4 == 32) else 0
+            stacks[key] = F.StackedWeight([c.weight for c in convs], 1 if tr else 0, pad_parts=pad)
         return stacks[key]
 
     def stacked_weights(self):
@@ -175,9 +179,10 @@ class Cell(nn.Module):
                 self._stack([m[0] for m in mods])
 
                 def job(xs, mods=mods, p=p):
-                    z = self._stacked_conv([m[0] for m in mods], xs[0])
+                    convs = [m[0] for m in mods]
+                    z = self._stacked_conv(convs, xs[0])
                     se = isinstance(mods[0], ConvBnSe)
-                    parts = F.unstack(z, len(mods), want_stats=mods[0][1].training or se)
+                    parts = F.unstack(z, len(mods) + self._stack(convs).pad_parts, want_stats=mods[0][1].training or se, used=len(mods))
                     return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
                             for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))

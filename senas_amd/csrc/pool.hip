@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void unstack_kernel(PoolGeom g, const float* _
     const int e = blockIdx.y;
     float* __restrict__ dst = parts.dst[e];
     double* __restrict__ stats = parts.stats[e];
+    if (dst == nullptr) return;                            // a padding part of the stack: nobody reads it
     SENAS_FWD_LOOP_BEGIN(total, P)
     int ch, ox, oy, n;
     decode<V>(idx, g.c / V, g.wo, g.ho, ch, ox, oy, n);
@@ -379,7 +380,7 @@ extern "C" int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* s
     for (int e = 0; e < SENAS_MAX_STACK; ++e) {
         parts.dst[e] = e < k ? dst[e] : nullptr;
         parts.stats[e] = (e < k && stats != nullptr) ? stats[e] : nullptr;
-        SENAS_REQUIRE(e >= k || parts.dst[e] != nullptr, "unstack_fwd: null part");
+        SENAS_REQUIRE(e != 0 || parts.dst[e] != nullptr, "unstack_fwd: null first part");
     }
     PoolGeom g{n, 1, (int)hw, c, 1, (int)hw, 1};                     // one row of hw pixels per image
     SENAS_REQUIRE(hw < 0x7fffffffL, "unstack_fwd: map too large");

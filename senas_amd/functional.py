@@ -693,8 +693,8 @@ class StackedWeight(object):
     refills every stacked buffer of the model (one multi-tensor copy) and repacks its MFMA image together with all
     other weights at the start of a pass, so using it costs no launch at all."""
 
-    def __init__(self, params, dim):
-        self.params, self.dim = list(params), dim
+    def __init__(self, params, dim, pad_parts=0):
+        self.params, self.dim, self.pad_parts = list(params), dim, pad_parts
         self.buf = None
         self.managed = False
         self.filled = None                     # the parameters' version counters when a packer last filled the buffer
@@ -709,8 +709,9 @@ class StackedWeight(object):
         p0 = self.params[0]
         if self.buf is None or self.buf.device != p0.device:
             shape = list(p0.shape)
-            shape[self.dim] = sum(p.shape[self.dim] for p in self.params)
-            self.buf = torch.empty(shape, device=p0.device, dtype=p0.dtype)
+            shape[self.dim] = sum(p.shape[self.dim] for p in self.params) + self.pad_parts * p0.shape[self.dim]
+            # zero-filled: the padding parts (zero weights that bring a stack of three to a full 32-channel tile) stay zero
+            self.buf = torch.zeros(shape, device=p0.device, dtype=p0.dtype)
             self.managed = False
         return self.buf
 
@@ -724,7 +725,9 @@ class StackedWeight(object):
     def tensor(self):
         buf = self.buffer()
         if not self.current():
-            torch.cat([p.detach() for p in self.params], dim=self.dim, out=buf)
+            with torch.no_grad():
+                for dst, p in zip(self.slices(), self.params):
+                    dst.copy_(p)
         return _StackFn.apply(buf, self.dim, *self.params)
 
 
@@ -733,8 +736,9 @@ class GradLanding(object):
     part during a backward pass; when every part was written in place the un-stacking's backward pass hands the buffer
     on as it is (no concatenation launch)."""
 
-    def __init__(self, k, shape):
+    def __init__(self, k, shape, used=None):
         self.k, self.shape = k, shape                      # shape of ONE part (n, c, h, w)
+        self.used = k if used is None else used            # parts beyond `used` are zero-weight padding: their gradient is zero
         self.buf = None
 
     def part(self, e, like):
@@ -749,9 +753,13 @@ class GradLanding(object):
         if buf is None:
             return None
         n, c, h, w = self.shape
+        if len(grads) != self.used:
+            return None
         for e, g in enumerate(grads):
             if g is None or g.data_ptr() != buf.data_ptr() + 4 * e * c or tuple(g.shape) != self.shape or g.stride() != buf[:, :c].stride():
                 return None
+        if self.used < self.k:
+            buf[:, self.used * c:].zero_()
         return buf
 
 
@@ -760,18 +768,20 @@ class _Unstack(torch.autograd.Function):
     channel concatenation of the k gradients."""
 
     @staticmethod
-    def forward(ctx, z, k, want_stats, landing):
+    def forward(ctx, z, k, want_stats, landing, used):
         z = nhwc(z)
         n, kc, h, w = z.shape
-        if kc % k != 0 or not 1 <= k <= _lib.MAX_STACK:
+        if kc % k != 0 or not 1 <= used <= k <= _lib.MAX_STACK:
             raise SenasHipError('unstack: %d channels into %d parts' % (kc, k))
         c = kc // k
-        parts = [new_nhwc(n, c, h, w, z) for _ in range(k)]
-        stats = [new_stats(n, c, z) for _ in range(k)] if want_stats else []
-        dp = (C.c_void_p * k)(*[t.data_ptr() for t in parts])
-        sp = (C.c_void_p * k)(*[t.data_ptr() for t in stats]) if want_stats else None
+        parts = [new_nhwc(n, c, h, w, z) for _ in range(used)]
+        stats = [new_stats(n, c, z) for _ in range(used)] if want_stats else []
+        pad = [None] * (k - used)
+        dp = (C.c_void_p * k)(*([t.data_ptr() for t in parts] + pad))
+        sp = (C.c_void_p * k)(*([t.data_ptr() for t in stats] + pad)) if want_stats else None
         _lib.check(_lib.lib().senas_unstack_fwd(n, h * w, c, k, z.data_ptr(), dp, sp, _stream()), 'senas_unstack_fwd')
-        ctx.k, ctx.shape = k, (n, c, h, w)
+        ctx.k, ctx.shape = used, (n, c, h, w)
+        ctx.k_total = k
         ctx.landing = landing
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*stats)
@@ -781,22 +791,25 @@ class _Unstack(torch.autograd.Function):
     def backward(ctx, *grads):
         gs = list(grads[:ctx.k])
         if all(g is None for g in gs):
-            return None, None, None, None
+            return None, None, None, None, None
         if ctx.landing is not None:
             whole = ctx.landing.take(gs)
             if whole is not None:                          # every consumer wrote its part in place
-                return whole, None, None, None
+                return whole, None, None, None, None
         ref = next(g for g in gs if g is not None)
         gs = [g if g is not None else torch.zeros(ctx.shape, device=ref.device, dtype=ref.dtype).contiguous(memory_format=CL) for g in gs]
-        return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None, None
+        gs += [torch.zeros_like(ref) for _ in range(ctx.k_total - ctx.k)]           # zero-weight padding parts
+        return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None, None, None
 
 
-def unstack(z, k, want_stats=True):
-    """The k per-edge parts of a stacked convolution output: [(z_e, stats_e or None, grad_slot_e)]."""
+def unstack(z, k, want_stats=True, used=None):
+    """The per-edge parts of a stacked convolution output: [(z_e, stats_e or None, grad_slot_e)] for the first ``used`` of
+    its k parts (the rest is zero-weight padding)."""
+    used = k if used is None else used
     n, kc, h, w = z.shape
-    landing = GradLanding(k, (n, kc // k, h, w)) if (kc // k) % 4 == 0 else None
-    out = _Unstack.apply(z, k, want_stats, landing)
-    return [(out[e], out[k + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(k)]
+    landing = GradLanding(k, (n, kc // k, h, w), used) if (kc // k) % 4 == 0 else None
+    out = _Unstack.apply(z, k, want_stats, landing, used)
+    return [(out[e], out[used + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(used)]
 
 
 def chan_stats(z):

@@ -114,6 +114,10 @@ class Cell(nn.Module):
         """Every StackedWeight this cell uses (built without running a forward pass), for the weight packer."""
         for j in range(self._input_num + self._meta_node_num):
             self._plan(j)
+        post = self.post_process
+        c_in = post.conv.in_channels
+        if self.stacked and c_in % 16 != 0 and c_in <= 32 and c_in % 4 == 0:
+            self.__dict__.setdefault('_stacks', {}).setdefault(('post', id(post.conv)), F.StackedWeight([post.conv.weight], 1, pad_to=32))
         return list(self.__dict__.get('_stacks', {}).values())
 
     def _stacked_conv(self, convs, x):
@@ -235,4 +239,24 @@ class Cell(nn.Module):
                 node_terms += [by_pos[p] for p in sorted(by_pos)]
             offset += nin + i
             add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True))
-        return self.post_process(torch.cat([states[nin + i] for i in range(nodes)], dim=1))
+        return self._post(states[nin:nin + nodes])
+
+    def _post(self, outs):
+        """post_process on the concatenated node outputs.  Three 8-channel nodes make 24 input channels, which fall off
+        the LDS convolution / weight-gradient kernels (16-channel passes, 32-row tiles): pad the concatenation with 8 zero
+        channels and the weight with 8 zero input planes (a persistent padded buffer, functional.StackedWeight) -- same
+        result, 32 -> 32 kernels."""
+        post = self.post_process
+        c_in = sum(o.shape[1] for o in outs)
+        if not self.stacked or c_in % 16 == 0 or c_in > 32 or c_in % 4 != 0:
+            return post(torch.cat(outs, dim=1))
+        stacks = self.__dict__.setdefault('_stacks', {})
+        key = ('post', id(post.conv))
+        if key not in stacks:
+            stacks[key] = F.StackedWeight([post.conv.weight], 1, pad_to=32)
+        o0 = outs[0]
+        zeros = torch.zeros((o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3]), device=o0.device).contiguous(memory_format=torch.channels_last)
+        x = torch.cat(list(outs) + [zeros], dim=1)
+        conv = post.conv
+        z, st = F.conv2d(x, stacks[key].tensor(), stride=1, pad=conv.padding[0], dil=1, want_stats=post.norm.training)
+        return F.bn_combine([F.Term(z, post.norm, stats=st)])

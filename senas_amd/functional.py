@@ -693,8 +693,9 @@ class StackedWeight(object):
     refills every stacked buffer of the model (one multi-tensor copy) and repacks its MFMA image together with all
     other weights at the start of a pass, so using it costs no launch at all."""
 
-    def __init__(self, params, dim, pad_parts=0):
+    def __init__(self, params, dim, pad_parts=0, pad_to=None):
         self.params, self.dim, self.pad_parts = list(params), dim, pad_parts
+        self.pad_to = pad_to                   # total size along dim (zero-filled beyond the parameters), overrides pad_parts
         self.buf = None
         self.managed = False
         self.filled = None                     # the parameters' version counters when a packer last filled the buffer
@@ -710,6 +711,8 @@ class StackedWeight(object):
         if self.buf is None or self.buf.device != p0.device:
             shape = list(p0.shape)
             shape[self.dim] = sum(p.shape[self.dim] for p in self.params) + self.pad_parts * p0.shape[self.dim]
+            if self.pad_to is not None:
+                shape[self.dim] = max(shape[self.dim], self.pad_to)
             # zero-filled: the padding parts (zero weights that bring a stack of three to a full 32-channel tile) stay zero
             self.buf = torch.zeros(shape, device=p0.device, dtype=p0.dtype)
             self.managed = False

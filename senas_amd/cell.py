@@ -106,7 +106,8 @@ class Cell(nn.Module):
             tr = isinstance(c0, nn.ConvTranspose2d)
             # three transposed 32 -> 8 candidates: a zero-weight fourth part makes the stack a full 32-channel tile, which
             # puts its weight gradient and data gradient on the LDS kernels (24 fine-grid channels fall off them)
-            pad = 1 if (tr and len(convs) == 3 and c0.out_channels * 4 == 32) else 0
+            # (the same for stride-1 Conv2d stacks: their data gradient gathers over the 24 stacked channels)
+            pad = 1 if (len(convs) == 3 and c0.out_channels * 4 == 32 and (tr or c0.stride[0] == 1)) else 0
             stacks[key] = F.StackedWeight([c.weight for c in convs], 1 if tr else 0, pad_parts=pad)
         return stacks[key]
 
@@ -194,8 +195,9 @@ class Cell(nn.Module):
                 self._stack([m.conv for m in mods])
 
                 def job(xs, mods=mods, p=p):
-                    z = self._stacked_conv([m.conv for m in mods], mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
-                    parts = F.unstack(z, len(mods), want_stats=mods[0].norm.training)
+                    convs = [m.conv for m in mods]
+                    z = self._stacked_conv(convs, mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
+                    parts = F.unstack(z, len(mods) + self._stack(convs).pad_parts, want_stats=mods[0].norm.training, used=len(mods))
                     return [(e, p, F.Term(zz, m.norm, stats=st, grad_slot=slot)) for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
             elif self.stacked and isinstance(m0, DepSepConv):

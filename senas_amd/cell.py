@@ -119,7 +119,7 @@ class Cell(nn.Module):
         c_in = post.conv.in_channels
         if self.stacked and c_in % 16 != 0 and c_in <= 32 and c_in % 4 == 0:
             self.__dict__.setdefault('_stacks', {}).setdefault(('post', id(post.conv)), F.StackedWeight([post.conv.weight], 1, pad_to=32))
-        return list(self.__dict__.get('_stacks', {}).values())
+        return [v for v in self.__dict__.get('_stacks', {}).values() if isinstance(v, F.StackedWeight)]
 
     def _stacked_conv(self, convs, x):
         """ONE convolution for the same-geometry convolutions of k edges that read the same tensor: weights stacked along
@@ -187,7 +187,8 @@ class Cell(nn.Module):
                     convs = [m[0] for m in mods]
                     z = self._stacked_conv(convs, xs[0])
                     se = isinstance(mods[0], ConvBnSe)
-                    parts = F.unstack(z, len(mods) + self._stack(convs).pad_parts, want_stats=mods[0][1].training or se, used=len(mods))
+                    sw = self._stack(convs)
+                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=mods[0][1].training or se, used=len(mods), owner=sw)
                     return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
                             for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
@@ -197,7 +198,8 @@ class Cell(nn.Module):
                 def job(xs, mods=mods, p=p):
                     convs = [m.conv for m in mods]
                     z = self._stacked_conv(convs, mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
-                    parts = F.unstack(z, len(mods) + self._stack(convs).pad_parts, want_stats=mods[0].norm.training, used=len(mods))
+                    sw = self._stack(convs)
+                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=mods[0].norm.training, used=len(mods), owner=sw)
                     return [(e, p, F.Term(zz, m.norm, stats=st, grad_slot=slot)) for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
             elif self.stacked and isinstance(m0, DepSepConv):
@@ -257,7 +259,10 @@ class Cell(nn.Module):
         if key not in stacks:
             stacks[key] = F.StackedWeight([post.conv.weight], 1, pad_to=32)
         o0 = outs[0]
-        zeros = torch.zeros((o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3]), device=o0.device).contiguous(memory_format=torch.channels_last)
+        zkey = ('zeros', o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3], str(o0.device))
+        if zkey not in stacks:                           # a constant: made once, only ever read
+            stacks[zkey] = torch.zeros((o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3]), device=o0.device).contiguous(memory_format=torch.channels_last)
+        zeros = stacks[zkey]
         x = torch.cat(list(outs) + [zeros], dim=1)
         conv = post.conv
         z, st = F.conv2d(x, stacks[key].tensor(), stride=1, pad=conv.padding[0], dil=1, want_stats=post.norm.training)

@@ -739,20 +739,26 @@ class GradLanding(object):
     part during a backward pass; when every part was written in place the un-stacking's backward pass hands the buffer
     on as it is (no concatenation launch)."""
 
-    def __init__(self, k, shape, used=None):
+    def __init__(self, k, shape, used=None, persistent=False):
         self.k, self.shape = k, shape                      # shape of ONE part (n, c, h, w)
         self.used = k if used is None else used            # parts beyond `used` are zero-weight padding: their gradient is zero
+        # persistent: the buffer lives across passes (owned by the stack it serves), so its padding parts are zeroed once,
+        # when it is allocated, and never again -- every pass rewrites exactly the used parts
+        self.persistent = persistent
         self.buf = None
 
     def part(self, e, like):
         n, c, h, w = self.shape
-        if self.buf is None:
-            self.buf = torch.empty((n, self.k * c, h, w), device=like.device, dtype=torch.float32, memory_format=CL)
+        if self.buf is None or self.buf.device != like.device:
+            make = torch.zeros if (self.persistent and self.used < self.k) else torch.empty
+            self.buf = make((n, self.k * c, h, w), device=like.device, dtype=torch.float32).contiguous(memory_format=CL)
         return self.buf[:, e * c:(e + 1) * c]
 
     def take(self, grads):
         """The buffer if ``grads`` are exactly its parts, else None; either way the buffer is released."""
-        buf, self.buf = self.buf, None
+        buf = self.buf
+        if not self.persistent:
+            self.buf = None
         if buf is None:
             return None
         n, c, h, w = self.shape
@@ -761,7 +767,7 @@ class GradLanding(object):
         for e, g in enumerate(grads):
             if g is None or g.data_ptr() != buf.data_ptr() + 4 * e * c or tuple(g.shape) != self.shape or g.stride() != buf[:, :c].stride():
                 return None
-        if self.used < self.k:
+        if self.used < self.k and not self.persistent:
             buf[:, self.used * c:].zero_()
         return buf
 
@@ -805,12 +811,22 @@ class _Unstack(torch.autograd.Function):
         return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None, None, None
 
 
-def unstack(z, k, want_stats=True, used=None):
+def unstack(z, k, want_stats=True, used=None, owner=None):
     """The per-edge parts of a stacked convolution output: [(z_e, stats_e or None, grad_slot_e)] for the first ``used`` of
-    its k parts (the rest is zero-weight padding)."""
+    its k parts (the rest is zero-weight padding).  ``owner``: an object (the stack's StackedWeight) that keeps the
+    gradient landing buffer of this shape from pass to pass."""
     used = k if used is None else used
     n, kc, h, w = z.shape
-    landing = GradLanding(k, (n, kc // k, h, w), used) if (kc // k) % 4 == 0 else None
+    landing = None
+    if (kc // k) % 4 == 0:
+        shape = (n, kc // k, h, w)
+        if owner is not None:
+            cache = owner.__dict__.setdefault('landings', {})
+            landing = cache.get((k, used, shape))
+            if landing is None:
+                landing = cache[(k, used, shape)] = GradLanding(k, shape, used, persistent=True)
+        else:
+            landing = GradLanding(k, shape, used)
     out = _Unstack.apply(z, k, want_stats, landing, used)
     return [(out[e], out[used + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(used)]
 

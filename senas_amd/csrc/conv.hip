@@ -451,6 +451,62 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const fl
 // stage 1: thread = (pixel lane, 4-channel group); per-tap partial sums in registers, reduced over the
 //          pixel lanes of the wave by shuffles and over the 4 waves through LDS -> part[block][c][tap]
 // stage 2: dw[c][tap] = sum over blocks (fixed order: bitwise reproducible)
+// the same sum over problems as a 4-columns-per-thread PLAIN gather (dilation 1): the data gradient of k transposed
+// depthwise convolutions (gather over dy_p at the convolution's stride) or of k stride-1 ones (flip: kernels turned by 180 degrees)
+template <int KS, int S>
+__global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g, DwTab tab, int k, int flip, float* __restrict__ out, long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C]
+    constexpr int TAPS = KS * KS, COLS = 3 * S + KS;
+    const int C = g.cout;
+    for (int i = threadIdx.x; i < k * TAPS * C; i += 256) {
+        const int p = i / (TAPS * C), r = i - p * TAPS * C, t = r / C, cc = r - t * C;
+        wl[i] = tab.w[p][cc * TAPS + (flip ? TAPS - 1 - t : t)];
+    }
+    __syncthreads();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C >> 2, wq = g.wout >> 2;
+    const int c = (int)(idx % cv) * 4;
+    long r = idx / cv;
+    const int ox0 = (int)(r % wq) * 4;
+    r /= wq;
+    const int oy = (int)(r % g.hout), n = (int)(r / g.hout);
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
+    const int ix0 = ox0 * S - g.pad;
+    for (int p = 0; p < k; ++p) {
+        const float* __restrict__ in = tab.a[p];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy * S - g.pad + ky;
+            if (iy < 0 || iy >= g.hin) continue;
+            const float* row = in + ((size_t)(n * g.hin + iy) * g.win) * g.cin + c;
+            float4 col[COLS];
+#pragma unroll
+            for (int x = 0; x < COLS; ++x) {
+                const int ix = ix0 + x;
+                col[x] = (ix >= 0 && ix < g.win) ? *reinterpret_cast<const float4*>(row + (size_t)ix * g.cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const float4 wt = *reinterpret_cast<const float4*>(wl + ((size_t)p * TAPS + ky * KS + kx) * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = col[j * S + kx];
+                    acc[j][0] = fmaf(v.x, wt.x, acc[j][0]); acc[j][1] = fmaf(v.y, wt.y, acc[j][1]);
+                    acc[j][2] = fmaf(v.z, wt.z, acc[j][2]); acc[j][3] = fmaf(v.w, wt.w, acc[j][3]);
+                }
+            }
+        }
+    }
+    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox0) * C + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stv<4>(out + o + (size_t)j * C, acc[j]);
+}
+
 template <int KS>
 __device__ __forceinline__ void dwconv_wgrad_part_body(const WgradGeom& g, const float* __restrict__ I,
                                                        const float* __restrict__ G, float* __restrict__ part,
@@ -1014,8 +1070,18 @@ extern "C" int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, cons
         SENAS_REQUIRE(dy[p] && w[p], "dwconv_multi_bwd_data: null pointer");
         tab.a[p] = dy[p]; tab.w[p] = w[p];
     }
-    const long total = (long)g->n * g->hi * g->wi * (g->ci / 4);
     const size_t lds = (size_t)k * g->kh * g->kw * g->ci * sizeof(float);
+    const bool flip = !g->transposed && g->stride == 1 && g->hi == g->ho && g->wi == g->wo && g->pad == g->dil * (g->kh / 2);
+    if ((g->transposed || flip) && dw_x4_ok(gg, 0)) {                  // a plain gather: four output columns per thread
+        const long total4 = (long)g->n * g->hi * (g->wi / 4) * (g->ci / 4);
+        dim3 grid4((unsigned)((total4 + 255) / 256));
+#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KS_, S_>), grid4, dim3(256), lds, as_stream(stream), gg, tab, k, flip ? 1 : 0, dx, total4)
+        if (g->kh == 3) { if (gg.stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
+        else { if (gg.stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#undef SENAS_X4
+        return launch_status("dwconv_multi_bwd_data (x4)");
+    }
+    const long total = (long)g->n * g->hi * g->wi * (g->ci / 4);
     dim3 grid((unsigned)((total + 255) / 256));
     if (!g->transposed) hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);
     else hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);

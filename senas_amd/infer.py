@@ -67,7 +67,7 @@ class Evaluator(object):
         torch.cuda.synchronize()
         reset_arena()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
             self.logits, self.mask = self._eager()
         reset_arena()
         self.graph = graph

@@ -225,6 +225,9 @@ int launch_stem_mfma(const GatherGeom& g, const float* in, const float* w, float
 
 // conv_thin.hip (one side of the GEMM view has <= 4 channels: HBM-bound single-pass kernels; weights in torch layout)
 bool thin_k_ok(const GatherGeom& g);
+bool thin_k4_ok(const GatherGeom& g);     // stride-1 plain gather, 4 output columns per thread
+int launch_thin_k4(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, int in_relu,
+                   double* stats, hipStream_t st);
 template <bool TG>
 int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   const float* mask, double* stats, hipStream_t st);

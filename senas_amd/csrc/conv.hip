@@ -715,6 +715,7 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     if (!g->transposed && stem_mfma_ok(gg)) return launch_stem_mfma(gg, x, w, y, in_relu, stats, st);
     // thin shapes (stem, head): single-pass HBM-bound kernels that read the torch-layout weights directly
     if (thin_k_ok(gg)) {
+        if (!g->transposed && thin_k4_ok(gg)) return launch_thin_k4(gg, x, w, g->ci, 1, 0, y, in_relu, stats, st);
         if (!g->transposed) return launch_thin_k<false>(gg, x, w, g->ci, 1, y, in_relu, nullptr, stats, st);
         return launch_thin_k<true>(gg, x, w, g->co, 0, y, in_relu, nullptr, stats, st);
     }
@@ -815,6 +816,8 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
         return launch_status("dwconv_bwd_data");
     }
     if (thin_k_ok(gg)) {
+        // a stride-1 "same" Conv2d: its data gradient is the plain gather over dy with the kernel turned by 180 degrees
+        if (!g->transposed && mask == nullptr && thin_k4_ok(gg)) return launch_thin_k4(gg, dy, w, g->ci, 0, 1, dx, 0, nullptr, st);
         if (!g->transposed) return launch_thin_k<true>(gg, dy, w, g->ci, 0, dx, 0, mask, nullptr, st);
         return launch_thin_k<false>(gg, dy, w, g->co, 1, dx, 0, mask, nullptr, st);
     }

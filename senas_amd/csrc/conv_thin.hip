@@ -111,6 +111,112 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(GatherGeom g, const fl
     }
 }
 
+// thin-K PLAIN gather, stride 1, FOUR consecutive output columns x 4 output channels per thread: a weight quad read from LDS
+// serves four pixels (16 FMAs per ds_read_b128 instead of 4) and the 16 accumulators give the VALU independent chains --
+// the one-pixel form above runs the supernet's 8 -> 8 / 8 -> 16 5x5 inner-edge convolutions at ~9 TF/s.
+// flip: taps mirrored (the data gradient of a stride-1 "same" Conv2d is this gather over dy with the kernel turned by
+// 180 degrees).  cin in {4, 8}; wout % 4 == 0; no mask.
+__global__ __launch_bounds__(256) void conv_thin_k4_kernel(GatherGeom g, const float* __restrict__ in,
+                                                           const float* __restrict__ w, int d1, int swap, int flip,
+                                                           float* __restrict__ out, int in_relu, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int taps = g.kh * g.kw;
+    const int wfloats = taps * g.cin * g.cout;
+    for (int i = threadIdx.x; i < wfloats; i += 256) {
+        const int b = i % g.cout, a = (i / g.cout) % g.cin, t = i / (g.cout * g.cin);
+        lds[i] = weight_at(w, d1, taps, swap, flip ? taps - 1 - t : t, a, b);
+    }
+    double* sred = reinterpret_cast<double*>(lds + ((wfloats + 3) & ~3));
+    if (stats != nullptr && threadIdx.x < 2 * g.cout) sred[threadIdx.x] = 0.0;
+    __syncthreads();
+
+    const int Q = g.cout >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, gpb = 256 / Q;      // pixel GROUPS per block
+    const int n = blockIdx.y, wq = g.wout >> 2, groups = g.hout * wq;
+    const int grp = blockIdx.x * gpb + pl;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    if (grp < groups) {
+        const int oy = grp / wq, ox0 = (grp - oy * wq) * 4;
+        float acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            const int iy = oy - g.pad + ky * g.dil;
+            if (iy < 0 || iy >= g.hin) continue;
+            const float* row = in + ((size_t)(n * g.hin + iy) * g.win) * g.cin;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const float* wt = lds + (ky * g.kw + kx) * g.cin * g.cout + q * 4;
+                const int ixb = ox0 - g.pad + kx * g.dil;
+                for (int c4 = 0; c4 < g.cin; c4 += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ix = ixb + j;
+                        v[j] = (ix >= 0 && ix < g.win) ? *reinterpret_cast<const float4*>(row + (size_t)ix * g.cin + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (in_relu) { v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f); }
+                    }
+                    const float4 w0 = *reinterpret_cast<const float4*>(wt + (c4 + 0) * g.cout), w1 = *reinterpret_cast<const float4*>(wt + (c4 + 1) * g.cout),
+                                 w2 = *reinterpret_cast<const float4*>(wt + (c4 + 2) * g.cout), w3 = *reinterpret_cast<const float4*>(wt + (c4 + 3) * g.cout);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j][0] = fmaf(v[j].x, w0.x, fmaf(v[j].y, w1.x, fmaf(v[j].z, w2.x, fmaf(v[j].w, w3.x, acc[j][0]))));
+                        acc[j][1] = fmaf(v[j].x, w0.y, fmaf(v[j].y, w1.y, fmaf(v[j].z, w2.y, fmaf(v[j].w, w3.y, acc[j][1]))));
+                        acc[j][2] = fmaf(v[j].x, w0.z, fmaf(v[j].y, w1.z, fmaf(v[j].z, w2.z, fmaf(v[j].w, w3.z, acc[j][2]))));
+                        acc[j][3] = fmaf(v[j].x, w0.w, fmaf(v[j].y, w1.w, fmaf(v[j].z, w2.w, fmaf(v[j].w, w3.w, acc[j][3]))));
+                    }
+                }
+            }
+        }
+        const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox0) * g.cout + q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(out + o + (size_t)j * g.cout) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s[c] += (double)acc[j][c];
+                ss[c] += (double)acc[j][c] * (double)acc[j][c];
+            }
+        }
+    }
+    if (stats != nullptr) {           // lanes that share q (stride Q inside the wave) -> LDS -> one atomic per channel per block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int o = Q; o < 64; o <<= 1) {
+                s[j] += __shfl_xor(s[j], o, 64);
+                ss[j] += __shfl_xor(ss[j], o, 64);
+            }
+        }
+        if ((threadIdx.x & 63) < Q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&sred[(q * 4 + j) * 2], s[j]);
+                atomicAdd(&sred[(q * 4 + j) * 2 + 1], ss[j]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * g.cout) atomicAdd(stats + (size_t)n * g.cout * 2 + threadIdx.x, sred[threadIdx.x]);
+    }
+}
+
+bool thin_k4_ok(const GatherGeom& g) {
+    const int q = g.cout >> 2;
+    // (a quarter of the one-pixel form's threads: only where that still fills the chip -- measured: 128x128x4 images up)
+    if ((long)g.n * g.hout * g.wout < 4L * 128 * 128) return false;
+    return g.stride == 1 && (g.cin == 4 || g.cin == 8) && g.cout % 4 == 0 && q >= 1 && q <= 4 && (q & (q - 1)) == 0 && g.wout % 4 == 0 &&
+           g.hout == g.hin && g.wout == g.win && g.kh == g.kw && g.pad == g.dil * (g.kh / 2) && g.kh * g.kw * g.cin * g.cout <= 8192 &&
+           (long)g.n * g.hout * g.wout * g.cout < 0x7fffffffL && g.n <= 65535;
+}
+
+int launch_thin_k4(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, int in_relu,
+                   double* stats, hipStream_t st) {
+    const int gpb = 256 / (g.cout >> 2), groups = g.hout * (g.wout >> 2);
+    dim3 grid((groups + gpb - 1) / gpb, g.n);
+    const size_t bytes = (size_t)((g.kh * g.kw * g.cin * g.cout + 3) & ~3) * sizeof(float) + (size_t)2 * g.cout * sizeof(double);
+    hipLaunchKernelGGL(conv_thin_k4_kernel, grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, in_relu, stats);
+    return launch_status("conv_thin_k4");
+}
+
 bool thin_k_ok(const GatherGeom& g) {
     const int q = g.cout >> 2;
     return g.cin <= 8 && g.cout % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin * g.cout <= 8192 &&

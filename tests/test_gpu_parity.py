@@ -463,6 +463,8 @@ _CONV_CASES = [
     (2, 3, 32, 40, 72, 7, 1, 1, False, False),      # RGB stem on the MFMA stem kernel (K = 147), ragged tiles
     (2, 1, 64, 16, 32, 7, 1, 1, False, True),       # stem with 64 outputs (two channel tiles), ReLU on load
     (2, 2, 32, 24, 40, 3, 1, 2, False, False),      # 2 input channels, dilated 3x3 (K = 18)
+    (4, 8, 16, 128, 128, 5, 1, 3, False, False),    # big-map inner edge: 4-columns-per-thread thin-K gather, forward and (flipped) data gradient
+    (4, 8, 8, 128, 132, 3, 1, 1, False, True),      # ... 3x3 with ReLU on load (the masked data gradient stays on the one-pixel form)
     (2, 8, 16, 24, 24, 5, 1, 2, False, False),      # stacked search candidates: two 8 -> 8 inner edges (c8 weight gradient, 16 columns)
     (2, 8, 12, 16, 16, 3, 1, 1, False, True),       # ... 12 columns (padded)
     (2, 32, 24, 32, 32, 5, 1, 3, False, False),     # three 32 -> 8 candidates stacked: 24 outputs; data gradient from 24 channels

@@ -9,7 +9,6 @@ dice_ce / dice_loss run as ``senas_dice_ce_fwd`` / ``senas_dice_ce_bwd`` (SURVEY
 the logits per direction, no one-hot tensor, no host round trip (the reference builds the one-hot on the CPU
 and copies it over, loss.py:199-203).  Like every op of this package there is no CPU path.
 """
-import ctypes as C
 
 import torch
 import torch.nn as nn

@@ -17,7 +17,6 @@ load inside the convolution kernel.
 """
 from enum import Enum
 
-import torch
 import torch.nn as nn
 
 from . import functional as F

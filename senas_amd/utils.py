@@ -1,5 +1,4 @@
 """Small host-side helpers of the hot path."""
-import torch
 import torch.nn as nn
 
 

@@ -91,13 +91,34 @@ class GradAllReducer(object):
         have = [(v, p.grad) for v, p in zip(self.views, self._order) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for v, p in zip(self.views, self._order) if p.grad is None]
         if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            self._gather(have)
         for v in missing:                                 # a parameter unused this step contributes zeros
             v.zero_()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
         for v, p in zip(self.views, self._order):
             p.grad = v
+
+    def _gather(self, have):
+        """Gradients -> flat buffer.  On the GPU: ONE launch (senas_copy_rows_batched) over a device table that is rebuilt
+        only when a gradient moved (under HIP-graph replay they never do); torch's multi-tensor copy issues one
+        device-to-device copy per tensor -- ~800 launches per step for the derived network."""
+        if not self.cuda or any(not g.is_contiguous() or g.dtype != torch.float32 for _, g in have):
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            return
+        import ctypes as C
+        from . import _lib
+        from . import functional as F
+        from .packing import _CopyItem
+        key = tuple(g.data_ptr() for _, g in have)
+        if getattr(self, '_gather_key', None) != key:
+            items = [_CopyItem(g.data_ptr(), v.data_ptr(), 1, g.numel(), g.numel()) for v, g in have]
+            raw = bytes((_CopyItem * len(items))(*items))
+            self._gather_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(have[0][0].device)
+            self._gather_key, self._gather_n = key, len(items)
+            self._gather_max = max(it.row_len for it in items)
+        _lib.check(_lib.lib().senas_copy_rows_batched(self._gather_table.data_ptr(), self._gather_n, self._gather_max, F._stream()),
+                   'senas_copy_rows_batched')
 
     # ------------------------------------------------------------------ overlapped mode
     def _attach(self):

@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the SENAS hot path on MI355X: images/sec of the derived-genotype train step
-(BASELINE.json configs[1]: models/senas_model.py, README genotype, 8x1x256x256 per GPU), plus --
-for reference in the same JSON line -- the supernet search step (configs[2], 4x1x256x256).
+(BASELINE.json configs[1]: models/senas_model.py, README genotype, 8x1x256x256 per GPU) and -- in the same JSON
+line, under ``search_step`` -- of the supernet search step (configs[2] / [3]: 4x1x256x256 per GPU).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = zero_grad -> forward -> Dice+CE loss -> backward -> (gradient all-reduce) -> clip_grad_norm_(5)
--> SGD step, on a synthetic batch already resident in HBM.  Weak scaling: 8 images per GPU.
+With N > 1 and no torch.distributed environment, this process only starts N ranks (``python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>``, one rank per GPU over RCCL) before
+touching any GPU, relays rank 0's JSON line and fails unless that line says ``n_gpus == N``; started by the driver's
+own torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+
+One train "step" = zero_grad -> forward -> Dice+CE loss -> backward -> (gradient all-reduce) -> clip_grad_norm_(5)
+-> SGD step, on a synthetic batch already resident in HBM.  Weak scaling: 8 (train) / 4 (search) images per GPU.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -26,9 +27,63 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3        # fp32 MFMA (= vector) dense peak
+# SURVEY.md section 8(d) contract figures (forward hooks on the oracle; fwd + bwd = 3 x fwd)
+DERIVED_GFLOP_PER_IMG = 126.6          # derived net, 1x256x256, one step
+DERIVED_GB_PER_IMG = 1.233
+SUPERNET_GB_PER_IMG = 5.690            # supernet S4, one fwd + bwd
+SUPERNET_GFLOP_PER_IMG = 88.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200, help='timed train steps (default: ~3.5 s of GPU time)')
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--search-steps', type=int, default=60, help='timed supernet search steps (0 = skip)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run forward+backward eagerly instead of replaying a HIP graph')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
+    ap.add_argument('--one-device', action='store_true',
+                    help='rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)')
+    return ap.parse_args(argv)
+
+
+def log(msg):
+    """Progress on stderr (the one JSON line goes to stdout)."""
+    sys.stderr.write('[bench %s] %s\n' % (time.strftime('%H:%M:%S'), msg))
+    sys.stderr.flush()
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run: no GPU call is made in this process."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in done.stdout.decode().splitlines():
+        if raw.startswith('{') and '"metric"' in raw:
+            line = raw
+    if done.returncode != 0 or line is None:
+        sys.stderr.write(done.stdout.decode()[-4000:])
+        sys.exit(done.returncode or 3)
+    if json.loads(line).get('n_gpus') != args.gpus:
+        sys.stderr.write('bench: asked for %d GPUs, the ranks report n_gpus=%s\n' % (args.gpus, json.loads(line).get('n_gpus')))
+        sys.exit(4)
+    print(line)
+    sys.exit(0)
 
 
 def build_derived(dev):
+    import torch
     from senas_amd.geno_searched import senas_node_4
     from senas_amd.models import get_segmentation_model
     from senas_amd.utils import weights_init
@@ -39,55 +94,12 @@ def build_derived(dev):
     return net.to(dev).train()
 
 
-def synthetic(batch, in_ch, ncls, size, rank, dev):
-    g = torch.Generator().manual_seed(1 + rank)
+def synthetic(batch, in_ch, ncls, size, seed, dev):
+    import torch
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(batch, in_ch, size, size, generator=g)
     y = torch.randint(0, ncls, (batch, size, size), generator=g)
     return x.to(dev), y.to(dev)
-
-
-def cpu_baseline_train(batch, size, reps=3):
-    """The CPU oracle (a port of the reference's torch-CPU path, pinned by the golden vectors) running the
-    identical train step on the host cores -- a reported baseline, not the thing measured."""
-    from oracle import senas_ref as R
-    from senas_amd.geno_searched import senas_node_4
-    from senas_amd.senas_model import SenasModel
-    from senas_amd.utils import weights_init
-    torch.manual_seed(0)
-    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
-    net.apply(weights_init)
-    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    for k in list(sd):
-        if k.startswith('blocks.0.0.'):
-            sd[k] = sd['stem1.' + k[len('blocks.0.0.'):]]
-    params = []
-    for k, v in sd.items():
-        if v.is_floating_point() and 'running' not in k and not k.startswith('blocks.0.0.'):
-            v.requires_grad_(True)
-            params.append(v)
-    opt = torch.optim.SGD(params, lr=6e-3, weight_decay=5e-4, momentum=0.9)
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(batch, 1, size, size, generator=g)
-    y = torch.randint(0, 2, (batch, size, size), generator=g)
-    geno = R.Genotype(*senas_node_4)
-    times = []
-    for i in range(reps + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        loss = R.dice_ce_loss(R.derived_forward(sd, x, geno)[-1], y)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 5)
-        opt.step()
-        log('cpu baseline step %d: %.2f s' % (i, time.perf_counter() - t0))
-        if i > 0:
-            times.append(time.perf_counter() - t0)
-    return batch / min(times)
-
-
-def log(msg):
-    """Progress on stderr (the one JSON line goes to stdout)."""
-    sys.stderr.write('[bench %s] %s\n' % (time.strftime('%H:%M:%S'), msg))
-    sys.stderr.flush()
 
 
 def host_threads():
@@ -110,28 +122,140 @@ def cpu_model_name():
     return 'unknown'
 
 
+def _oracle_leaves(net, prefix=''):
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    a, b = prefix + 'blocks.0.0.', prefix + 'stem1.'
+    for k in list(sd):
+        if k.startswith(a):
+            sd[k] = sd[b + k[len(a):]]
+    params = []
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k and not k.startswith(a):
+            v.requires_grad_(True)
+            params.append(v)
+    return sd, params
+
+
+def cpu_baseline_train(batch, size, reps=3):
+    """The CPU oracle (a port of the reference's torch-CPU path, pinned by the golden vectors) running the
+    identical train step on the host cores -- a reported baseline, not the thing measured."""
+    import torch
+    from oracle import senas_ref as R
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.utils import weights_init
+    torch.manual_seed(0)
+    net = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
+    net.apply(weights_init)
+    sd, params = _oracle_leaves(net)
+    opt = torch.optim.SGD(params, lr=6e-3, weight_decay=5e-4, momentum=0.9)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, 1, size, size, generator=g)
+    y = torch.randint(0, 2, (batch, size, size), generator=g)
+    geno = R.Genotype(*senas_node_4)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.dice_ce_loss(R.derived_forward(sd, x, geno)[-1], y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt.step()
+        log('cpu baseline (train) step %d: %.2f s' % (i, time.perf_counter() - t0))
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    return batch / min(times)
+
+
+def cpu_baseline_search(batch, size, reps=2):
+    """The oracle running one search step (architecture pass on a validation batch + Adam, weight pass on a training
+    batch + clip + SGD; experiments/search_arc.py:252-299) on the host cores."""
+    import torch
+    from oracle import senas_ref as R
+    from senas_amd.senas_search import NAS
+    torch.manual_seed(0)
+    net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device='cpu')
+    sd, params = _oracle_leaves(net, 'net.')
+    arch = [sd[k] for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma')]
+    opt_w = torch.optim.SGD(params, lr=5e-3, weight_decay=3e-4, momentum=0.9)
+    opt_a = torch.optim.Adam(arch, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+    g = torch.Generator().manual_seed(1)
+    xt, yt = torch.randn(batch, 1, size, size, generator=g), torch.randint(0, 2, (batch, size, size), generator=g)
+    xv, yv = torch.randn(batch, 1, size, size, generator=g), torch.randint(0, 2, (batch, size, size), generator=g)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        opt_a.zero_grad()
+        R.dice_ce_loss(R.nas_forward(sd, xv)[-1], yv).backward()
+        opt_a.step()
+        opt_w.zero_grad()
+        R.dice_ce_loss(R.nas_forward(sd, xt)[-1], yt).backward()
+        torch.nn.utils.clip_grad_norm_(params, 5)
+        opt_w.step()
+        log('cpu baseline (search) step %d: %.2f s' % (i, time.perf_counter() - t0))
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    return batch / min(times)
+
+
+def timed(step, steps, world, dev):
+    """EXACTLY ``steps`` calls bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), out
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of kernel ``name`` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs over this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; aggregated by
+    tools/pmc_traffic.py).  Returns (bytes or None, source)."""
+    for fname in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', fname)
+        try:
+            pmc = json.load(open(path))
+            rec = pmc['kernels'].get(name)
+            if rec is None:                          # symbol spelled with fewer defaulted template arguments
+                close = [v for k, v in pmc['kernels'].items() if k.startswith(name[:-1] + ',')]
+                rec = max(close, key=lambda v: v['launches']) if close else None
+            if rec:
+                return int((2 * rec['fetch_kb_avg'] + rec['write_kb_avg']) * 1024), \
+                    'profiles/%s (rocprofv3 --pmc passes of an earlier run of this command; not measured in this run)' % fname
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--search-steps', type=int, default=2, help='timed supernet search steps (0 = skip)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='run forward+backward eagerly instead of replaying a HIP graph')
-    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
-    ap.add_argument('--one-device', action='store_true',
-                    help='rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args)                          # never returns
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        log('WORLD_SIZE=%d but --gpus %d: reporting the world size actually running' % (world, args.gpus))
     dev_index = 0 if args.one_device else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ:
+            log('HSA_ENABLE_IPC_MODE_LEGACY is not exported; setting it to 0 (dmabuf IPC) for RCCL')
+            os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
         torch.cuda.set_device(dev_index)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
@@ -150,10 +274,9 @@ def main():
         broadcast_parameters(net)
     crit = SegmentationLosses('dice_ce')
     opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)     # senas_promise12.yml training block
-    x, y = synthetic(args.batch, 1, 2, args.size, rank, dev)
-    params = [p for p in net.parameters()]
+    x, y = synthetic(args.batch, 1, 2, args.size, 1 + rank, dev)
     from senas_amd.step import TrainStep
-    log('model on %s, %d params; %s forward+backward' % (dev, sum(p.numel() for p in params),
+    log('model on %s, %d params; %s forward+backward' % (dev, sum(p.numel() for p in net.parameters()),
                                                           'eager' if args.no_graph else 'capturing HIP graph of'))
     step = TrainStep(net, crit, opt, x, y, world_size=world, grad_clip=5.0, use_graph=not args.no_graph)
     log('warm-up x%d' % args.warmup)
@@ -161,31 +284,21 @@ def main():
         step()
     torch.cuda.synchronize()
     log('timing %d steps' % args.steps)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # per-kernel HIP-event timing: the same step run eagerly right after the timed region (events cannot
+    elapsed, loss = timed(step, args.steps, world, dev)
+    # per-kernel HIP-event timing: the same pass run eagerly right after the timed region (events cannot
     # be read back from inside a replayed graph; kernel durations are the same in both modes)
     probe_steps = 2
+    early, step.fb.early = step.fb.early, None                  # (no collective inside the probe passes)
     F.TIMER = F.KernelTimer()
     for _ in range(probe_steps):
         step.fb._eager()
     timer, F.TIMER = F.TIMER, None
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    step.fb.early = early
     images = args.batch * world * args.steps
     value = images / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, over the timed region)
+    # ---- roofline of the dominant kernel (HIP events on the launch stream)
     event_overhead_ms = F.KernelTimer.empty_pair_ms()
     agg = timer.summary(event_overhead_ms)
     roof = None
@@ -197,20 +310,7 @@ def main():
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         per_launch_ms = a['ms'] / a['launches']
         tflops = a['flops'] / (a['ms'] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this
-        # very command, averaged per kernel symbol, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-        # gfx950; committed as profiles/r1_pmc_traffic.json by tools/pmc_traffic.py (null if not collected)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')))
-            rec = pmc['kernels'].get(name)
-            if rec is None:                          # symbol spelled with fewer defaulted template arguments
-                close = [v for k, v in pmc['kernels'].items() if k.startswith(name[:-1] + ',')]
-                rec = max(close, key=lambda v: v['launches']) if close else None
-            if rec:
-                traffic = int((2 * rec['fetch_kb_avg'] + rec['write_kb_avg']) * 1024)
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic, traffic_source = pmc_traffic(name)
         # the same kernel symbol serves several layer shapes: per-geometry rates of its launches (n,hi,wi,ci,ho,wo,co,kh,kw,s,p,d)
         by_geo = {}
         for rname, flops, nbytes, e0, e1, tag in timer.records:
@@ -222,78 +322,114 @@ def main():
                 b[2] += flops
         geo_rows = [{'geometry': ','.join(str(v) for v in k), 'launches': v[0], 'avg_ms': round(v[1] / v[0], 4),
                      'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(by_geo.items(), key=lambda kv: -kv[1][1])[:4]]
+        step_tflops = args.batch * DERIVED_GFLOP_PER_IMG / ms_per_step
         roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(tflops, 3), 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'launches': a['launches'],
+                'frac': round(tflops / F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+                'launches': a['launches'],
                 'algorithmic_bytes_per_launch': int(a['bytes'] / a['launches']),
                 'avg_launch_ms': round(per_launch_ms, 4),
                 'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 3),
-                'share_of_step': round((a['ms'] / probe_steps) / (1e3 * elapsed / args.steps), 3),
+                'share_of_step': round((a['ms'] / probe_steps) / ms_per_step, 3),
                 'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / probe_steps, 2),
+                # the whole step against the same roof: SURVEY 8(d) FLOPs of one step / step time / peak
+                'step_achieved': round(step_tflops, 2), 'step_frac': round(step_tflops / F32_PEAK_TFLOPS, 4),
+                'step_hbm_gbs_algorithmic': round(args.batch * DERIVED_GB_PER_IMG / (ms_per_step * 1e-3), 1),
                 'event_pair_overhead_us': round(1e3 * event_overhead_ms, 2),
                 'by_geometry': geo_rows,
-                'timing_source': 'HIP events around each launch, %d eager steps right after the timed region; every span '
+                'timing_source': 'HIP events around each launch, %d eager passes right after the timed region; every span '
                                  'less the reading of an empty event pair' % probe_steps}
 
     out = {
-        'metric': 'images/sec at 256x256 - senas derived-genotype train step (fwd+loss+bwd+clip+SGD)',
+        'metric': 'images/sec at 256x256 - senas derived-genotype train step (fwd+loss+bwd+clip+SGD); supernet search step under search_step',
         'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (randn slices, randint labels, seed 1+rank), random-init weights',
         'config': {'workload': 'BASELINE configs[1]: SenasModel README genotype (senas_node_4), c=32 depth=5, '
                                '%dx1x%dx%d per GPU, fp32' % (args.batch, args.size, args.size),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach()),
-                   'hip_graph': bool(step.graphed)},
+                   'hip_graph': bool(step.graphed), 'timed_region_s': round(elapsed, 3),
+                   'allreduce_overlapped_with_backward': bool(step.fb.graph_tail is not None)},
         'roofline': roof,
     }
+    log('train step: %.2f ms/step, %.2f images/s' % (ms_per_step, value))
+    step.close()
+    del step, net, opt
 
-    log('train step: %.2f ms/step, %.2f images/s' % (1e3 * elapsed / args.steps, value))
-    if rank == 0 and world == 1 and args.search_steps > 0:
-        out["search_step"] = bench_search(dev, args.search_steps, use_graph=not args.no_graph)
-        log('search step: %s' % json.dumps(out['search_step']))
+    if args.search_steps > 0:
+        out['search_step'] = bench_search(dev, args.search_steps, rank, world, use_graph=not args.no_graph)
+        if rank == 0:
+            log('search step: %s' % json.dumps(out['search_step']))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        torch.set_num_threads(host_threads())
+        threads = host_threads()
+        torch.set_num_threads(threads)
         log('cpu baseline on %d threads (cpu_count %s)' % (torch.get_num_threads(), os.cpu_count()))
-        cb = args.batch
-        v = cpu_baseline_train(cb, args.size, reps=2)
-        out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                               'cpu': cpu_model_name(),
-                               'sample': 'same train step (oracle/senas_ref.py, torch-CPU fp32) on %dx1x%dx%d, best of 2 after 1 warm-up' % (cb, args.size, args.size)}
+        common = {'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model_name(),
+                  'thread_cap': 'min(cores this process may run on, 16 = the GPU box\'s per-GPU CPU share); host reports %s CPUs' % os.cpu_count()}
+        v = cpu_baseline_train(args.batch, args.size, reps=3)
+        out['cpu_baseline'] = dict(common, value=round(v, 3),
+                                   sample='same train step (oracle/senas_ref.py, torch-CPU fp32) on %dx1x%dx%d, best of 3 after 1 warm-up'
+                                          % (args.batch, args.size, args.size))
+        if 'search_step' in out:
+            v = cpu_baseline_search(4, 256, reps=2)
+            out['search_step']['cpu_baseline'] = dict(common, value=round(v, 3),
+                                                      sample='same search step (arch pass + Adam, weight pass + clip + SGD) on 4+4 images '
+                                                             '1x256x256, best of 2 after 1 warm-up; train images per second')
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_search(dev, steps, use_graph=True):
-    """Supernet search step (BASELINE configs[2]): arch step on 4 validation images (Adam) + weight step on
-    4 train images (SGD, clip 5) -- experiments/search_arc.py:252-299.  images/sec counts train images."""
+def bench_search(dev, steps, rank, world, use_graph=True):
+    """Supernet search step (BASELINE configs[2]; configs[3] with N ranks): arch step on 4 validation images (Adam) +
+    weight step on 4 train images (SGD, clip 5) per GPU -- experiments/search_arc.py:252-299.  images/sec counts train
+    images, whole job."""
+    import torch
     from senas_amd.loss import SegmentationLosses
+    from senas_amd.parallel import broadcast_parameters
     from senas_amd.senas_search import NAS
     from senas_amd.step import SearchStep
     torch.manual_seed(0)
     net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False, device=dev).to(dev).train()
+    if world > 1:
+        broadcast_parameters(net)
     crit = SegmentationLosses('dice_ce')
     opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
     opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
-    xt, yt = synthetic(4, 1, 2, 256, 0, dev)
-    xv, yv = synthetic(4, 1, 2, 256, 100, dev)
+    xt, yt = synthetic(4, 1, 2, 256, 1 + rank, dev)
+    xv, yv = synthetic(4, 1, 2, 256, 101 + rank, dev)
     log('search: supernet built, capturing forward+backward')
-    search = SearchStep(net, crit, opt_w, opt_a, xt.clone(), yt.clone(), grad_clip=5.0, use_graph=use_graph)
+    search = SearchStep(net, crit, opt_w, opt_a, xt.clone(), yt.clone(), world_size=world, grad_clip=5.0, use_graph=use_graph,
+                        count_nodes=use_graph and world == 1)
 
     def step():
-        search(xt, yt, xv, yv)
+        return search(xt, yt, xv, yv)
 
-    log('search: warm-up step')
-    step()
-    torch.cuda.synchronize()
-    log('search: timing %d steps' % steps)
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    log('search: warm-up steps')
+    for _ in range(2):
         step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {'workload': 'BASELINE configs[2]: NAS supernet c=32 depth=5 nodes=3, arch step (4 val) + weight step (4 train), 1x256x256',
-            "train_images_per_sec": round(4 / dt, 3), "ms_per_step": round(dt * 1e3, 2), "steps": steps, "hip_graph": bool(search.graphed)}
+    log('search: timing %d steps' % steps)
+    elapsed, _ = timed(step, steps, world, dev)
+    dt = elapsed / steps
+    # algorithmic HBM bytes of one step per GPU (SURVEY 8(d): 5.690 GB per image for forward + backward = 3 x forward):
+    # the weight pass is a full forward + backward over 4 images; the architecture pass runs with the weights frozen --
+    # forward + data gradients, no weight gradients -- and is charged 2/3 of that
+    gbytes = 4 * SUPERNET_GB_PER_IMG * (1.0 + 2.0 / 3.0)
+    achieved = gbytes / dt
+    res = {'workload': 'BASELINE configs[%d]: NAS supernet c=32 depth=5 nodes=3, arch step (4 val) + weight step (4 train) per GPU, 1x256x256'
+                       % (2 if world == 1 else 3),
+           'value': round(4 * world / dt, 3), 'unit': 'train images/s', 'n_gpus': world, 'train_images_per_sec': round(4 * world / dt, 3),
+           'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'timed_region_s': round(elapsed, 3), 'hip_graph': bool(search.graphed),
+           'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'algorithmic_gb_per_step': round(gbytes, 2),
+                        'convention': '4 img x 5.690 GB (weight pass, fwd+bwd) + 4 img x 2/3 x 5.690 GB (architecture pass: '
+                                      'weights frozen, forward + data gradients only); whole step, not one kernel -- the step is '
+                                      'thousands of 3-40 us launches, no single kernel carries more than a few percent',
+                        'graph_nodes_per_step': search.graph_nodes()}}
+    search.close()
+    return res
 
 
 if __name__ == '__main__':

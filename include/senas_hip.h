@@ -92,13 +92,16 @@ int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d
                              int64_t* elems);
 /* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
 int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
-/* Stacked weights of the search cell (see senas_unstack_fwd): item i copies rows x row_len floats from the dense
- * src into dst rows that are dst_stride floats apart -- every per-edge weight of the model into its slice of a stacked
- * buffer in ONE launch.  items_dev is a DEVICE array, max_elems = max rows*row_len over the items.                    */
+/* Stacked weights of the search cell (see senas_unstack_fwd): item i copies rows x row_len floats from src rows that
+ * are src_stride floats apart into dst rows that are dst_stride floats apart -- every per-edge weight of the model into
+ * its slice of a stacked buffer in ONE launch, and (the other way round) every slice of the stacked weight gradients
+ * into the per-edge gradients (accumulate != 0: dst += src).  items_dev is a DEVICE array, max_elems = max
+ * rows*row_len over the items.                                                                                       */
 typedef struct senas_copy_item {
     const float* src;
     float* dst;
-    int64_t rows, row_len, dst_stride;
+    int64_t rows, row_len, src_stride, dst_stride;
+    int64_t accumulate;
 } senas_copy_item;
 int senas_copy_rows_batched(const senas_copy_item* items_dev, int n, int64_t max_elems, void* stream);
 /* Workspace of the weight gradient: *bytes to allocate and whether it must be zero-filled on entry
@@ -288,7 +291,9 @@ int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const flo
                    void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
  *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
- *   dmix: float[nterms] or NULL; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
+ *   dmix: float[nterms] or NULL, overwritten -- or, with dmix_accumulate != 0, added to: the cells of one kind share
+ *   their mixing weights (search/senas_search.py:252-259 computes them once per forward), so their nodes sum
+ *   d loss / d mix into ONE buffer in stream order; dse_w1[t] / dse_w2[t]: like se_w1 / se_w2
  *   abk: float[3][nterms][n][c] scratch; dz[t]: gradient of z_t or NULL (skipped); ds_out: gradient of
  *   the residual input or NULL.  With relu, the mask comes from mask8 (as written by senas_node_fwd) if
  *   given, else from y; one of the two must be non-NULL.
@@ -296,9 +301,9 @@ int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const flo
  *   wider NHWC tensor, e.g. the gradient of a torch.cat along channels -- read in place, no copy).             */
 int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
                    const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
-                   double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
-                   float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride, float* ds_out,
-                   void* stream);
+                   double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, int dmix_accumulate,
+                   float* const* dse_w1, float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride,
+                   float* ds_out, void* stream);
 
 /* out = sum of n dense fp32 tensors of numel elements (n <= SENAS_MAX_TERMS, 16-byte aligned): the gradient of a
  * tensor with n consumers (a cell state feeding several edges) in one pass instead of n-1 binary accumulations.  */
@@ -325,15 +330,18 @@ int senas_seg_metric_update(int n, int64_t hw, int c, const float* logits, const
 /* ---- optimizer step -------------------------------------------------------------------------
  * nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.SGD.step() (momentum, dampening,
  * weight decay, nesterov; experiments/train_model.py:284-289, search_arc.py:280-285) over n tensors in two
- * launches.  items_dev: DEVICE array; grad == NULL: the tensor is skipped (like a parameter without .grad);
- * buf: momentum buffer (ignored when momentum == 0).  partial64: double[64] scratch.  max_norm <= 0: no
- * clipping.  first_step != 0: buffers are initialised with the gradient (torch's first step).  Gradients are
- * left scaled by the clip coefficient, as clip_grad_norm_ leaves them.  total_norm_out: float[1] or NULL.   */
+ * launches (three with clipping).  items_dev: DEVICE array; grad == NULL: the tensor is skipped (like a parameter
+ * without .grad); buf: momentum buffer (ignored when momentum == 0); first != 0: this tensor's buffer is initialised
+ * with the gradient (torch's first step for it).  partial64: double[1 + n * ceil(max_numel / 1024)] scratch (one slot
+ * per block, folded in a fixed order: the norm is bit-identical on every rank).  max_norm <= 0: no clipping.
+ * first_step != 0: every tensor is treated as first.  Gradients are left scaled by the clip coefficient, as
+ * clip_grad_norm_ leaves them.  total_norm_out: float[1] or NULL.                                                  */
 typedef struct senas_sgd_item {
     float* param;
     float* grad;
     float* buf;
     int64_t numel;
+    int64_t first;
 } senas_sgd_item;
 int senas_sgd_clip_step(const senas_sgd_item* items_dev, int n, int64_t max_numel, double* partial64,
                         float max_norm, float lr, float momentum, float dampening, float weight_decay,

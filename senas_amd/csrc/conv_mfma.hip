@@ -556,12 +556,13 @@ __global__ void pack_weights_batched_kernel(const PackItem* __restrict__ items) 
     it.dst[i] = v;
 }
 
-// rows x row_len floats from a dense source into rows of a wider destination (the per-edge weights into their slice
-// of a stacked weight buffer): one launch for all items
+// rows x row_len floats between two row-strided buffers (the per-edge weights into their slice of a stacked weight
+// buffer; the slices of a stacked weight gradient back into the per-edge gradients): one launch for all items
 struct CopyItem {
     const float* src;
     float* dst;
-    long rows, row_len, dst_stride;
+    long rows, row_len, src_stride, dst_stride;
+    long accumulate;            // != 0: dst += src
 };
 
 __global__ void copy_rows_batched_kernel(const CopyItem* __restrict__ items) {
@@ -569,7 +570,9 @@ __global__ void copy_rows_batched_kernel(const CopyItem* __restrict__ items) {
     const long total = it.rows * it.row_len;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / it.row_len, c = i - r * it.row_len;
-        it.dst[r * it.dst_stride + c] = it.src[i];
+        const float v = it.src[r * it.src_stride + c];
+        float* out = it.dst + r * it.dst_stride + c;
+        *out = it.accumulate ? *out + v : v;
     }
 }
 

@@ -44,6 +44,7 @@ struct SeGradTable {            // per-term gradient destinations (each its own 
     float* w2[SENAS_MAX_TERMS];
     float* dgamma[SENAS_MAX_TERMS];
     float* dbeta[SENAS_MAX_TERMS];
+    int dmix_accumulate;        // d mix is added to what the buffer holds (shared mixing weights of the cells of one kind)
 };
 
 // ------------------------------------------------------------------------------------------ forward prepare
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_generic_kernel(NodeDesc 
             if (se) da2[i * c + ch] = w * dot * g * (1.0 - g);
         }
     const double dmix_tot = block_sum(dmix_part, red);
-    if (threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)dmix_tot;
+    if (threadIdx.x == 0 && dmix != nullptr) dmix[t] = (seg.dmix_accumulate ? dmix[t] : 0.f) + (float)dmix_tot;
 
     if (se) {
         __syncthreads();
@@ -645,7 +646,8 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
     dmix_part = wave_sum(dmix_part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmix_part;
     __syncthreads();                                             // red[], da2[], SE operands visible
-    if (write_grads && threadIdx.x == 0 && dmix != nullptr) dmix[t] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (write_grads && threadIdx.x == 0 && dmix != nullptr)
+        dmix[t] = (seg.dmix_accumulate ? dmix[t] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
 
     double e[kImgs];
 #pragma unroll
@@ -868,9 +870,9 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
 
 extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
                               const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
-                              double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, float* const* dse_w1,
-                              float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride, float* ds_out,
-                              void* stream) {
+                              double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, int dmix_accumulate,
+                              float* const* dse_w1, float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride,
+                              float* ds_out, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_bwd: bad descriptor");
     SENAS_REQUIRE(z && dy && coefs && gate && p1 && p2 && dgamma && dbeta && abk && dz && (!d.relu || y || mask8), "node_bwd: null pointer");
@@ -883,6 +885,7 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     ZTable zt{};
     DzTable dzt{};
     SeGradTable seg{};
+    seg.dmix_accumulate = dmix_accumulate;
     bool any_se = false, any_dz = false;
     for (int t = 0; t < d.nterms; ++t) {
         zt.p[t] = z[t];

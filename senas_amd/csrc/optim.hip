@@ -1,7 +1,8 @@
 // clip_grad_norm_ + SGD(momentum, weight decay) over ALL parameter tensors in two launches
 // (experiments/train_model.py:284-289, experiments/search_arc.py:280-285 do this with one torch kernel per
 // tensor list chunk: ~110 launches per step on the 807 tensors of the derived network).
-//   pass 1: sum of squares of every gradient   -> 64 fp64 partial sums
+//   pass 1: sum of squares of every gradient   -> one fp64 partial per block (plain stores), folded in a FIXED order by
+//           one block (no atomics: the clip coefficient is bit-identical on every data-parallel rank)
 //   pass 2: coef = min(1, max_norm / (sqrt(total) + 1e-6));  g *= coef (written back, as clip_grad_norm_ does);
 //           d = g + wd * p;  buf = first ? d : momentum * buf + (1 - dampening) * d;
 //           p -= lr * (nesterov ? d + momentum * buf : buf)
@@ -14,15 +15,14 @@ struct SgdItem {                 // == senas_sgd_item
     float* grad;
     float* buf;
     int64_t numel;
+    int64_t first;               // != 0: buf is uninitialised -- this step sets it to the gradient (torch's first step)
 };
-
-constexpr int kNormSlots = 64;
 
 __global__ __launch_bounds__(256) void sgd_sqnorm_kernel(const SgdItem* __restrict__ items, double* __restrict__ partial) {
     __shared__ double red[4];
     const SgdItem it = items[blockIdx.y];
     const int64_t base = (int64_t)blockIdx.x * 1024;
-    if (base >= it.numel) return;                                   // block-uniform
+    if (base >= it.numel) return;                                   // block-uniform (its slot stays zero)
     double s = 0.0;
     if (it.grad != nullptr) {
 #pragma unroll
@@ -34,7 +34,21 @@ __global__ __launch_bounds__(256) void sgd_sqnorm_kernel(const SgdItem* __restri
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&partial[(blockIdx.y + blockIdx.x) % kNormSlots], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[1 + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[0] = sum of partial[1 .. count] in an order that depends on nothing but count
+__global__ __launch_bounds__(256) void sgd_sqnorm_fold_kernel(double* __restrict__ partial, long count) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < count; i += 256) s += partial[1 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[0] = red[0];
 }
 
 __global__ __launch_bounds__(256) void sgd_step_kernel(const SgdItem* __restrict__ items, const double* __restrict__ partial,
@@ -45,9 +59,7 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(const SgdItem* __restrict
     if (base >= it.numel) return;
     float coef = 1.f;
     if (max_norm > 0.f) {
-        double tot = 0.0;
-        for (int k = 0; k < kNormSlots; ++k) tot += partial[k];     // same order in every block: one value for all
-        const float total_norm = (float)sqrt(tot);
+        const float total_norm = (float)sqrt(partial[0]);
         coef = fminf(max_norm / (total_norm + 1e-6f), 1.f);
         if (norm_out != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *norm_out = total_norm;
     }
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(const SgdItem* __restrict
         float p = it.param[i];
         float d = weight_decay != 0.f ? fmaf(weight_decay, p, g) : g;
         if (momentum != 0.f) {
-            const float b = first ? d : fmaf(momentum, it.buf[i], (1.f - dampening) * d);
+            const float b = (first || it.first) ? d : fmaf(momentum, it.buf[i], (1.f - dampening) * d);
             it.buf[i] = b;
             d = nesterov ? fmaf(momentum, b, d) : b;
         }
@@ -82,9 +94,11 @@ extern "C" int senas_sgd_clip_step(const senas_sgd_item* items_dev, int n, int64
     dim3 grid((unsigned)((max_numel + 1023) / 1024), n);
     const senas::SgdItem* items = reinterpret_cast<const senas::SgdItem*>(items_dev);
     if (max_norm > 0.f) {
-        hipError_t e = hipMemsetAsync(partial64, 0, senas::kNormSlots * sizeof(double), st);
+        const long count = (long)grid.x * n;
+        hipError_t e = hipMemsetAsync(partial64, 0, (size_t)(1 + count) * sizeof(double), st);
         if (e != hipSuccess) { senas::set_error("sgd_clip_step: memset", e); return SENAS_ELAUNCH; }
         hipLaunchKernelGGL(senas::sgd_sqnorm_kernel, grid, dim3(256), 0, st, items, partial64);
+        hipLaunchKernelGGL(senas::sgd_sqnorm_fold_kernel, dim3(1), dim3(256), 0, st, partial64, count);
     }
     hipLaunchKernelGGL(senas::sgd_step_kernel, grid, dim3(256), 0, st, items, partial64, max_norm, lr, momentum, dampening,
                        weight_decay, nesterov, first_step, total_norm_out);

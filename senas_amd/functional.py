@@ -114,29 +114,46 @@ MAX_STACK = _lib.MAX_STACK
 MAX_BNRELU = _lib.MAX_BNRELU
 _NOSPAN = _NoSpan()
 
-# (weight data_ptr, direction) -> packed fragment image kept fresh by senas_amd.packing.WeightPacker;
+# (weight data_ptr, direction) -> packed fragment image kept fresh by the INSTALLED senas_amd.packing.WeightPacker;
 # empty: every convolution call repacks its own weights
 PACKED = {}
-# False from the moment an optimizer has moved the weights until the packer refreshes the images again: in between
-# (e.g. a validation forward after a training step) every convolution repacks its own, current, weights
-PACKED_VALID = True
+# Bumped whenever weights change behind torch's version counters (the fused SGD kernel writes them through raw
+# pointers).  A packer's images / stacked buffers only count while the packer was refreshed in the current generation
+# -- each packer carries its own stamp, so refreshing one packer never re-validates another one's stale images.
+WEIGHT_GEN = 0
+
+
+def weights_moved():
+    global WEIGHT_GEN
+    WEIGHT_GEN += 1
 
 
 def _packed(w, direction):
-    """Address of the cached fragment image of ``w``, or None.  An entry only counts while the parameter it was made
-    for is alive and still lives at the address it is filed under: a freed model's addresses get reused by the next
-    model's weights, and its images must not be."""
-    if not PACKED_VALID:
-        return None
+    """Address of the cached fragment image of ``w``, or None.  An entry only counts while its packer is current, the
+    parameter it was made for is alive and still lives at the address it is filed under (a freed model's addresses
+    get reused by the next model's weights, and its images must not be) and torch has not seen it change since."""
     ent = PACKED.get((w.data_ptr(), direction))
-    if ent is None:
+    if ent is None or ent.packer.gen != WEIGHT_GEN:
         return None
     owner = ent.ref()
-    # (torch's in-place updates -- any torch optimizer -- bump the version counter; the fused SGD kernel does not, which
-    # is what PACKED_VALID is for)
     if owner is None or owner.data_ptr() != w.data_ptr() or owner._version != ent.version:
         return None
     return ent.img.data_ptr()
+
+
+# senas_amd.gradsink.GradSink of the running step driver, or None: parameter gradients go through autograd
+SINK = None
+
+
+def wgrad_dest(w):
+    """Where a backward kernel writes d loss / d w, and what autograd is handed for it: the parameter's view in the
+    flat gradient buffer and None (first gradient of the pass under a step driver), or a fresh tensor twice."""
+    if SINK is not None:
+        v = SINK.dest(w)
+        if v is not None:
+            return v, None
+    t = torch.empty_like(w)
+    return t, t
 
 
 def _span(kind, g, x, w, y):
@@ -205,14 +222,14 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
                                                    x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dwt, dw = wgrad_dest(w)
             nbytes, zero = C.c_int64(), C.c_int32()
             _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
             # pre-zeroed arena slice where the path accumulates with atomics (no memset launch per conv); plain
             # scratch where it writes per-block partials
             wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
             with _span('conv_wgrad', g, x, w, dy):
-                _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dw.data_ptr(),
+                _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
                                                      wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
         return dx, dw, None, None, None, None, None, None, None, None
 
@@ -399,6 +416,39 @@ def blend2(x1, x2, g):
     return _Blend2.apply(x1, x2, g)
 
 
+class _EdgeMix(torch.autograd.Function):
+    """M[e][k] = beta[e] * (w_norm[e][k] if edge e is a NORM edge else w_chg[e][k]) for all edges of a cell kind at once
+    (search/cell.py:33-36,100-106: every MixedOp scales its candidates by its alpha row, every node scales the edge by
+    beta).  The cells of one kind share M within a forward pass; their nodes read their rows of it in place and ADD
+    d loss / d M into the zero-filled ``dM`` in stream order (senas_node_bwd, dmix_accumulate), which this backward pass turns into the
+    three gradients -- a handful of tiny launches per pass instead of ~10 per cell."""
+
+    @staticmethod
+    def forward(ctx, w_norm, w_chg, betas, is_norm, dM):
+        W = torch.where(is_norm, w_norm, w_chg)
+        M = (betas.unsqueeze(1) * W).contiguous()
+        ctx.save_for_backward(W, betas, is_norm, dM)
+        ctx.set_materialize_grads(False)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        W, betas, is_norm, dM = ctx.saved_tensors
+        g = dM if gM is None else dM + gM
+        dW = g * betas.unsqueeze(1)
+        zero = torch.zeros((), device=g.device, dtype=g.dtype)
+        return torch.where(is_norm, dW, zero), torch.where(is_norm, zero, dW), (g * W).sum(1), None, None
+
+
+class SharedMix(object):
+    """Rows [off, off + rows) of an _EdgeMix matrix as the mixing weights of one node: ``M`` (for autograd ordering and
+    the kernel's read), the flat offset / length of the node's weights in it, and the accumulation buffer ``dM``."""
+    __slots__ = ('M', 'off', 'count', 'dM')
+
+    def __init__(self, M, off, count, dM):
+        self.M, self.off, self.count, self.dM = M, off, count, dM
+
+
 class _FanOut(torch.autograd.Function):
     """n aliases of x for n consumers; the backward pass adds the incoming gradients in ONE launch (senas_sum_n)
     instead of leaving n-1 binary accumulations to autograd."""
@@ -475,9 +525,9 @@ class _DwMulti(torch.autograd.Function):
             _lib.check(L.senas_dwconv_multi_bwd_data(C.byref(g), k, dyp, wp, dx.data_ptr(), _stream()), 'senas_dwconv_multi_bwd_data')
         dws = [None] * k
         if any(ctx.needs_input_grad[3:]):
-            dws = [torch.empty_like(w) for w in ws]
+            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
             scratch = torch.empty(int(L.senas_dwconv_multi_ws_bytes(C.byref(g), k)), device=x.device, dtype=torch.uint8)
-            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dws])
+            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
             _lib.check(L.senas_dwconv_multi_bwd_weight(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), _stream()),
                        'senas_dwconv_multi_bwd_weight')
         return (dx, None, None) + tuple(dws)
@@ -541,9 +591,9 @@ class _PwMulti(torch.autograd.Function):
             _lib.check(L.senas_pw_multi_bwd_data(k, n, h * w_, cin, cout, arr(dys), arr(ws), arr(dxs), _stream()), 'senas_pw_multi_bwd_data')
         dws = [None] * k
         if any(need[2 + k:]):
-            dws = [torch.empty_like(w) for w in ws]
+            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
             scratch = torch.empty(int(L.senas_pw_multi_ws_bytes(k, n, h * w_, cin, cout)), device=dev, dtype=torch.uint8)
-            _lib.check(L.senas_pw_multi_bwd_weight(k, n, h * w_, cin, cout, arr(xs), arr(dys), arr(dws), scratch.data_ptr(), _stream()),
+            _lib.check(L.senas_pw_multi_bwd_weight(k, n, h * w_, cin, cout, arr(xs), arr(dys), arr(dwt), scratch.data_ptr(), _stream()),
                        'senas_pw_multi_bwd_weight')
         return (None, None) + tuple(dxs) + tuple(dws)
 
@@ -598,7 +648,7 @@ class _BnReluMulti(torch.autograd.Function):
                    'senas_bnrelu_multi_fwd')
         ctx.k, ctx.shape = k, (n, c, h, w)
         ctx.masks = masks
-        ctx.save_for_backward(saved, *zs, *gammas)
+        ctx.save_for_backward(saved, *zs, *gammas, *betas)
         ctx.set_materialize_grads(False)
         return tuple(ys)
 
@@ -607,15 +657,17 @@ class _BnReluMulti(torch.autograd.Function):
         k = ctx.k
         n, c, h, w = ctx.shape
         saved = ctx.saved_tensors[0]
-        zs, gammas = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:1 + 2 * k]
+        zs, gammas, betas = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:1 + 2 * k], ctx.saved_tensors[1 + 2 * k:1 + 3 * k]
         dev = saved.device
         live = [t for t in range(k) if dys[t] is not None]
         if not live:
             return (None,) * (1 + 3 * k)
         need = ctx.needs_input_grad
         dzs = [torch.empty_like(zs[t], memory_format=CL) if need[1 + t] else None for t in range(k)]
-        dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(k)]
-        dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(k)]
+        # (a tensor that receives no gradient in this pass keeps a scratch destination and hands autograd nothing)
+        dgt, dgs = zip(*[wgrad_dest(gammas[t]) if t in live else (None, None) for t in range(k)])
+        dbt, dbs = zip(*[wgrad_dest(betas[t]) if t in live else (None, None) for t in range(k)])
+        dgs, dbs = list(dgs), list(dbs)
         sums = zeros64((k, n, c, 2), dev)
         items = (_lib.BnReluItem * len(live))()
         keep = []
@@ -632,12 +684,12 @@ class _BnReluMulti(torch.autograd.Function):
             it.z, it.mask8, it.gamma = zs[t].data_ptr(), ctx.masks[t].data_ptr(), gammas[t].data_ptr()
             it.mean_invstd = saved[t].data_ptr()
             it.dy, it.dy_pixel_stride = dy.data_ptr(), stride
-            it.dz, it.dgamma, it.dbeta = _p(dzs[t]), dgs[t].data_ptr(), dbs[t].data_ptr()
+            it.dz, it.dgamma, it.dbeta = _p(dzs[t]), dgt[t].data_ptr(), dbt[t].data_ptr()
             it.sums = sums[t].data_ptr()
         _lib.check(_lib.lib().senas_bnrelu_multi_bwd(items, len(live), n, h * w, c, _stream()), 'senas_bnrelu_multi_bwd')
-        dead = [t for t in range(k) if t not in live]
-        for t in dead:
-            dzs[t], dgs[t], dbs[t] = None, None, None
+        for t in range(k):
+            if t not in live:
+                dzs[t] = None
         return (None,) + tuple(dzs) + tuple(dgs) + tuple(dbs)
 
 
@@ -676,10 +728,13 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, buf, dim, *params):
         ctx.dim, ctx.sizes = dim, [p.shape[dim] for p in params]
+        ctx.set_materialize_grads(False)
         return buf.view_as(buf)
 
     @staticmethod
     def backward(ctx, dw):
+        if dw is None:              # written into the stack's gradient buffer of the flat-gradient sink (gradsink.py)
+            return (None,) * (2 + len(ctx.sizes))
         grads, off = [], 0
         for size in ctx.sizes:
             grads.append(dw.narrow(ctx.dim, off, size))
@@ -698,13 +753,20 @@ class StackedWeight(object):
         self.pad_to = pad_to                   # total size along dim (zero-filled beyond the parameters), overrides pad_parts
         self.buf = None
         self.managed = False
+        self.packer = None                     # the WeightPacker that keeps the buffer filled while ``managed``
         self.filled = None                     # the parameters' version counters when a packer last filled the buffer
+
+    def __deepcopy__(self, memo):
+        # a copied model gets an unmanaged stack over ITS parameters, not a copy of the packer / gradient buffers behind this one
+        import copy
+        return StackedWeight([copy.deepcopy(p, memo) for p in self.params], self.dim, self.pad_parts, self.pad_to)
 
     def mark_filled(self):
         self.filled = tuple(p._version for p in self.params)
 
     def current(self):
-        return self.managed and PACKED_VALID and self.filled == tuple(p._version for p in self.params)
+        return (self.managed and self.packer is not None and self.packer.gen == WEIGHT_GEN and
+                self.filled == tuple(p._version for p in self.params))
 
     def buffer(self):
         p0 = self.params[0]

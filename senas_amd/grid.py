@@ -52,3 +52,23 @@ class MacroGrid(nn.Module):
             self.blocks.append(row)
             widths.append(wrow)
         self.head_block = nn.ModuleList([make_head(c, widths[-1][0], nclass)])
+        # step drivers may cut the autograd graph at the outputs of the down path (senas_amd.step: backward is then run
+        # -- and captured -- in two parts, so that the up-path gradients are all-reduced while the rest still runs)
+        self.cut = None
+
+    def down_parameters(self):
+        """Parameters of the down path (stems, down cells): the ones whose gradients backward produces last."""
+        out, seen = [], set()
+        for m in [self.stem0, self.stem1] + list(self.blocks[0]):
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        return out
+
+    def _down_done(self, s0, outs):
+        """Called by the subclasses' forward with the stem output and the down-path outputs."""
+        if self.cut is None:
+            return s0, outs
+        cut = self.cut([s0] + list(outs))
+        return cut[0], list(cut[1:])

@@ -39,11 +39,17 @@ class Evaluator(object):
         self.batches = 0
         self.logits = self.mask = None
         self.graph = None
-        self.packer = WeightPacker(model)          # weights are constant here: one refresh, then every replay reuses it
+        self.packer = WeightPacker(model)          # weights are constant between refresh() calls: every replay reuses the images
         self.packer.install()
         self.packer.refresh()
         if use_graph:
             self._capture(warmup)
+
+    def refresh(self):
+        """Re-derive everything cached from the weights (packed images, stacked buffers).  ``__call__`` does it by itself
+        when an optimizer moved the weights since the last call, so an evaluator can be reused for per-epoch validation
+        as the drivers' ``infer()`` loops are (experiments/train_model.py:306-340)."""
+        self.packer.refresh()
 
     def _forward(self, x):
         return self.model(x)
@@ -84,10 +90,12 @@ class Evaluator(object):
             if y is None:
                 raise ValueError('this evaluator was built with targets')
             self.y.copy_(y, non_blocking=True)
+        if self.packer.stale():                    # the captured launches read the images by address: keep them current
+            self.refresh()
         if self.graph is None:
             self.logits, self.mask = self._eager()
         else:
-            self.graph.replay()                    # (reads its own packed images by address, whatever F.PACKED_VALID says)
+            self.graph.replay()
             if self.y is not None:
                 self.metric._acc_n += 1             # the replay ran the captured update launch
         self.batches += 1

@@ -75,6 +75,8 @@ class _Node(torch.autograd.Function):
                 st = F.chan_stats(z)
             stats[t] = st
         mixc = mix.detach().float().contiguous() if mix is not None else None
+        if mixc is not None and meta.get('mix_off') is not None:        # rows of a shared _EdgeMix matrix, read in place
+            mixc = mixc.view(-1)[meta['mix_off']:meta['mix_off'] + T]
         d = _desc(meta, gammas, betas, w1s, w2s, stats, mixc)
         coefs = torch.empty((T, 4, c), device=dev, dtype=torch.float32)
         gate = torch.empty((T, n, c), device=dev, dtype=torch.float32)
@@ -145,27 +147,35 @@ class _Node(torch.autograd.Function):
                     dzs[t] = torch.empty_like(zs[k], memory_format=CL)
         ds_out = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
-        dgs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # own tensors: autograd adopts them
-        dbs = [torch.empty(c, device=dev, dtype=torch.float32) for _ in range(T)]     # as .grad without cloning a view
-        dmix = torch.empty(T, device=dev, dtype=torch.float32) if ctx.has_mix else None
+        # destinations: the parameter's view in the flat gradient buffer under a step driver (autograd then gets None),
+        # else own tensors that autograd adopts as .grad
+        dgt, dgs = zip(*[F.wgrad_dest(g) for g in gammas])
+        dbt, dbs = zip(*[F.wgrad_dest(b) for b in betas])
+        shared = meta.get('dmix_buf') if ctx.has_mix else None
+        if shared is not None:                               # the cells of a kind add into one buffer (functional._EdgeMix)
+            dmix_dst, dmix, dmix_acc = shared.view(-1)[meta['mix_off']:meta['mix_off'] + T], None, 1
+        else:
+            dmix = torch.empty(T, device=dev, dtype=torch.float32) if ctx.has_mix else None
+            dmix_dst, dmix_acc = dmix, 0
         abk = torch.empty((3, T, n, c), device=dev, dtype=torch.float32)
-        dw1s = [torch.empty_like(wt) for wt in w1s]
-        dw2s = [torch.empty_like(wt) for wt in w2s]
+        dw1t, dw1s = zip(*[F.wgrad_dest(wt) for wt in w1s]) if ns else ((), ())
+        dw2t, dw2s = zip(*[F.wgrad_dest(wt) for wt in w2s]) if ns else ((), ())
         se_pos = {t: k for k, t in enumerate(se_ids)}
-        dw1p = _arr([dw1s[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
-        dw2p = _arr([dw2s[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
+        dw1p = _arr([dw1t[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
+        dw2p = _arr([dw2t[se_pos[t]].data_ptr() if t in se_pos else None for t in range(T)])
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
         se_m, se_a1 = ctx.se_buf
         _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), dy_stride, yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
                                     F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
-                                    _arr([t_.data_ptr() for t_ in dgs]), _arr([t_.data_ptr() for t_ in dbs]),
-                                    F._p(dmix), dw1p, dw2p, abk.data_ptr(), dzp, dz_strides, F._p(ds_out),
+                                    _arr([t_.data_ptr() for t_ in dgt]), _arr([t_.data_ptr() for t_ in dbt]),
+                                    F._p(dmix_dst), dmix_acc, dw1p, dw2p, abk.data_ptr(), dzp, dz_strides, F._p(ds_out),
                                     F._stream()), 'senas_node_bwd')
         grads = [dzs[t] for t in real]
-        grads += dgs + dbs
-        grads += dw1s + dw2s
-        grads += [torch.zeros_like(q) for q in meta['passengers']]
+        grads += list(dgs) + list(dbs)
+        grads += list(dw1s) + list(dw2s)
+        # exactly-zero gradients: the zeroed view of the flat buffer already is one
+        grads += [None if (F.SINK is not None and F.SINK.dest(q) is not None) else torch.zeros_like(q) for q in meta['passengers']]
         assert len(grads) == ctx.nflat
         return (None, dmix, ds_out) + tuple(grads)
 
@@ -185,7 +195,13 @@ def bn_combine(terms, mix=None, residual=None, relu=False):
     if ref.shape[1] > 256:
         raise SenasHipError('bn_combine: more than 256 channels is not on the SENAS path')
     passengers = [p for tm in terms for p in tm.passengers]
+    shared = mix if isinstance(mix, F.SharedMix) else None
+    if shared is not None:
+        if shared.count != T:
+            raise SenasHipError('bn_combine: %d shared mixing weights for %d terms' % (shared.count, T))
+        mix = shared.M
     meta = {
+        'mix_off': shared.off if shared is not None else None, 'dmix_buf': shared.dM if shared is not None else None,
         'T': T, 'real': real, 'se': se_ids, 'shape': tuple(ref.shape), 'training': terms[0].bn.training, 'relu': bool(relu),
         'stats': [tm.stats for tm in terms],
         'buffers': [(tm.bn.running_mean, tm.bn.running_var, tm.bn.num_batches_tracked) for tm in terms],

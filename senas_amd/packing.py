@@ -23,21 +23,29 @@ class _Item(C.Structure):
 
 class _CopyItem(C.Structure):
     """senas_copy_item (include/senas_hip.h)."""
-    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('row_len', C.c_int64), ('dst_stride', C.c_int64)]
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('row_len', C.c_int64), ('src_stride', C.c_int64),
+                ('dst_stride', C.c_int64), ('accumulate', C.c_int64)]
+
+
+def copy_table(items, device):
+    """Device table for senas_copy_rows_batched: (table tensor, item count, largest item in floats)."""
+    raw = bytes((_CopyItem * len(items))(*items))
+    return (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device), len(items), max(it.rows * it.row_len for it in items))
 
 
 class _Image(object):
     """One cached fragment image: weak reference to the tensor it was made from, the image, and that tensor's version
     counter when the image was last refreshed on the host's watch."""
-    __slots__ = ('ref', 'img', 'version')
+    __slots__ = ('ref', 'img', 'version', 'packer')
 
-    def __init__(self, w, img):
-        self.ref, self.img, self.version = weakref.ref(w), img, -1
+    def __init__(self, w, img, packer):
+        self.ref, self.img, self.version, self.packer = weakref.ref(w), img, -1, packer
 
 
 class WeightPacker(object):
     def __init__(self, model):
         L = _lib.lib()
+        self.gen = -1                # functional.WEIGHT_GEN at the last refresh: the images count only in that generation
         self.entries = []            # (weight parameter, direction, image tensor)
         items = []
         seen = set()
@@ -50,9 +58,9 @@ class WeightPacker(object):
                 if not p.is_contiguous():
                     raise _lib.SenasHipError('stacked weights must be contiguous parameters')
                 if sw.dim == 0:                                   # Conv2d [co][ci][kh][kw]: one dense block
-                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), 1, p.numel(), p.numel()))
+                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), 1, p.numel(), p.numel(), p.numel(), 0))
                 else:                                             # ConvTranspose2d [ci][co][kh][kw]: one row per input channel
-                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), p.shape[0], p.numel() // p.shape[0], buf.stride(0)))
+                    copies.append(_CopyItem(p.data_ptr(), dst.data_ptr(), p.shape[0], p.numel() // p.shape[0], p.numel() // p.shape[0], buf.stride(0), 0))
         self.n_copies = len(copies)
         self.max_copy = max((it.rows * it.row_len for it in copies), default=0)
         if copies:
@@ -82,7 +90,7 @@ class WeightPacker(object):
         if self.n:
             raw = bytes((_Item * self.n)(*items))
             self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.entries[0][0].device)
-        self.images = {(w.data_ptr(), d): _Image(w, img) for w, d, img in self.entries}
+        self.images = {(w.data_ptr(), d): _Image(w, img, self) for w, d, img in self.entries}
 
     def refresh(self):
         """Refill the stacked buffers (one launch) and repack every weight (one launch).  Call after the
@@ -93,20 +101,35 @@ class WeightPacker(object):
         if self.n:
             _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
                        'senas_pack_batched')
+        self.mark_refreshed()
+
+    def mark_refreshed(self):
+        """Host-side bookkeeping of a refresh (also called after a graph replay that started with the refresh launches)."""
         for ent in self.images.values():
             w = ent.ref()
             ent.version = w._version if w is not None else -1
         for sw in self.stacks:
             sw.mark_filled()
-        F.PACKED_VALID = True
+        self.gen = F.WEIGHT_GEN
+
+    def stale(self):
+        """Have the weights moved since the last refresh (an optimizer step of either kind)?"""
+        if self.gen != F.WEIGHT_GEN:
+            return True
+        for ent in self.images.values():
+            w = ent.ref()
+            if w is None or w._version != ent.version:
+                return True
+        return any(sw.filled != tuple(p._version for p in sw.params) for sw in self.stacks)
 
     def install(self):
         F.PACKED = self.images
         for sw in self.stacks:
-            sw.managed = True                   # refresh() keeps the buffer current: no cat launch per use
+            sw.managed, sw.packer = True, self  # refresh() keeps the buffer current: no cat launch per use
 
     def uninstall(self):
         if F.PACKED is self.images:
             F.PACKED = {}
         for sw in self.stacks:
-            sw.managed = False
+            if sw.packer is self:
+                sw.managed, sw.packer = False, None

@@ -64,6 +64,9 @@ class GradAllReducer(object):
             self._attach()
 
     # ------------------------------------------------------------------ common
+    def after_backward(self):
+        """Hook of the step drivers, called right after backward (inside the captured graph): nothing to do here."""
+
     def zero_grad(self):
         """Replaces optimizer.zero_grad()."""
         if self.overlap:
@@ -112,7 +115,7 @@ class GradAllReducer(object):
         from .packing import _CopyItem
         key = tuple(g.data_ptr() for _, g in have)
         if getattr(self, '_gather_key', None) != key:
-            items = [_CopyItem(g.data_ptr(), v.data_ptr(), 1, g.numel(), g.numel()) for v, g in have]
+            items = [_CopyItem(g.data_ptr(), v.data_ptr(), 1, g.numel(), g.numel(), g.numel(), 0) for v, g in have]
             raw = bytes((_CopyItem * len(items))(*items))
             self._gather_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(have[0][0].device)
             self._gather_key, self._gather_n = key, len(items)
@@ -158,6 +161,36 @@ class GradAllReducer(object):
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
         self.flat.mul_(1.0 / self.world)
+
+
+class SinkReducer(object):
+    """The same contract over segments first..last of a ``gradsink.GradSink``: ``p.grad`` are persistent views of the
+    flat buffer the backward kernels write into, so there is nothing to gather -- ``finish()`` is one all-reduce of
+    the span and one scale launch, and on one GPU nothing at all."""
+
+    overlap = False
+
+    def __init__(self, sink, first=0, last=None, world_size=None, process_group=None):
+        self.sink, self.first = sink, first
+        self.last = len(sink.segments) - 1 if last is None else last
+        self.group = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.params = [p for i in range(self.first, self.last + 1) for p in sink.segments[i]]
+
+    def zero_grad(self):
+        self.sink.begin(self.first, self.last)
+
+    def after_backward(self):
+        self.sink.finish()
+
+    def finish(self):
+        if self.world == 1:
+            return
+        span = self.sink.span(self.first, self.last)
+        dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group)
+        span.mul_(1.0 / self.world)
+
+    reduce_all = finish
 
 
 def broadcast_parameters(module, src=0, process_group=None):

@@ -93,6 +93,7 @@ class SenasModel(MacroGrid):
         outs = [self.stem1(s0)]
         for j in range(1, self._depth):
             outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1]))
+        s0, outs = self._down_done(s0, outs)
         for j in reversed(range(self._depth - 1)):
             for i in range(1, self._depth - j):
                 cell = self.blocks[i][j]

@@ -3,35 +3,69 @@ experiments/train_model.py:264-305 and experiments/search_arc.py:252-299, withou
 syncs), with the launch-bound part -- forward, loss, backward: ~10^3 short kernels -- captured once in
 a HIP graph and replayed.
 
-What is inside the graph: forward, criterion, backward (gradients are written to tensors owned by the
-graph's memory pool).  What stays eager: the gradient all-reduce (RCCL is never called inside a
-capture), clip_grad_norm_ and the optimizer step -- a dozen launches.
+What is inside the graph: forward, criterion, backward.  Parameter gradients do not travel through autograd:
+the backward kernels write them into one flat buffer (``gradsink.GradSink``; ``p.grad`` are persistent views
+of it), which is also the all-reduce buffer and the fused optimizer's gradient table.  What stays eager: the
+gradient all-reduce (RCCL is never called inside a capture), clip_grad_norm_ and the optimizer step -- a few launches.
+
+With more than one rank the backward pass is captured as TWO graphs cut at the outputs of the down path
+(``grid.MacroGrid.cut``): the up-path / head gradients -- the first ~70 % of the flat buffer, complete once the first
+graph has run -- are all-reduced while the second graph (down cells, stems) still runs; only the second, smaller
+all-reduce is exposed.
 """
 import torch
+import torch.distributed as dist
 
 from . import functional as F
 from . import optim
 from .arena import reset_arena
+from .gradsink import GradSink
+from .grid import MacroGrid
 from .packing import WeightPacker
-from .parallel import GradAllReducer
+from .parallel import SinkReducer
+
+
+def _macro_grid(model):
+    for m in model.modules():
+        if isinstance(m, MacroGrid):
+            return m
+    return None
+
+
+def _segments(model, exclude=()):
+    """[later-in-backward weights (up cells, head), earlier-in-backward weights (stems, down cells)] of a model built
+    on the macro grid, else [all parameters]."""
+    skip = set(id(p) for p in exclude)
+    grid = _macro_grid(model)
+    if grid is None:
+        return [[p for p in model.parameters() if id(p) not in skip]]
+    down = [p for p in grid.down_parameters() if id(p) not in skip]
+    down_ids = set(id(p) for p in down)
+    up = [p for p in model.parameters() if id(p) not in skip and id(p) not in down_ids]
+    return [up, down]
 
 
 class GraphedForwardBackward(object):
     """Captures ``loss = criterion(model(x), y); loss.backward()`` on static input buffers.
 
+    ``reducer``: the ``SinkReducer`` of the segments this pass produces gradients for (it zeroes them first).
     ``frozen``: parameters whose gradients this pass does not need (``requires_grad`` is off while the pass is built
-    or run eagerly, so their weight-gradient kernels are never launched).  ``repoint``: parameters whose ``.grad``
-    must be re-pointed at this graph's gradient tensors after a replay (needed when another graph writes gradients
-    of the same parameters elsewhere)."""
+    or run eagerly, so their weight-gradient kernels are never launched).
+    ``early``: a ``SinkReducer`` over the leading segments whose gradients are complete once the part of backward above
+    the macro grid's cut has run; given (and more than one rank), backward is split there and that all-reduce overlaps
+    the rest of backward."""
 
-    def __init__(self, model, criterion, x, y, reducer, warmup=2, use_graph=True, packer=None, frozen=(), repoint=()):
+    def __init__(self, model, criterion, x, y, reducer, warmup=2, use_graph=True, packer=None, frozen=(), early=None,
+                 count_nodes=False):
         self.model, self.criterion, self.reducer = model, criterion, reducer
+        self.count_nodes, self.nodes = count_nodes, None
         self.x, self.y = x, y                      # static buffers; refill with .copy_() between steps
         self.loss = None
-        self.graph = None
-        self.graph_grads = None
+        self.graph = self.graph_tail = None
         self.frozen = [p for p in frozen if p.requires_grad]
-        self.repoint_ids = set(id(p) for p in repoint)
+        self.grid = _macro_grid(model)
+        self.early = early if (early is not None and early.world > 1 and self.grid is not None) else None
+        self._work = None
         if packer is None:
             packer = WeightPacker(model)           # one launch per step refreshes every conv's weight image
             packer.install()
@@ -39,22 +73,65 @@ class GraphedForwardBackward(object):
         if use_graph:
             self._capture(warmup)
 
-    def _eager(self):
+    # ------------------------------------------------------------------ the pass, whole or in two parts
+    def _head(self):
+        """zero_grad, forward, loss and -- without a cut -- all of backward; with a cut, backward down to the cut."""
         self.reducer.zero_grad()
         self.packer.refresh()
         for p in self.frozen:
             p.requires_grad_(False)
+        cut = self.early is not None
+        if cut:
+            self._cut_src = self._cut_leaf = None
+            self.grid.cut = self._cut
         try:
             loss = self.criterion(self.model(self.x), self.y)
             loss.backward()
         finally:
-            for p in self.frozen:
-                p.requires_grad_(True)
+            if cut:
+                self.grid.cut = None
+            if not cut:
+                for p in self.frozen:
+                    p.requires_grad_(True)
+        self.reducer.after_backward()
         return loss.detach()
 
+    def _cut(self, tensors):
+        self._cut_src = [t for t in tensors if t.requires_grad]
+        self._cut_leaf = [t.detach().requires_grad_(t.requires_grad) for t in tensors]
+        return self._cut_leaf
+
+    def _tail(self):
+        """The rest of backward below the cut."""
+        try:
+            leaves = [l for l in self._cut_leaf if l.requires_grad]
+            pairs = [(s, l.grad) for s, l in zip(self._cut_src, leaves) if l.grad is not None]
+            if pairs:
+                torch.autograd.backward([s for s, _ in pairs], [g for _, g in pairs])
+        finally:
+            self._cut_src = self._cut_leaf = None
+            for p in self.frozen:
+                p.requires_grad_(True)
+        self.reducer.after_backward()
+
+    def _eager(self):
+        loss = self._head()
+        if self.early is not None:
+            self._launch_early()
+            self._tail()
+        return loss
+
+    def _launch_early(self):
+        e = self.early
+        self._work = dist.all_reduce(e.sink.span(e.first, e.last), op=dist.ReduceOp.SUM, group=e.group, async_op=True)
+
+    # ------------------------------------------------------------------ capture / replay
     def _capture(self, warmup):
-        if self.reducer.overlap:
-            raise ValueError('a graph-replayed backward cannot drive gradient hooks; use overlap=False')
+        # the eager warm-up passes run the model in training mode: batch-norm running statistics (and their step
+        # counters) would advance on whatever the static buffers hold -- put them back afterwards
+        buffers = [b for b in self.model.buffers()]
+        kept = [b.detach().clone() for b in buffers]
+        early, self.early = self.early, None       # no collectives while warming up
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -62,28 +139,67 @@ class GraphedForwardBackward(object):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.early = early
         reset_arena()
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if self.count_nodes else torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
-            self.loss = self._eager()
+            self.loss = self._head()
+        if self.count_nodes:
+            self.nodes = _graph_nodes(graph)
+            graph.instantiate()
+        if self.early is not None:
+            tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tail, pool=graph.pool(), capture_error_mode='thread_local'):
+                self._tail()
+            self.graph_tail = tail
         reset_arena()
         self.graph = graph
-        self.graph_grads = [p.grad for p in self.reducer.params]     # written in place by every replay
-        self.repoint = [(p, g) for p, g in zip(self.reducer.params, self.graph_grads) if id(p) in self.repoint_ids]
+        with torch.no_grad():
+            for b, k in zip(buffers, kept):
+                b.copy_(k)
 
     def __call__(self):
         if self.graph is None:
             self.loss = self._eager()
         else:
             self.graph.replay()
-            F.PACKED_VALID = True                  # the replay starts with the packer's refresh launches
-            if self.reducer.world > 1:             # reduce_all() re-points p.grad at the flat buffer
-                for p, g in zip(self.reducer.params, self.graph_grads):
-                    p.grad = g
-            else:
-                for p, g in self.repoint:
-                    p.grad = g
+            self.packer.mark_refreshed()           # the replay starts with the packer's refresh launches
+            if self.graph_tail is not None:
+                self._launch_early()
+                self.graph_tail.replay()
         return self.loss
+
+    def finish(self):
+        """After the pass: the (remaining) all-reduce; gradients are averaged over the ranks when this returns
+        (stream-ordered)."""
+        r, e = self.reducer, self.early
+        if r.world == 1:
+            return
+        if e is None:
+            r.finish()
+            return
+        rest = r.sink.span(e.last + 1, r.last)
+        dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=r.group)
+        self._work.wait()
+        self._work = None
+        r.sink.span(r.first, r.last).mul_(1.0 / r.world)
+
+
+def _graph_nodes(graph):
+    """Number of nodes (kernel launches, memsets, copies) of a captured graph that was kept (``keep_graph=True``), or
+    None when the runtime does not say."""
+    try:
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+        n = C.c_size_t(0)
+        err = hip.hipGraphGetNodes(C.c_void_p(graph.raw_cuda_graph()), None, C.byref(n))
+        return int(n.value) if err == 0 else None
+    except (OSError, AttributeError, RuntimeError):
+        return None
+
+
+def _model_stacks(model):
+    return [sw for m in model.modules() if hasattr(m, 'stacked_weights') for sw in m.stacked_weights()]
 
 
 class SearchStep(object):
@@ -98,21 +214,37 @@ class SearchStep(object):
     all-reduce carries 246 floats instead of 7.9 MB.  The results are identical to the reference's order of operations."""
 
     def __init__(self, model, criterion, weight_optimizer, arch_optimizer, x, y, world_size=1, grad_clip=5.0,
-                 use_graph=True):
+                 use_graph=True, process_group=None, count_nodes=False):
         self.params = [p for p in model.parameters()]
         arch = [p for g in arch_optimizer.param_groups for p in g['params']]
         arch_ids = set(id(p) for p in arch)
         weights = [p for p in self.params if id(p) not in arch_ids]
-        self.reducer = GradAllReducer(self.params, world_size=world_size)
-        self.arch_reducer = GradAllReducer(arch, world_size=world_size)
         self.opt_w, self.opt_a, self.grad_clip = weight_optimizer, arch_optimizer, grad_clip
-        self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, frozen=weights,
-                                              repoint=arch)
-        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph, packer=self.fb_arch.packer,
-                                         repoint=arch)
+        packer = WeightPacker(model)
+        packer.install()
+        # flat gradient buffer: [up-path weights | down-path weights | architecture]
+        segs = _segments(model, exclude=arch) + [arch]
+        self.sink = GradSink(segs, _model_stacks(model)).install()
+        last = len(segs) - 1
+        self.reducer = SinkReducer(self.sink, 0, last, world_size, process_group)
+        self.arch_reducer = SinkReducer(self.sink, last, last, world_size, process_group)
+        early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and last >= 2) else None
+        self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, packer=packer,
+                                              frozen=weights, count_nodes=count_nodes)
+        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph, packer=packer, early=early,
+                                         count_nodes=count_nodes and early is None)
         self.graphed = self.fb.graph is not None
-        # static gradient addresses (graph replays) -> clip + SGD in two launches instead of ~110
-        self.fused = optim.FusedClipSGD(weight_optimizer, grad_clip) if (self.graphed and optim.supported(weight_optimizer)) else None
+        # static gradient addresses -> clip + SGD in two launches instead of ~110
+        self.fused = optim.FusedClipSGD(weight_optimizer, grad_clip) if optim.supported(weight_optimizer) else None
+
+    def close(self):
+        """Uninstall the packed-weight cache and the gradient sink (``p.grad`` stay views of the flat buffer)."""
+        _close(self)
+
+    def graph_nodes(self):
+        """Launches per step inside the two captured graphs (needs ``count_nodes=True``), or None."""
+        a, b = self.fb_arch.nodes, self.fb.nodes
+        return a + b if (a is not None and b is not None) else None
 
     def __call__(self, x_train, y_train, x_valid=None, y_valid=None):
         fb = self.fb
@@ -120,41 +252,54 @@ class SearchStep(object):
             fb.x.copy_(x_valid, non_blocking=True)
             fb.y.copy_(y_valid, non_blocking=True)
             self.fb_arch()
-            self.arch_reducer.finish()
+            self.fb_arch.finish()
             self.opt_a.step()
         fb.x.copy_(x_train, non_blocking=True)
         fb.y.copy_(y_train, non_blocking=True)
         loss = fb()
-        self.reducer.finish()
+        fb.finish()
         if self.fused is not None:
             self.fused.step()
         else:
             if self.grad_clip:
                 torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
             self.opt_w.step()
-        F.PACKED_VALID = False                     # the weights moved: the packed / stacked images are stale until the next pass
+        F.weights_moved()                          # the packed / stacked images are stale until the next pass refreshes them
         return loss
+
+
+def _close(step):
+    step.sink.uninstall()
+    step.fb.packer.uninstall()
 
 
 class TrainStep(object):
     """One optimisation step of the derived network: graph(fwd+loss+bwd) -> all-reduce -> clip -> SGD."""
 
-    def __init__(self, model, criterion, optimizer, x, y, world_size=1, grad_clip=5.0, use_graph=True, overlap=False):
+    def __init__(self, model, criterion, optimizer, x, y, world_size=1, grad_clip=5.0, use_graph=True, process_group=None):
         self.params = [p for p in model.parameters()]
-        self.reducer = GradAllReducer(self.params, world_size=world_size, overlap=overlap and not use_graph)
         self.optimizer, self.grad_clip, self.world = optimizer, grad_clip, world_size
-        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph)
+        packer = WeightPacker(model)
+        packer.install()
+        segs = _segments(model)
+        self.sink = GradSink(segs, _model_stacks(model)).install()
+        self.reducer = SinkReducer(self.sink, 0, len(segs) - 1, world_size, process_group)
+        early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and len(segs) > 1) else None
+        self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph, packer=packer, early=early)
         self.graphed = self.fb.graph is not None
-        self.fused = optim.FusedClipSGD(optimizer, grad_clip) if (self.graphed and optim.supported(optimizer)) else None
+        self.fused = optim.FusedClipSGD(optimizer, grad_clip) if optim.supported(optimizer) else None
+
+    def close(self):
+        _close(self)
 
     def __call__(self):
         loss = self.fb()
-        self.reducer.finish()
+        self.fb.finish()
         if self.fused is not None:
             self.fused.step()
         else:
             if self.grad_clip:
                 torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
             self.optimizer.step()
-        F.PACKED_VALID = False                     # the weights moved: the packed images are stale until the next pass
+        F.weights_moved()                          # the packed images are stale until the next pass refreshes them
         return loss

@@ -375,6 +375,131 @@ def gen_nets(S, M, GS, Loss):
     print('nets: %d cases' % len(index))
 
 
+def _kaiming_init(net, gen):
+    """The reference's own initialisation scale (utils/utils.py:240-250 ``weights_init``: kaiming-normal fan_out for
+    convolutions, xavier-normal for the SE linears, BN weight 1 / bias 0) drawn from ``gen``, with a mild spread on the
+    BN affines so that they are exercised; architecture tensors at the reference's 1e-3 * randn."""
+    import math
+    import torch.nn as nn
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                fan_out = m.weight.shape[0] * m.weight[0][0].numel()       # torch's _calculate_fan_in_and_fan_out
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * math.sqrt(2.0 / fan_out))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.05 * torch.randn(m.bias.shape, generator=gen))
+            elif isinstance(m, nn.Linear):
+                fi, fo = m.weight.shape[1], m.weight.shape[0]
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * math.sqrt(2.0 / (fi + fo)))
+        for k, p in net.named_parameters():
+            if 'alphas' in k or 'betas' in k or k == 'gamma':
+                p.copy_(1e-3 * torch.randn(p.shape, generator=gen))
+
+
+def _full_case(net, x, tgt, crit, tag, out):
+    """Whole-net case with EVERY parameter gradient stored: the reference's fp64 run (rounded to fp32 for storage) is
+    the expected value, its fp32 run is kept beside it (logits, loss) and the largest fp32-vs-fp64 gradient deviation
+    over all tensors is recorded, so a test can hold every tensor to north_star's 1e-3 without an escape clause."""
+    import copy
+    net64 = copy.deepcopy(net).double()
+    out.update(_pack(net.state_dict().items(), tag + '/sd0/'))
+    logits = net(x)
+    loss = crit(logits, tgt)
+    loss.backward()
+    out[tag + '/x'], out[tag + '/target'] = _np(x), _np(tgt)
+    out[tag + '/logits'] = _np(logits[-1])
+    out[tag + '/loss'] = _np(loss)
+    logits64 = net64(x.double())
+    loss64 = crit(logits64, tgt)
+    loss64.backward()
+    out[tag + '/loss64'] = _np(loss64)
+    g32 = dict((k, p.grad) for k, p in net.named_parameters() if p.grad is not None)
+    g64 = dict((k, p.grad) for k, p in net64.named_parameters() if p.grad is not None)
+    out.update(_pack([(k, g.float()) for k, g in g64.items()], tag + '/grad64/'))
+    # per tensor, on the scale of the tensor -- but never below 1e-3 of the largest gradient of the net: a gradient that
+    # is analytically zero (a BN bias in front of another BN) is noise in both precisions
+    top = max(float(g.abs().max()) for g in g64.values())
+    worst = max(float((g32[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-3 * top)) for k in g64)
+    out[tag + '/ref32_vs_ref64'] = np.array(worst)
+    out[tag + '/grad_top'] = np.array(top)
+    print('%s: %d tensors, worst fp32-vs-fp64 gradient deviation of the reference itself %.2e' % (tag, len(g64), worst))
+
+
+def gen_nets2(S, M, GS, Loss):
+    """Round-2 additions (kept in their own file so that the round-1 fixtures stay byte-identical):
+    the reference's DEFAULT flags ``use_sharing=True`` / ``double_down_channel=True`` (search/senas_search.py:118,148,
+    26,45; models/senas_model.py:80), and full-width (c=32) nets at the reference's initialisation scale with fp64
+    gradients of every parameter."""
+    gen = torch.Generator().manual_seed(25)
+    out, index = {}, []
+    crit = Loss('dice_ce')
+    for tag, kw, shape, ncls in (
+            ('nas.c8.d4.share_dd', dict(input_c=1, c=8, num_classes=2, depth=4, meta_node_num=3, use_sharing=True,
+                                        double_down_channel=True), (2, 1, 64, 64), 2),
+            ('nas.c8.d4.share', dict(input_c=1, c=8, num_classes=2, depth=4, meta_node_num=3, use_sharing=True,
+                                     double_down_channel=False), (2, 1, 64, 64), 2)):
+        torch.manual_seed(7)
+        net = S.NAS(multi_gpus=False, device=torch.device('cpu'), **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+        out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        _net_case(net, x, tgt, crit, tag, out, arch_full=True)
+        index.append(tag)
+    for tag, geno, kw, shape in (
+            ('derived.node4.c8.dd', GS.senas_node_4, dict(nclass=2, in_channels=1, c=8, depth=4, double_down_channel=True),
+             (2, 1, 64, 64)),
+            ('derived.node3.c8.dd', GS.senas_node_3, dict(nclass=3, in_channels=3, c=8, depth=4, double_down_channel=True),
+             (2, 3, 64, 64))):
+        net = M.SenasModel(genotype=geno, **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, kw['nclass'], (shape[0],) + shape[2:], generator=gen)
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        out[tag + '/genotype'] = np.array(_geno_json(geno))
+        _net_case(net, x, tgt, crit, tag, out, arch_full=False)
+        net.eval()
+        with torch.no_grad():
+            out[tag + '/logits_eval'] = _np(net(x)[-1])
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'nets2.npz'), **out)
+    print('nets2: %d cases' % len(index))
+
+    # full-width nets, reference initialisation scale, every gradient in fp64
+    out, index = {}, []
+    gen = torch.Generator().manual_seed(26)
+    tag, kw = 'full.derived.node4.c32.d2', dict(nclass=2, in_channels=1, c=32, depth=2)
+    net = M.SenasModel(genotype=GS.senas_node_4, **kw)
+    _kaiming_init(net, gen)
+    net.train()
+    x = torch.randn(2, 1, 64, 64, generator=gen)
+    tgt = torch.randint(0, 2, (2, 64, 64), generator=gen)
+    out[tag + '/kw'] = np.array(json.dumps(kw))
+    out[tag + '/genotype'] = np.array(_geno_json(GS.senas_node_4))
+    _full_case(net, x, tgt, crit, tag, out)
+    index.append(tag)
+    tag, kw = 'full.nas.c32.d2', dict(input_c=1, c=32, num_classes=2, depth=2, meta_node_num=3, use_sharing=False,
+                                      double_down_channel=False)
+    torch.manual_seed(8)
+    net = S.NAS(multi_gpus=False, device=torch.device('cpu'), **kw)
+    _kaiming_init(net, gen)
+    net.train()
+    x = torch.randn(2, 1, 64, 64, generator=gen)
+    tgt = torch.randint(0, 2, (2, 64, 64), generator=gen)
+    out[tag + '/kw'] = np.array(json.dumps(kw))
+    out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+    _full_case(net, x, tgt, crit, tag, out)
+    index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'nets_full.npz'), **out)
+    print('nets_full: %d cases' % len(index))
+
+
 def gen_search_step(S, Loss):
     """One full search step as experiments/search_arc.py:252-299 runs it after alpha_begin:
     Architecture.step on a validation batch (Adam on arch params), then the weight step
@@ -477,11 +602,15 @@ def gen_loss_metric(Loss, Metric):
 def main():
     torch.set_num_threads(4)
     S, C, O, G, M, GS, Loss, Metric = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'round2':          # only the round-2 files (the others stay byte-identical)
+        gen_nets2(S, M, GS, Loss)
+        return
     gen_prims(O)
     gen_blocks(O)
     gen_mixed(C, O)
     gen_cells(C, M, GS)
     gen_nets(S, M, GS, Loss)
+    gen_nets2(S, M, GS, Loss)
     gen_search_step(S, Loss)
     gen_genoparse(S, G)
     gen_loss_metric(Loss, Metric)

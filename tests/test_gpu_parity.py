@@ -170,18 +170,25 @@ def _build_net(z, tag):
     from senas_amd.senas_model import SenasModel
     from senas_amd.senas_search import NAS
     kw = json.loads(str(z[tag + '/kw']))
-    if tag.startswith('nas'):
-        net = NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=dev(), **kw)
+    if 'nas' in tag.split('.'):
+        kw.setdefault('use_sharing', False)
+        kw.setdefault('double_down_channel', False)
+        net = NAS(multi_gpus=False, device=dev(), **kw)
     else:
         net = SenasModel(genotype=gio.geno_from_json(z[tag + '/genotype'], Genotype), **kw)
     return load_into(net, gio.unpack(z, tag + '/sd0/')).train(), kw
 
 
-@pytest.mark.parametrize('tag', gio.index('nets'))
-def test_whole_net(tag):
+NET_CASES = [(f, t) for f in ('nets', 'nets2') for t in gio.index(f)]
+
+
+@pytest.mark.parametrize('fixture,tag', NET_CASES)
+def test_whole_net(fixture, tag):
+    """nets: round-1 cases; nets2: the reference's default flags -- NAS(use_sharing=True, double_down_channel=True)
+    (search/senas_search.py:118,148,26,45) and SenasModel(double_down_channel=True) (models/senas_model.py:80)."""
     from senas_amd.genotype import Genotype
     from senas_amd.loss import SegmentationLosses
-    z = gio.load('nets')
+    z = gio.load(fixture)
     net, kw = _build_net(z, tag)
     if tag.startswith('nas'):
         assert net.genotype() == gio.geno_from_json(z[tag + '/genotype'], Genotype)       # bit-exact
@@ -199,11 +206,18 @@ def test_whole_net(tag):
     # reference and must be within 2e-4 of the tensor scale, or 10x the reference's own fp32 error.
     full32, full64 = gio.sub(z, tag + '/gradfull/'), gio.sub(z, tag + '/gradfull64/')
     top = max(float(np.abs(e).max()) for e in full64.values())
+    escaped = []
     for k, e64 in full64.items():
         scale = max(float(np.abs(e64).max()), 1e-3 * top)
         ref_err = float(np.abs(full32[k] - e64).max()) / scale
         gpu_err = float(np.abs(got[k] - e64).max()) / scale
         assert gpu_err <= max(2e-4, 10 * ref_err), '%s grad %s: gpu %.2e vs fp64, reference fp32 %.2e' % (tag, k, gpu_err, ref_err)
+        if gpu_err > 1e-3:
+            escaped.append((k, gpu_err, ref_err))
+    # tensors past north_star's 1e-3 only pass on the strength of the reference's own fp32-vs-fp64 spread: bounded in
+    # number (the c = 32 fixtures of test_full_width_net_every_gradient have no such escape at all)
+    print('%s: %d of %d full gradients beyond 1e-3 (conditioning escape): %s' % (tag, len(escaped), len(full64), escaped[:4]))
+    assert len(escaped) <= max(2, len(full64) // 4), escaped
     d32, d64 = gio.digest(z, tag + '/grad/'), gio.digest(z, tag + '/grad64/')
     assert set(d32) == set(got)
     top = max(v[1] for v in d64.values())
@@ -229,6 +243,32 @@ def test_whole_net(tag):
         net.eval()
         with torch.no_grad():
             close(net(x)[-1], z[tag + '/logits_eval'], tag + ' eval', rel=1e-3)
+
+
+@pytest.mark.parametrize('tag', gio.index('nets_full'))
+def test_full_width_net_every_gradient(tag):
+    """c = 32 nets at the reference's initialisation scale (weights_init), 2x1x64x64: EVERY parameter gradient against
+    the reference's fp64 gradients at north_star's 1e-3 -- no conditioning escape (the fixture records that the
+    reference's own fp32 run is within 2e-5 of fp64 on every tensor)."""
+    from senas_amd.loss import SegmentationLosses
+    z = gio.load('nets_full')
+    assert float(z[tag + '/ref32_vs_ref64']) < 1e-4
+    net, kw = _build_net(z, tag)
+    x = torch.from_numpy(z[tag + '/x']).to(dev())
+    tgt = torch.from_numpy(z[tag + '/target']).to(dev())
+    outs = net(x)
+    close(outs[-1], z[tag + '/logits'], tag + ' logits', rel=2e-4)
+    loss = SegmentationLosses('dice_ce')(outs, tgt)
+    assert abs(float(loss) - float(z[tag + '/loss64'])) <= 1e-5 * abs(float(z[tag + '/loss64']))
+    loss.backward()
+    got = grads_of(net)
+    exp = gio.unpack(z, tag + '/grad64/')
+    top = float(z[tag + '/grad_top'])
+    assert set(exp) == set(got), set(exp) ^ set(got)
+    errs = {k: float(np.abs(got[k] - e).max()) / max(float(np.abs(e).max()), 1e-3 * top) for k, e in exp.items()}
+    worst = max(errs, key=errs.get)
+    print('%s: %d gradients, worst %s %.2e' % (tag, len(errs), worst, errs[worst]))
+    assert errs[worst] <= 1e-3, (worst, errs[worst])
 
 
 def test_search_step_trajectory():
@@ -286,13 +326,11 @@ def test_search_step_driver_trajectory(graphed):
             # the architecture pass left no weight gradient behind: every weight gradient present now is the weight pass's
             assert all(p.grad is not None for p in net.arch_parameters())
     got = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
-    # the capture warm-up passes moved the batch-norm running statistics (never the weights): compare parameters only
-    skip = ('running_mean', 'running_var', 'num_batches_tracked') if graphed else ()
+    # (the capture warm-up passes leave the batch-norm running statistics where they were: buffers are compared too)
     for k, e in gio.sub(z, 'sd2full/').items():
-        if not k.endswith(skip) or not skip:
-            close(got[k], e, 'after-step ' + k, rel=1e-3)
+        close(got[k], e, 'after-step ' + k, rel=1e-3)
     assert net.genotype() == gio.geno_from_json(z['genotype'], Genotype)
-    step.fb.packer.uninstall()
+    step.close()
 
 
 
@@ -534,11 +572,11 @@ def test_weight_packer_and_graph_step_match_eager():
         else:
             step = TrainStep(net, crit, opt, x, y, use_graph=True)
             assert step.graphed and F.PACKED
-            # the capture warm-up ran forward/backward (BN running stats moved) but never stepped the optimizer
             for _ in range(3):
                 losses.append(float(step()))
-            step.fb.packer.uninstall()
-        results.append((losses, {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if 'running' not in k and 'num_batches' not in k}))
+            step.close()
+        # (buffers included: the capture warm-up passes must leave the running statistics where they were)
+        results.append((losses, {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}))
     (l0, w0), (l1, w1) = results
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
@@ -1180,7 +1218,7 @@ def test_eager_forward_after_a_graphed_step_sees_the_new_weights(kind):
         want = twin(x)[-1]
     close(got, want.cpu().numpy(), 'eager forward after a graphed %s step' % kind, rel=1e-5)
     run()                                          # and the driver keeps working after the interleaved eager pass
-    step.fb.packer.uninstall()
+    step.close()
 
 
 @pytest.mark.parametrize('case', [(3, 2, 32, 12, 20, True, False), (6, 4, 32, 16, 16, True, True), (2, 2, 8, 9, 7, True, False),

@@ -123,13 +123,18 @@ def test_cell(tag):
 
 
 # ------------------------------------------------------------------ whole nets
+NET_CASES = [(f, t) for f in ('nets', 'nets2') for t in gio.index(f)]
+
+
 def _run_net(z, tag):
     kw = json.loads(str(z[tag + '/kw']))
     sd = gio.add_missing_counters(gio.torch_sd(gio.unpack(z, tag + '/sd0/')))
-    gio.share_stem(sd, 'net.' if tag.startswith('nas') else '')
+    gio.share_stem(sd, 'net.' if 'nas' in tag.split('.') else '')
+    if kw.get('use_sharing'):              # one Parameter under two names (search/senas_search.py:148-150)
+        sd['alphas_up_nm'] = sd['alphas_dn_nm']
     x = torch.from_numpy(z[tag + '/x'])
     tgt = torch.from_numpy(z[tag + '/target'])
-    if tag.startswith('nas'):
+    if 'nas' in tag.split('.'):
         outs = R.nas_forward(sd, x, depth=kw['depth'], nodes=kw['meta_node_num'],
                              supervision=kw.get('supervision', False))
     else:
@@ -138,9 +143,10 @@ def _run_net(z, tag):
     return sd, x, tgt, outs, kw
 
 
-@pytest.mark.parametrize('tag', gio.index('nets'))
-def test_whole_net(tag):
-    z = gio.load('nets')
+@pytest.mark.parametrize('fixture,tag', NET_CASES)
+def test_whole_net(fixture, tag):
+    """nets: round-1 cases; nets2: the reference's default flags (use_sharing / double_down_channel)."""
+    z = gio.load(fixture)
     sd, x, tgt, outs, kw = _run_net(z, tag)
     for i, o in enumerate(outs):
         _close(o.detach(), z[tag + '/logits%d' % i], '%s logits%d' % (tag, i), rtol=2e-4, atol=2e-5)
@@ -155,7 +161,7 @@ def test_whole_net(tag):
     gio.check_digest(exp, got, rtol=1e-4, what=tag)      # same thread count as the generator: bit-for-bit
     gio.check_digest(gio.digest(z, tag + '/bn1/'), {k: v.detach().numpy() for k, v in sd.items()}, rtol=1e-4, what=tag + ' bn')
     if tag.startswith('nas'):
-        g = R.derive_genotype({k: v.detach() for k, v in gio.torch_sd(gio.unpack(z, tag + '/sd0/')).items()},
+        g = R.derive_genotype({k: v.detach() for k, v in sd.items()},
                               depth=kw['depth'], nodes=kw['meta_node_num'])
         assert g == gio.geno_from_json(z[tag + '/genotype'], R.Genotype)
     if tag + '/logits_eval' in z.files:
@@ -164,6 +170,26 @@ def test_whole_net(tag):
             ev = R.derived_forward(sd, x, geno, depth=kw['depth'], supervision=kw.get('supervision', False),
                                    training=False)[-1]
         _close(ev, z[tag + '/logits_eval'], tag + ' eval', rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('tag', gio.index('nets_full'))
+def test_full_width_net_every_gradient(tag):
+    """c = 32 nets at the reference's initialisation scale: EVERY parameter gradient of the oracle (fp32) against the
+    reference's fp64 gradients.  The fixtures record that the reference's own fp32 run is within 2e-5 of them on every
+    tensor, so the bound needs no conditioning escape."""
+    z = gio.load('nets_full')
+    assert float(z[tag + '/ref32_vs_ref64']) < 1e-4
+    sd, x, tgt, outs, kw = _run_net(z, tag)
+    _close(outs[-1].detach(), z[tag + '/logits'], tag + ' logits', rtol=2e-4, atol=2e-5)
+    loss = R.dice_ce_loss(outs[-1], tgt)
+    _close(loss.detach(), z[tag + '/loss'], tag + ' loss', rtol=1e-5, atol=1e-6)
+    loss.backward()
+    got = gio.alias_shared_stem(_grads_of(sd), 'net.' if 'nas' in tag.split('.') else '')
+    exp = gio.unpack(z, tag + '/grad64/')
+    top = float(z[tag + '/grad_top'])
+    assert set(exp) <= set(got)
+    worst = max(float(np.abs(got[k] - e).max()) / max(float(np.abs(e).max()), 1e-3 * top) for k, e in exp.items())
+    assert worst <= 1e-4, worst
 
 
 def test_search_step_trajectory():

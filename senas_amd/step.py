@@ -66,6 +66,7 @@ class GraphedForwardBackward(object):
         self.grid = _macro_grid(model)
         self.early = early if (early is not None and early.world > 1 and self.grid is not None) else None
         self._work = None
+        self._collectives = True
         if packer is None:
             packer = WeightPacker(model)           # one launch per step refreshes every conv's weight image
             packer.install()
@@ -122,6 +123,8 @@ class GraphedForwardBackward(object):
         return loss
 
     def _launch_early(self):
+        if not self._collectives:
+            return
         e = self.early
         self._work = dist.all_reduce(e.sink.span(e.first, e.last), op=dist.ReduceOp.SUM, group=e.group, async_op=True)
 
@@ -131,7 +134,7 @@ class GraphedForwardBackward(object):
         # counters) would advance on whatever the static buffers hold -- put them back afterwards
         buffers = [b for b in self.model.buffers()]
         kept = [b.detach().clone() for b in buffers]
-        early, self.early = self.early, None       # no collectives while warming up
+        self._collectives = False                  # the warm-up passes run cut in two like the captured ones, without the all-reduce
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -139,7 +142,7 @@ class GraphedForwardBackward(object):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.early = early
+        self._collectives = True
         reset_arena()
         graph = torch.cuda.CUDAGraph(keep_graph=True) if self.count_nodes else torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime

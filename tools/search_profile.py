@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    print(bench.bench_search(torch.device('cuda:0'), steps), flush=True)
+    print(bench.bench_search(torch.device('cuda:0'), steps, 0, 1), flush=True)
 
 
 if __name__ == '__main__':

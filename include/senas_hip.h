@@ -229,6 +229,48 @@ int senas_bnrelu_multi_fwd(const senas_bnrelu_item* items, int k, int n, int64_t
                            float eps, void* stream);
 int senas_bnrelu_multi_bwd(const senas_bnrelu_item* items, int k, int n, int64_t hw, int c, void* stream);
 
+/* ---- the second half of k DepSepConv candidates in one pass per direction ---------------------------------------------
+ * utils/operations.py:107-115: depthwise conv -> BatchNorm2d(c_in) -> ReLU -> 1x1 conv (c_in -> c_out) -> BatchNorm2d.
+ * Given the depthwise outputs z1 (with their producer-side statistics), problem p computes
+ *     z2 = W relu(BN1(z1))
+ * with BN1 + ReLU applied on load (the activated tensor is never stored) and the statistics of z2 for the BatchNorm2d
+ * that follows (applied by the cell node, senas_node_fwd).  Backward (two launches for all k problems): dz1, d gamma1,
+ * d beta1 and dW from dz2, recomputing W^T dz2 and the ReLU mask per pixel instead of storing them.
+ * cin a power-of-two multiple of 4 up to 64, cout 4 or 8; otherwise SENAS_EUNSUPPORTED and nothing is launched.
+ * items: HOST array of k descriptors (k <= SENAS_MAX_DSTAIL).
+ *   forward : reads z1, stats1 (training != 0; else running_mean1 / running_var1), gamma1, beta1, w; writes z2, stats2
+ *             (ADDED into, may be NULL), mean_invstd (float[2][cin], kept for backward), the running buffers of BN1.
+ *   backward: reads z1, dz2 (pixel stride dz2_pixel_stride floats, 0 = cout), w, gamma1, beta1, mean_invstd; sums:
+ *             double[n][cin][2], ZERO on entry; writes dz1 (NULL: skipped), dgamma1, dbeta1 (float[cin]) and -- when dw
+ *             is given (for all problems or none) -- dw [cout][cin], accumulated in dw_acc (double[cout][cin] =
+ *             senas_dstail_ws_bytes(...) bytes per problem, ZERO on entry).                                          */
+#define SENAS_MAX_DSTAIL 8
+typedef struct senas_dstail_item {
+    const float* z1;
+    const double* stats1;
+    const float* gamma1;
+    const float* beta1;
+    float* running_mean1;
+    float* running_var1;
+    int64_t* num_batches_tracked1;
+    float* mean_invstd;
+    const float* w;
+    float* z2;
+    double* stats2;
+    const float* dz2;
+    int64_t dz2_pixel_stride;
+    double* sums;
+    float* dz1;
+    float* dgamma1;
+    float* dbeta1;
+    float* dw;
+    double* dw_acc;
+} senas_dstail_item;
+int senas_dstail_fwd(const senas_dstail_item* items, int k, int n, int64_t hw, int cin, int cout, int training,
+                     float momentum, float eps, void* stream);
+int64_t senas_dstail_ws_bytes(int k, int n, int64_t hw, int cin, int cout);
+int senas_dstail_bwd(const senas_dstail_item* items, int k, int n, int64_t hw, int cin, int cout, void* stream);
+
 /* ---- fused "normalise, gate, mix, add, activate" ------------------------------------------------
  * y[n,p,c] = act( sum_t coef[t][n][c] * z_t[n,p,c] + bias[n][c] (+ residual[n,p,c]) )
  * This single pass replaces, per cell node, the BatchNorm2d of every candidate op, the SE channel

@@ -34,6 +34,16 @@ class BnReluItem(C.Structure):
                 ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('sums', C.c_void_p)]
 
 
+class DsTailItem(C.Structure):
+    """senas_dstail_item (include/senas_hip.h)."""
+    _fields_ = [('z1', C.c_void_p), ('stats1', C.c_void_p), ('gamma1', C.c_void_p), ('beta1', C.c_void_p),
+                ('running_mean1', C.c_void_p), ('running_var1', C.c_void_p), ('num_batches_tracked1', C.c_void_p),
+                ('mean_invstd', C.c_void_p), ('w', C.c_void_p), ('z2', C.c_void_p), ('stats2', C.c_void_p), ('dz2', C.c_void_p),
+                ('dz2_pixel_stride', C.c_int64), ('sums', C.c_void_p), ('dz1', C.c_void_p), ('dgamma1', C.c_void_p),
+                ('dbeta1', C.c_void_p), ('dw', C.c_void_p), ('dw_acc', C.c_void_p)]
+
+
+MAX_DSTAIL = 8
 MAX_BNRELU = 8
 MAX_DWMULTI = 4
 MAX_PWMULTI = 8
@@ -91,6 +101,9 @@ SIGNATURES = {
     'senas_pw_multi_bwd_weight': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _P, _P]),
     'senas_bnrelu_multi_fwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _I, _F, _F, _P]),
     'senas_bnrelu_multi_bwd': (_I, [C.POINTER(BnReluItem), _I, _I, _L, _I, _P]),
+    'senas_dstail_fwd': (_I, [C.POINTER(DsTailItem), _I, _I, _L, _I, _I, _I, _F, _F, _P]),
+    'senas_dstail_ws_bytes': (C.c_int64, [_I, _I, _L, _I, _I]),
+    'senas_dstail_bwd': (_I, [C.POINTER(DsTailItem), _I, _I, _L, _I, _I, _P]),
     'senas_combine_fwd': (_I, [_I, _L, _I, _I, _PP, _P, _P, _P, _I, _P, _P]),
     'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
     'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),

@@ -90,6 +90,7 @@ class Cell(nn.Module):
 
     # ------------------------------------------------------------------ state-major execution
     stacked = True      # run same-named candidates of the edges LEAVING one state as one convolution (class-wide switch)
+    fused_tail = True   # DepSepConv candidates: batch-norm + ReLU + 1x1 convolution as one pass (functional.dstail)
 
     def _out_edges(self, j):
         """Flat indices of the edges that read state j (one per later node)."""
@@ -159,11 +160,14 @@ class Cell(nn.Module):
                 for i, (z, st) in zip(idxs, parts):
                     zs[i], sts[i] = z, st
             bns = [m[1] for _, _, m in items]
-            if F.bnrelu_multi_ok(zs, bns):
-                mids = F.bnrelu_multi(zs, bns, sts)
-            else:
-                mids = [F.bn_combine([F.Term(z, bn, stats=st)], relu=True) for z, bn, st in zip(zs, bns, sts)]
-            pws = F.pw_multi(mids, [m[3] for _, _, m in items], items[0][2][4].training)      # the pointwise halves, batched
+            # batch-norm + ReLU + pointwise convolution of all of them: one launch, the activated tensors never stored
+            pws = F.dstail(zs, bns, sts, [m[3] for _, _, m in items], items[0][2][4].training) if self.fused_tail else None
+            if pws is None:
+                if F.bnrelu_multi_ok(zs, bns):
+                    mids = F.bnrelu_multi(zs, bns, sts)
+                else:
+                    mids = [F.bn_combine([F.Term(z, bn, stats=st)], relu=True) for z, bn, st in zip(zs, bns, sts)]
+                pws = F.pw_multi(mids, [m[3] for _, _, m in items], items[0][2][4].training)      # the pointwise halves, batched
             if pws is None:
                 pws = [run_conv(m[3], mid, want_stats=m[4].training) for (_, _, m), mid in zip(items, mids)]
             return [(e, p, F.Term(z2, m[4], stats=st2)) for (e, p, m), (z2, st2) in zip(items, pws)]

@@ -721,6 +721,119 @@ def bnrelu_multi(zs, bns, stats):
     return list(_BnReluMulti.apply(meta, *flat))
 
 
+class _DsTail(torch.autograd.Function):
+    """z2_t = W_t relu(BatchNorm2d_t(z1_t)) for k DepSepConv candidates in ONE launch, two backward (senas_dstail_*): the
+    batch-norm + ReLU of the depthwise half is applied on load by the pointwise half, forward and backward, so the
+    activated tensor and its gradient never exist in memory.  flat = [z1.., gamma1.., beta1.., w..]; outputs z2.. (+ the
+    producer-side statistics of every z2 for the BatchNorm2d that follows)."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        k = meta['k']
+        z1s = [nhwc(z) for z in flat[:k]]
+        gammas = [_dev(g).contiguous() for g in flat[k:2 * k]]
+        betas = [_dev(b).contiguous() for b in flat[2 * k:3 * k]]
+        ws = [_dev(w).contiguous() for w in flat[3 * k:4 * k]]
+        n, cin, h, w_ = z1s[0].shape
+        cout = ws[0].shape[0]
+        dev = z1s[0].device
+        z2s = [new_nhwc(n, cout, h, w_, z1s[0]) for _ in range(k)]
+        stats2 = [new_stats(n, cout, z1s[0]) for _ in range(k)] if meta['want_stats'] else []
+        saved = torch.empty((k, 2, cin), device=dev, dtype=torch.float32)
+        items = (_lib.DsTailItem * k)()
+        for t in range(k):
+            if tuple(z1s[t].shape) != (n, cin, h, w_) or tuple(ws[t].shape[:2]) != (cout, cin):
+                raise SenasHipError('dstail: problems disagree in shape')
+            rm, rv, nbt = meta['buffers'][t]
+            it = items[t]
+            it.z1, it.stats1 = z1s[t].data_ptr(), _p(meta['stats'][t])
+            it.gamma1, it.beta1 = gammas[t].data_ptr(), betas[t].data_ptr()
+            it.running_mean1, it.running_var1, it.num_batches_tracked1 = _p(rm), _p(rv), _p(nbt)
+            it.mean_invstd = saved[t].data_ptr()
+            it.w, it.z2 = ws[t].data_ptr(), z2s[t].data_ptr()
+            it.stats2 = stats2[t].data_ptr() if stats2 else None
+        _lib.check(_lib.lib().senas_dstail_fwd(items, k, n, h * w_, cin, cout, int(meta['training']), BN_MOMENTUM, BN_EPS, _stream()),
+                   'senas_dstail_fwd')
+        ctx.k, ctx.dims = k, (n, cin, cout, h, w_)
+        ctx.save_for_backward(saved, *z1s, *gammas, *betas, *ws)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*stats2)
+        return tuple(z2s) + tuple(stats2)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k, L = ctx.k, _lib.lib()
+        n, cin, cout, h, w_ = ctx.dims
+        saved = ctx.saved_tensors[0]
+        z1s, gammas, betas, ws = (ctx.saved_tensors[1 + i * k:1 + (i + 1) * k] for i in range(4))
+        dev = saved.device
+        if all(g is None for g in grads[:k]):
+            return (None,) * (1 + 4 * k)
+        need = ctx.needs_input_grad
+        want_w = any(need[1 + 3 * k:1 + 4 * k])
+        dz1s = [torch.empty_like(z1s[t], memory_format=CL) if need[1 + t] else None for t in range(k)]
+        dgt, dgs = zip(*[wgrad_dest(g) for g in gammas])
+        dbt, dbs = zip(*[wgrad_dest(b) for b in betas])
+        dwt, dws = zip(*[wgrad_dest(w) for w in ws]) if want_w else ((None,) * k, (None,) * k)
+        sums = zeros64((k, n, cin, 2), dev)
+        dw_acc = zeros64((k, cout * cin), dev) if want_w else None          # fp64 accumulators of the k weight gradients
+        items = (_lib.DsTailItem * k)()
+        keep = []
+        for t in range(k):
+            dy = grads[t]
+            if dy is None:
+                dy = torch.zeros((n, cout, h, w_), device=dev).contiguous(memory_format=CL)
+            _dev(dy)
+            ct = dy.stride(3) if dy.dim() == 4 else 0
+            if tuple(dy.shape) == (n, cout, h, w_) and ct > cout and dy.stride() == (h * w_ * ct, 1, w_ * ct, ct):
+                stride = ct                                   # a channel slice of a wider NHWC tensor, read in place
+            else:
+                dy, stride = nhwc(dy), cout
+            keep.append(dy)
+            it = items[t]
+            it.z1, it.gamma1, it.beta1 = z1s[t].data_ptr(), gammas[t].data_ptr(), betas[t].data_ptr()
+            it.mean_invstd, it.w = saved[t].data_ptr(), ws[t].data_ptr()
+            it.dz2, it.dz2_pixel_stride, it.sums = dy.data_ptr(), stride, sums[t].data_ptr()
+            it.dz1, it.dgamma1, it.dbeta1 = _p(dz1s[t]), dgt[t].data_ptr(), dbt[t].data_ptr()
+            if want_w:
+                it.dw, it.dw_acc = dwt[t].data_ptr(), dw_acc[t].data_ptr()
+        _lib.check(L.senas_dstail_bwd(items, k, n, h * w_, cin, cout, _stream()), 'senas_dstail_bwd')
+        return (None,) + tuple(dz1s) + tuple(dgs) + tuple(dbs) + tuple(dws)
+
+
+def dstail(z1s, bns, stats, convs, want_stats):
+    """[(z2_t, stats2_t)] for k (depthwise output, its BatchNorm2d, its producer statistics, the 1x1 convolution that
+    follows the ReLU) quadruples, or None when the shapes are off the fused path (the caller then runs batch-norm + ReLU and
+    the pointwise convolutions as separate launches)."""
+    k = len(z1s)
+    if not 1 <= k <= _lib.MAX_DSTAIL:
+        return None
+    n, cin, h, w_ = z1s[0].shape
+    c0 = convs[0]
+    cout = c0.weight.shape[0]
+    if isinstance(c0, torch.nn.ConvTranspose2d) or any(tuple(z.shape) != (n, cin, h, w_) for z in z1s):
+        return None
+    for c in convs:
+        if (c.kernel_size, c.stride, c.padding, c.groups, tuple(c.weight.shape)) != ((1, 1), (1, 1), (0, 0), 1, (cout, cin, 1, 1)) or c.bias is not None:
+            return None
+    training = bns[0].training
+    if any(bn.training != training for bn in bns):
+        return None
+    if not training and torch.is_grad_enabled() and any(z.requires_grad for z in z1s):
+        return None                                          # (the kernel pair has no eval-mode backward)
+    if _lib.lib().senas_dstail_ws_bytes(k, n, h * w_, cin, cout) == 0:
+        return None
+    st = list(stats)
+    for t in range(k):
+        if training and st[t] is None:
+            st[t] = chan_stats(z1s[t])
+    meta = {'k': k, 'training': training, 'stats': st, 'want_stats': bool(want_stats),
+            'buffers': [(bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn in bns]}
+    flat = list(z1s) + [bn.weight for bn in bns] + [bn.bias for bn in bns] + [c.weight for c in convs]
+    out = _DsTail.apply(meta, *flat)
+    return [(out[t], out[k + t] if want_stats else None) for t in range(k)]
+
+
 class _StackFn(torch.autograd.Function):
     """The stacked weight buffer as a differentiable function of the per-edge parameters it is assembled from: the
     forward pass hands out the (already filled) buffer, the backward pass hands every parameter its slice of d buffer."""

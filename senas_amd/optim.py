@@ -94,6 +94,7 @@ class FusedClipSGD(object):
                                                   self.grad_clip, g['lr'], g['momentum'], g['dampening'], g['weight_decay'],
                                                   int(g['nesterov']), 0, self.total_norm.data_ptr(), F._stream()),
                    'senas_sgd_clip_step')
+        self.opt._opt_called = True        # (what lr schedulers look at to warn about a step order they cannot see here)
         if had_first:                      # those buffers now hold the first gradient: drop the flags
             self.table = None
         return self.total_norm

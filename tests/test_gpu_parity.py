@@ -1441,3 +1441,69 @@ def test_blend2_vs_torch():
     close(a.grad, a64.grad.numpy(), 'dx1', rel=1e-5)
     close(b.grad, b64.grad.numpy(), 'dx2', rel=1e-5)
     close(g.grad, g64.grad.numpy(), 'dgamma', rel=1e-4)
+
+
+@pytest.mark.parametrize('case', [(3, 2, 32, 8, 12, 20, True, False), (6, 4, 32, 8, 16, 16, True, True), (2, 2, 8, 8, 9, 7, True, False),
+                                  (8, 1, 64, 4, 8, 8, True, True), (1, 3, 16, 8, 5, 5, True, False), (4, 2, 32, 8, 8, 12, False, False),
+                                  (6, 4, 32, 8, 64, 64, True, False)])
+def test_dstail_vs_torch(case):
+    """senas_dstail_fwd / _bwd -- BatchNorm2d + ReLU + 1x1 convolution of k DepSepConv candidates as one pass, the activated
+    tensor recomputed instead of stored -- against float64 torch: outputs, producer statistics, running buffers, dz1,
+    dgamma1, dbeta1, dW (folded by the last block); with the upstream gradient arriving as a channel slice (strided)."""
+    from senas_amd import functional as F
+    k, n, cin, cout, h, w, training, strided = case
+    gen = torch.Generator().manual_seed(sum(case[:6]))
+    bns = [nn.BatchNorm2d(cin) for _ in range(k)]
+    convs = [nn.Conv2d(cin, cout, 1, bias=False) for _ in range(k)]
+    zs, want = [], []
+    wide = [torch.randn(n, 3 * cout, h, w, generator=gen) for _ in range(k)]
+    for bn, conv, wd in zip(bns, convs, wide):
+        with torch.no_grad():
+            bn.weight.copy_(1.0 + 0.3 * torch.randn(cin, generator=gen))
+            bn.bias.copy_(0.3 * torch.randn(cin, generator=gen))
+            bn.running_mean.copy_(0.2 * torch.randn(cin, generator=gen))
+            bn.running_var.copy_(0.5 + torch.rand(cin, generator=gen))
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (1.0 / cin ** 0.5))
+        bn.train(training)
+        z = (0.3 + torch.randn(n, cin, h, w, generator=gen)) * 1.5
+        zs.append(z)
+        rbn, rconv = nn.BatchNorm2d(cin).double(), nn.Conv2d(cin, cout, 1, bias=False).double()
+        rbn.load_state_dict({kk: (v.double() if v.is_floating_point() else v.clone()) for kk, v in bn.state_dict().items()})
+        rconv.weight.data.copy_(conv.weight.double())
+        rbn.train(training)
+        zz = z.double().requires_grad_(True)
+        y = rconv(torch.relu(rbn(zz)))
+        (y * wd[:, cout:2 * cout].double()).sum().backward()
+        want.append((y.detach(), zz.grad, rbn.weight.grad, rbn.bias.grad, rconv.weight.grad, rbn.running_mean, rbn.running_var))
+    dbns, dconvs = [bn.to(dev()) for bn in bns], [c.to(dev()) for c in convs]
+    z_in = [z.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for z in zs]
+    if not training:
+        assert F.dstail(z_in, dbns, [None] * k, dconvs, False) is None      # eval mode only without autograd
+        with torch.no_grad():
+            outs = F.dstail(z_in, dbns, [None] * k, dconvs, False)
+        for (y, st), wnt in zip(outs, want):
+            assert st is None
+            close(y, wnt[0].numpy(), 'eval output', rel=2e-5)
+        return
+    outs = F.dstail(z_in, dbns, [None] * k, dconvs, True)
+    loss = 0
+    for (y, st), wd in zip(outs, wide):
+        wdev = wd.to(dev()).contiguous(memory_format=torch.channels_last)
+        if strided:
+            cat = torch.cat([torch.zeros_like(y), y, torch.zeros_like(y)], dim=1)        # dy of y = a channel slice of d cat
+            loss = loss + (cat * wdev).sum()
+        else:
+            loss = loss + (y * wdev[:, cout:2 * cout]).sum()
+    loss.backward()
+    for t in range(k):
+        y, dz, dg, db, dw, rm, rv = want[t]
+        close(outs[t][0], y.numpy(), 'output %d' % t, rel=2e-5)
+        exp = torch.stack([y.sum((2, 3)), (y ** 2).sum((2, 3))], -1)
+        close(outs[t][1].float(), exp.float().numpy(), 'stats %d' % t, rel=2e-5)
+        close(z_in[t].grad, dz.numpy(), 'dz1 %d' % t, rel=2e-4)
+        close(dbns[t].weight.grad, dg.numpy(), 'dgamma %d' % t, rel=2e-4)
+        close(dbns[t].bias.grad, db.numpy(), 'dbeta %d' % t, rel=2e-4)
+        close(dconvs[t].weight.grad, dw.numpy(), 'dW %d' % t, rel=2e-4)
+        close(dbns[t].running_mean, rm.numpy(), 'running_mean %d' % t, rel=2e-5)
+        close(dbns[t].running_var, rv.numpy(), 'running_var %d' % t, rel=2e-5)
+        assert int(dbns[t].num_batches_tracked) == 1

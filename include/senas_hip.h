@@ -319,16 +319,21 @@ typedef struct senas_node_desc {
     const float* se_w1[SENAS_MAX_TERMS];
     const float* se_w2[SENAS_MAX_TERMS];
     int32_t se_mid[SENAS_MAX_TERMS];
+    int32_t stats_image_stride[SENAS_MAX_TERMS];   /* doubles between the statistics of consecutive images; 0 = 2c (dense) */
     const float* mix;
 } senas_node_desc;
 
-/* y = act(sum_t mix_t * gate_t * BN_t(z_t) + residual).  Saved for backward (caller-allocated):
+/* y = act(sum_t mix_t * gate_t * BN_t(z_t) + residual).
+ * z_pixel_stride (may be NULL = all dense): floats between consecutive pixels of z_t; larger than c when z_t is a channel
+ * slice of a wider NHWC tensor -- the per-edge part of a stacked convolution output (search/cell.py:100-106 sums the
+ * candidates of several edges; their same-named convolutions run as one), read in place together with the matching
+ * slice of the stacked statistics (stats_image_stride).  Saved for backward (caller-allocated):
  *   coefs  float[nterms][4][c]  (mean, invstd, scale, shift)      gate   float[nterms][n][c]
  *   coef   float[nterms][n][c]  shiftc float[nterms][n][c]        (scratch of the forward pass)
  *   se_m   float[nterms][n][c], se_a1 float[nterms][n][16]        (only touched for SE terms; may be NULL without)
  *   mask8  uint8[n*hw*c/4] or NULL: with relu and c % 4 == 0, byte k holds (y > 0) of the 4 floats of 16-byte
  *          piece k in bits 0..3 -- lets the backward pass read 1 byte where it would read 16 of y          */
-int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
+int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                    float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, uint8_t* mask8,
                    void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
@@ -341,7 +346,7 @@ int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const flo
  *   given, else from y; one of the two must be non-NULL.
  *   dy_pixel_stride: floats between consecutive pixels of dy (0 or c: dense NHWC; larger: dy is a channel slice of a
  *   wider NHWC tensor, e.g. the gradient of a torch.cat along channels -- read in place, no copy).             */
-int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
+int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* dy, int64_t dy_pixel_stride,
                    const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                    double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, int dmix_accumulate,
                    float* const* dse_w1, float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride,

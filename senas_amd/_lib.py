@@ -59,7 +59,7 @@ class NodeDesc(C.Structure):
                 ('stats', C.c_void_p * _T), ('gamma', C.c_void_p * _T), ('beta', C.c_void_p * _T),
                 ('running_mean', C.c_void_p * _T), ('running_var', C.c_void_p * _T),
                 ('num_batches_tracked', C.c_void_p * _T), ('se_w1', C.c_void_p * _T), ('se_w2', C.c_void_p * _T),
-                ('se_mid', C.c_int32 * _T), ('mix', C.c_void_p)]
+                ('se_mid', C.c_int32 * _T), ('stats_image_stride', C.c_int32 * _T), ('mix', C.c_void_p)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -112,8 +112,8 @@ SIGNATURES = {
     'senas_dice_ce_bwd': (_I, [_L, _I, _P, _P, _P, _P, _P, _P]),
     'senas_seg_metric_update': (_I, [_I, _L, _I, _P, _P, _F, _P, _P, _P, _P]),
     'senas_sgd_clip_step': (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
-    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'senas_node_bwd': (_I, [_N, _PP, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
+    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_kernel_name': (C.c_char_p, [_G, _I]),
     'senas_last_error': (C.c_char_p, []),
     'senas_abi_version': (_I, []),

@@ -129,15 +129,16 @@ class Cell(nn.Module):
             self.__dict__.setdefault('_stacks', {}).setdefault(('post', id(post.conv)), F.StackedWeight([post.conv.weight], 1, pad_to=32))
         return [v for v in self.__dict__.get('_stacks', {}).values() if isinstance(v, F.StackedWeight)]
 
-    def _stacked_conv(self, convs, x):
+    def _stacked_conv(self, convs, x, want_stats):
         """ONE convolution for the same-geometry convolutions of k edges that read the same tensor: weights stacked along
-        c_out (every edge receives its slice of the stacked weight gradient), output split per edge by the caller."""
+        c_out (every edge receives its slice of the stacked weight gradient).  Returns the stacked output and its
+        producer-side statistics; the caller hands every edge its channel slice of both (functional.unstack: aliases, no
+        launch)."""
         c0 = convs[0]
         tr = isinstance(c0, nn.ConvTranspose2d)
         w = self._stack(convs).tensor()
-        z, _ = F.conv2d(x, w, stride=c0.stride[0], pad=c0.padding[0], dil=c0.dilation[0], transposed=tr,
-                        out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=False)
-        return z
+        return F.conv2d(x, w, stride=c0.stride[0], pad=c0.padding[0], dil=c0.dilation[0], transposed=tr,
+                        out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=want_stats)
 
     def _depsep_job(self, items):
         """DepSepConv candidates (edge, position, module) that read one state: their depthwise convolutions, ONE batched
@@ -196,10 +197,11 @@ class Cell(nn.Module):
 
                 def job(xs, mods=mods, p=p):
                     convs = [m[0] for m in mods]
-                    z = self._stacked_conv(convs, xs[0])
                     se = isinstance(mods[0], ConvBnSe)
+                    want = mods[0][1].training or se
+                    z, st = self._stacked_conv(convs, xs[0], want)
                     sw = self._stack(convs)
-                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=mods[0][1].training or se, used=len(mods), owner=sw)
+                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=want, used=len(mods), owner=sw, stats=st)
                     return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
                             for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
@@ -208,9 +210,10 @@ class Cell(nn.Module):
 
                 def job(xs, mods=mods, p=p):
                     convs = [m.conv for m in mods]
-                    z = self._stacked_conv(convs, mods[0]._resample(xs[0]))     # resampled ONCE for the k edges
+                    want = mods[0].norm.training
+                    z, st = self._stacked_conv(convs, mods[0]._resample(xs[0]), want)     # resampled ONCE for the k edges
                     sw = self._stack(convs)
-                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=mods[0].norm.training, used=len(mods), owner=sw)
+                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=want, used=len(mods), owner=sw, stats=st)
                     return [(e, p, F.Term(zz, m.norm, stats=st, grad_slot=slot)) for e, m, (zz, st, slot) in zip(edges, mods, parts)]
                 jobs.append((job, 1))
             elif self.stacked and isinstance(m0, DepSepConv):

@@ -29,11 +29,14 @@ struct NodeDesc {                // device-visible copy of senas_node_desc
     const float* w1[SENAS_MAX_TERMS];
     const float* w2[SENAS_MAX_TERMS];
     int mid[SENAS_MAX_TERMS];
+    int sstride[SENAS_MAX_TERMS];   // doubles between the statistics of consecutive images (2c when dense; wider: the term
+                                    // is a channel slice of a stacked convolution output and so are its statistics)
     const float* mix;
 };
 
 struct ZTable {
     const float* p[SENAS_MAX_TERMS];
+    int s[SENAS_MAX_TERMS];         // pixel stride of z_t in floats (c when dense; wider: a channel slice of a stacked tensor)
 };
 struct DzTable {
     float* p[SENAS_MAX_TERMS];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void node_prepare_fwd_kernel(NodeDesc d, float
     double s = 0.0, q = 0.0;
     if (act && st != nullptr && (d.training || se))
         for (int i = row; i < n; i += R) {
-            const double v0 = st[((size_t)i * c + ch) * 2], v1 = st[((size_t)i * c + ch) * 2 + 1];
+            const double v0 = st[(size_t)i * d.sstride[t] + ch * 2], v1 = st[(size_t)i * d.sstride[t] + ch * 2 + 1];
             s += v0; q += v1;
             if (se) zsum_s[i * c + ch] = v0;
         }
@@ -174,6 +177,7 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
     const size_t img_off = (size_t)n * hw * c;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cv) * V;
+        const size_t pixel = (size_t)n * hw + (size_t)(i / cv);
         const size_t off = img_off + (size_t)(i / cv) * c + ch;
         float acc[V], tmp[V];
 #pragma unroll
@@ -185,7 +189,7 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
         }
         for (int t = 0; t < nterms; ++t) {
             if (z.p[t] == nullptr) continue;
-            ldv<V>(z.p[t] + off, tmp);
+            ldv<V>(z.p[t] + pixel * z.s[t] + ch, tmp);
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
         }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
         double s = 0.0, q = 0.0;
         if (act && st != nullptr && (d.training || se))
             for (int i = row; i < nimg; i += R) {
-                const double v0 = st[((size_t)i * c + ch) * 2], v1 = st[((size_t)i * c + ch) * 2 + 1];
+                const double v0 = st[(size_t)i * d.sstride[t] + ch * 2], v1 = st[(size_t)i * d.sstride[t] + ch * 2 + 1];
                 s += v0; q += v1;
                 if (i == n) zown[ch] = v0;
             }
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) void node_reduce_kernel(long hw, int c, long c
             a1 += ds;
 #pragma unroll
             for (int t = 0; t < TT; ++t)
-                if (t < tt && z.p[t0 + t] != nullptr) a2[t] += (double)ds * (double)z.p[t0 + t][o];
+                if (t < tt && z.p[t0 + t] != nullptr) a2[t] += (double)ds * (double)z.p[t0 + t][((size_t)n * hw + p) * z.s[t0 + t] + ch];
         }
     }
     auto reduce_to = [&](double v, double* dst) {
@@ -425,7 +429,8 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
             }
 #pragma unroll
             for (int t = 0; t < TT; ++t)
-                if (t < tt && z.p[t0 + t] != nullptr) zv[t][u] = reinterpret_cast<const float4*>(z.p[t0 + t])[o4];
+                if (t < tt && z.p[t0 + t] != nullptr)
+                    zv[t][u] = reinterpret_cast<const float4*>(z.p[t0 + t])[(img + (ok ? pp : q0)) * (size_t)(z.s[t0 + t] >> 2) + q];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(256) void node_prepare_bwd_generic_kernel(NodeDesc 
             for (int j = 0; j < mid; ++j) e += da1[i * kMaxMid + j] * d.w1[t][j * c + ch];
             e /= hw;
         }
-        const double Z = st != nullptr ? st[((size_t)i * c + ch) * 2] : 0.0;
+        const double Z = st != nullptr ? st[(size_t)i * d.sstride[t] + ch * 2] : 0.0;
         s1 += u1 * p1[(size_t)i * c + ch] + hw * e;
         s2 += u1 * p2[tb + (size_t)i * c + ch] + e * Z;
     }
@@ -625,7 +630,7 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
         P1[k] = ok ? p1[o] : 0.0;
         P2[k] = ok ? p2[tb + o] : 0.0;
         Gt[k] = ok ? (double)gate[tb + o] : 0.0;
-        Zs[k] = ok && st != nullptr ? st[o * 2] : 0.0;
+        Zs[k] = ok && st != nullptr ? st[(size_t)(ok ? i : 0) * d.sstride[t] + ch * 2] : 0.0;
     }
     if (se) {
         for (int i = threadIdx.x; i < mid * c; i += 256) { w1_s[i] = d.w1[t][i]; w2_s[i] = d.w2[t][i]; }
@@ -772,7 +777,7 @@ __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, 
             float* out = dz.p[t];
             if (out == nullptr) continue;
             const int ko = t * kt + kbase + ch;
-            ldv<V>(z.p[t] + off, zv);
+            ldv<V>(z.p[t] + ((size_t)n * hw + (size_t)(i / cv)) * z.s[t] + ch, zv);
             ldv<V>(A + ko, av);
             ldv<V>(B + ko, bv);
             ldv<V>(K + ko, kv);
@@ -807,6 +812,7 @@ static bool fill_desc(const senas_node_desc* s, NodeDesc& d) {
         d.w1[t] = in ? s->se_w1[t] : nullptr;
         d.w2[t] = in ? s->se_w2[t] : nullptr;
         d.mid[t] = in ? s->se_mid[t] : 0;
+        d.sstride[t] = (in && s->stats_image_stride[t] > 0) ? s->stats_image_stride[t] : 2 * s->c;
         if (in) {
             if (!d.gamma[t] || !d.beta[t]) return false;
             if ((d.rmean[t] == nullptr) != (d.rvar[t] == nullptr)) return false;
@@ -835,16 +841,29 @@ static unsigned node_grid(long work, int n) {
 
 using namespace senas;
 
-extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const float* residual, float* y,
+// z pixel strides: dense (c) unless given; a strided term must keep 16-byte alignment for the vector kernels
+static bool fill_ztable(const NodeDesc& d, const float* const* z, const int32_t* z_pixel_stride, ZTable& zt) {
+    for (int t = 0; t < SENAS_MAX_TERMS; ++t) { zt.p[t] = nullptr; zt.s[t] = d.c; }
+    for (int t = 0; t < d.nterms; ++t) {
+        zt.p[t] = z[t];
+        zt.s[t] = (z_pixel_stride != nullptr && z_pixel_stride[t] > 0) ? z_pixel_stride[t] : d.c;
+        if (zt.s[t] < d.c) return false;
+        if (zt.s[t] != d.c && d.c % 4 == 0 && (zt.s[t] % 4 != 0 || (reinterpret_cast<uintptr_t>(z[t]) & 15) != 0)) return false;
+        if (d.sstride[t] < 2 * d.c) return false;
+    }
+    return true;
+}
+
+extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                               float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1,
                               uint8_t* mask8, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_fwd: bad descriptor");
     SENAS_REQUIRE(z && y && coefs && gate && coef && shiftc, "node_fwd: null pointer");
     ZTable zt{};
+    SENAS_REQUIRE(fill_ztable(d, z, z_pixel_stride, zt), "node_fwd: a strided term must keep 16-byte alignment and stride >= c");
     bool any_se = false;
     for (int t = 0; t < d.nterms; ++t) {
-        zt.p[t] = z[t];
         if (d.w1[t]) { any_se = true; SENAS_REQUIRE(d.stats[t], "node_fwd: SE term without statistics"); }
         SENAS_REQUIRE(!(d.training && z[t] && !d.stats[t]), "node_fwd: training-mode term without statistics");
     }
@@ -868,7 +887,7 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     return launch_status("node_fwd");
 }
 
-extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const float* dy, int64_t dy_pixel_stride,
+extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* dy, int64_t dy_pixel_stride,
                               const float* y, const uint8_t* mask8, const float* coefs, const float* gate, const float* se_m, const float* se_a1,
                               double* p1, double* p2, float* const* dgamma, float* const* dbeta, float* dmix, int dmix_accumulate,
                               float* const* dse_w1, float* const* dse_w2, float* abk, float* const* dz, const int32_t* dz_pixel_stride,
@@ -883,12 +902,12 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
                   "node_bwd: a strided dy must keep 16-byte alignment");
     const int dys = (int)dy_pixel_stride;
     ZTable zt{};
+    SENAS_REQUIRE(fill_ztable(d, z, z_pixel_stride, zt), "node_bwd: a strided term must keep 16-byte alignment and stride >= c");
     DzTable dzt{};
     SeGradTable seg{};
     seg.dmix_accumulate = dmix_accumulate;
     bool any_se = false, any_dz = false;
     for (int t = 0; t < d.nterms; ++t) {
-        zt.p[t] = z[t];
         dzt.p[t] = dz[t];
         dzt.s[t] = (dz_pixel_stride != nullptr && dz_pixel_stride[t] > 0) ? dz_pixel_stride[t] : d.c;
         SENAS_REQUIRE(dzt.s[t] >= d.c && (d.c % 4 != 0 || dzt.s[t] == d.c ||

@@ -38,6 +38,18 @@ def nhwc(t):
     return t.contiguous(memory_format=CL)
 
 
+def nhwc_slice(t):
+    """(tensor, pixel stride in floats) for a kernel that can read a channel slice of a wider NHWC tensor in place: the
+    slice itself when its layout is [n][h][w][wider c] with 16-byte alignment, else a dense NHWC copy."""
+    _dev(t)
+    if t.dim() == 4:
+        n, c, h, w = t.shape
+        ct = t.stride(3)
+        if ct > c and ct % 4 == 0 and c % 4 == 0 and t.stride() == (h * w * ct, 1, w * ct, ct) and t.data_ptr() % 16 == 0:
+            return t, ct
+    return nhwc(t), t.shape[1]
+
+
 def new_nhwc(n, c, h, w, like):
     return torch.empty((n, c, h, w), device=like.device, dtype=torch.float32, memory_format=CL)
 
@@ -986,10 +998,36 @@ class _Unstack(torch.autograd.Function):
         return torch.cat(gs, dim=1).contiguous(memory_format=CL), None, None, None, None
 
 
-def unstack(z, k, want_stats=True, used=None, owner=None):
+class _UnstackView(torch.autograd.Function):
+    """[n, k*c, h, w] -> k channel slices [n, c, h, w] that ALIAS the stacked tensor: no kernel runs -- the consumers (the
+    cell node kernels) read a slice in place through its pixel stride, and the matching slice of the stacked convolution's
+    own producer-side statistics.  Backward as _Unstack: the consumers write their gradients straight into the stacked
+    gradient buffer (GradLanding)."""
+
+    @staticmethod
+    def forward(ctx, z, k, landing, used):
+        z = nhwc(z)
+        n, kc, h, w = z.shape
+        c = kc // k
+        parts = []
+        for e in range(used):
+            # the same storage, not a view in autograd's eyes (this Function owns the backward pass)
+            parts.append(torch.empty(0, device=z.device, dtype=z.dtype).set_(z.untyped_storage(), z.storage_offset() + e * c,
+                                                                             (n, c, h, w), (h * w * kc, 1, w * kc, kc)))
+        ctx.k, ctx.shape, ctx.k_total, ctx.landing = used, (n, c, h, w), k, landing
+        ctx.set_materialize_grads(False)
+        return tuple(parts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return _Unstack.backward(ctx, *grads)[:4]
+
+
+def unstack(z, k, want_stats=True, used=None, owner=None, stats=None):
     """The per-edge parts of a stacked convolution output: [(z_e, stats_e or None, grad_slot_e)] for the first ``used`` of
     its k parts (the rest is zero-weight padding).  ``owner``: an object (the stack's StackedWeight) that keeps the
-    gradient landing buffer of this shape from pass to pass."""
+    gradient landing buffer of this shape from pass to pass.  ``stats``: the stacked convolution's own statistics
+    (double [n, k*c, 2]) -- with them (or when none are wanted) the parts are aliases of ``z`` and nothing is launched."""
     used = k if used is None else used
     n, kc, h, w = z.shape
     landing = None
@@ -1002,6 +1040,11 @@ def unstack(z, k, want_stats=True, used=None, owner=None):
                 landing = cache[(k, used, shape)] = GradLanding(k, shape, used, persistent=True)
         else:
             landing = GradLanding(k, shape, used)
+    c = kc // k
+    if c % 4 == 0 and (stats is not None or not want_stats):
+        out = _UnstackView.apply(z, k, landing, used)
+        return [(out[e], stats[:, e * c:(e + 1) * c] if stats is not None else None, (landing, e) if landing is not None else None)
+                for e in range(used)]
     out = _Unstack.apply(z, k, want_stats, landing, used)
     return [(out[e], out[used + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(used)]
 

@@ -34,6 +34,8 @@ def _desc(meta, gammas, betas, w1s, w2s, stats, mix):
     for t in range(T):
         rm, rv, nbt = meta['buffers'][t]
         d.stats[t] = stats[t].data_ptr() if stats[t] is not None else None
+        # (a slice of a stacked convolution's statistics: images further apart than 2c doubles)
+        d.stats_image_stride[t] = stats[t].stride(0) if (stats[t] is not None and stats[t].dim() == 3) else 0
         d.gamma[t], d.beta[t] = gammas[t].data_ptr(), betas[t].data_ptr()
         d.running_mean[t] = rm.data_ptr() if rm is not None else None
         d.running_var[t] = rv.data_ptr() if rv is not None else None
@@ -53,7 +55,7 @@ class _Node(torch.autograd.Function):
         L = _lib.lib()
         T, real, se_ids = meta['T'], meta['real'], meta['se']
         nr, ns = len(real), len(se_ids)
-        zs = [F.nhwc(z) for z in flat[:nr]]
+        zs, zstr = zip(*[F.nhwc_slice(z) for z in flat[:nr]]) if nr else ((), ())
         gammas = [F._dev(g).contiguous() for g in flat[nr:nr + T]]
         betas = [F._dev(b).contiguous() for b in flat[nr + T:nr + 2 * T]]
         w1s = [w.contiguous() for w in flat[nr + 2 * T:nr + 2 * T + ns]]
@@ -65,11 +67,13 @@ class _Node(torch.autograd.Function):
             if wt.shape[0] > SE_MID_MAX:
                 raise SenasHipError('SE hidden width %d > %d' % (wt.shape[0], SE_MID_MAX))
         zfull, stats = [None] * T, [None] * T
+        zstrides = (C.c_int32 * T)()
         for k, t in enumerate(real):
             z = zs[k]
             if tuple(z.shape) != (n, c, h, w):
                 raise SenasHipError('node terms disagree in shape: %s vs %s' % (tuple(z.shape), (n, c, h, w)))
             zfull[t] = z
+            zstrides[t] = zstr[k]
             st = meta['stats'][t]
             if st is None and (training or t in se_ids):
                 st = F.chan_stats(z)
@@ -90,7 +94,7 @@ class _Node(torch.autograd.Function):
         mask8 = torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if (meta['relu'] and c % 4 == 0 and tracked) else None
         res = F.nhwc(residual) if residual is not None else None
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
-        _lib.check(L.senas_node_fwd(C.byref(d), zp, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
+        _lib.check(L.senas_node_fwd(C.byref(d), zp, zstrides, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
                                     scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._p(mask8),
                                     F._stream()),
                    'senas_node_fwd')
@@ -132,8 +136,10 @@ class _Node(torch.autograd.Function):
         mix = mixc if ctx.has_mix else None
         d = _desc(meta, gammas, betas, w1s, w2s, ctx.stats, mix)
         zfull = [None] * T
+        zstrides = (C.c_int32 * T)()
         for k, t in enumerate(real):
             zfull[t] = zs[k]
+            zstrides[t] = zs[k].stride(3) if zs[k].stride(3) > c else c       # a slice saved by the forward pass stays a slice
         need = ctx.needs_input_grad
         dzs, dz_strides = [None] * T, (C.c_int32 * T)()
         slots = meta.get('slots') or [None] * T
@@ -166,7 +172,7 @@ class _Node(torch.autograd.Function):
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         dzp = _arr([z.data_ptr() if z is not None else None for z in dzs])
         se_m, se_a1 = ctx.se_buf
-        _lib.check(L.senas_node_bwd(C.byref(d), zp, dy.data_ptr(), dy_stride, yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
+        _lib.check(L.senas_node_bwd(C.byref(d), zp, zstrides, dy.data_ptr(), dy_stride, yptr, F._p(mask8), coefs.data_ptr(), gate.data_ptr(),
                                     F._p(se_m), F._p(se_a1), p[0].data_ptr(), p[1:].data_ptr(),
                                     _arr([t_.data_ptr() for t_ in dgt]), _arr([t_.data_ptr() for t_ in dbt]),
                                     F._p(dmix_dst), dmix_acc, dw1p, dw2p, abk.data_ptr(), dzp, dz_strides, F._p(ds_out),

@@ -112,6 +112,25 @@ int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* bytes, int32_t
 int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
                             float* dw, void* ws, int ws_is_zero, void* stream);
 
+/* Two-stage weight gradients (per-block partial images, then a sum in block order -- bitwise reproducible) with the
+ * second stage DEFERRED: the call launches the partial kernel only and describes the remaining sum in *defer
+ * (defer->kind == 0: nothing is left, dw is complete when the stream has passed the call; defer == NULL: as the plain
+ * entry point).  ws must then stay alive and untouched until senas_wgrad_sum_batched has run for that item: one launch
+ * folds up to SENAS_MAX_SUMS such items (items: HOST array).  A backward pass of the derived network has ~100 of these
+ * 5 us sums, the supernet's ~320 (weight gradients of nn.Conv2d / nn.ConvTranspose2d, utils/operations.py:118-130).   */
+#define SENAS_MAX_SUMS 64
+typedef struct senas_sum_item {
+    const float* part;
+    float* dw;
+    int32_t kind;               /* 0 none, 1 flat partials [nblk][n_elem], 2 wgrad_lds images [nblk][taps * A/32][32][32] */
+    int32_t A, B, taps;         /* kind 2 */
+    int32_t n_elem;             /* kind 1 */
+    int32_t nblk;
+} senas_sum_item;
+int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
+                                     float* dw, void* ws, int ws_is_zero, senas_sum_item* defer, void* stream);
+int senas_wgrad_sum_batched(const senas_sum_item* items, int n, void* stream);
+
 /* ---- pooling / resampling --------------------------------------------------------------------
  * nn.AvgPool2d(3, stride, 1, count_include_pad=False)  (operations.py:62,150)
  * nn.MaxPool2d(3, stride, 1)                            (operations.py:64; senas_search.py:31)
@@ -181,6 +200,9 @@ int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* co
 int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k);
 int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
                                   void* ws, void* stream);
+/* as above with the k sums deferred (defer: k items, see senas_wgrad_sum_batched)                                       */
+int senas_dwconv_multi_bwd_weight_deferred(const senas_conv_geom* g, int k, const float* x, const float* const* dy,
+                                           float* const* dw, void* ws, senas_sum_item* defer, void* stream);
 
 /* ---- k independent pointwise convolutions of one shape ------------------------------------------------------------
  * The 1x1 halves of the DepSepConv candidates (utils/operations.py:107-115) of the edges that leave one state: each

@@ -43,6 +43,13 @@ class DsTailItem(C.Structure):
                 ('dbeta1', C.c_void_p), ('dw', C.c_void_p), ('dw_acc', C.c_void_p)]
 
 
+class SumItem(C.Structure):
+    """senas_sum_item (include/senas_hip.h)."""
+    _fields_ = [('part', C.c_void_p), ('dw', C.c_void_p), ('kind', C.c_int32), ('A', C.c_int32), ('B', C.c_int32), ('taps', C.c_int32),
+                ('n_elem', C.c_int32), ('nblk', C.c_int32)]
+
+
+MAX_SUMS = 64
 MAX_DSTAIL = 8
 MAX_BNRELU = 8
 MAX_DWMULTI = 4
@@ -78,6 +85,8 @@ SIGNATURES = {
     'senas_copy_rows_batched': (_I, [_P, _I, _L, _P]),
     'senas_conv2d_bwd_weight_ws': (_I, [_G, _P, _P]),
     'senas_conv2d_bwd_weight': (_I, [_G, _P, _I, _P, _P, _P, _I, _P]),
+    'senas_conv2d_bwd_weight_deferred': (_I, [_G, _P, _I, _P, _P, _P, _I, C.POINTER(SumItem), _P]),
+    'senas_wgrad_sum_batched': (_I, [C.POINTER(SumItem), _I, _P]),
     'senas_avgpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'senas_avgpool3_bwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     'senas_maxpool3_fwd': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
@@ -95,6 +104,7 @@ SIGNATURES = {
     'senas_dwconv_multi_bwd_data': (_I, [_G, _I, _PP, _PP, _P, _P]),
     'senas_dwconv_multi_ws_bytes': (C.c_int64, [_G, _I]),
     'senas_dwconv_multi_bwd_weight': (_I, [_G, _I, _P, _PP, _PP, _P, _P]),
+    'senas_dwconv_multi_bwd_weight_deferred': (_I, [_G, _I, _P, _PP, _PP, _P, C.POINTER(SumItem), _P]),
     'senas_pw_multi_fwd': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _PP, _P]),
     'senas_pw_multi_bwd_data': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _P]),
     'senas_pw_multi_ws_bytes': (C.c_int64, [_I, _I, _L, _I, _I]),

@@ -193,7 +193,8 @@ int launch_mfma_wgrad(WgradGeom g, const float* I, const float* G, float* dw, fl
 // wgrad_lds.hip (stride-1 "same" weight gradient, persistent, both operands in LDS); part: per-block partial image
 bool lds_wgrad_ok(const WgradGeom& g);
 int64_t lds_wgrad_ws_bytes(const WgradGeom& g);
-int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, hipStream_t st);
+int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                     hipStream_t st);
 void lds_wgrad_name(const WgradGeom& g, char* buf, int len);
 void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st);
 

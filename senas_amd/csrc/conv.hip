@@ -845,8 +845,88 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     return launch_direct<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
 }
 
+// One launch for the second stage of up to SENAS_MAX_SUMS two-stage weight gradients: block b belongs to the item whose
+// block range [first[i], first[i + 1]) contains it.
+struct SumTab {
+    senas_sum_item it[SENAS_MAX_SUMS];
+    int first[SENAS_MAX_SUMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_sum_batched_kernel(SumTab tab) {
+    __shared__ float red[8][32];
+    int i = 0;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.first[i + 1]) ++i;               // block-uniform
+    const senas_sum_item& it = tab.it[i];
+    const int blk = blockIdx.x - tab.first[i];
+    if (it.kind == 1) {             // flat partials [nblk][n_elem] -> dw[n_elem]: one wave per element, fixed-order tree
+        const int e = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (e >= it.n_elem) return;
+        float v = 0.f;
+        for (int b = lane; b < it.nblk; b += 64) v += it.part[(size_t)b * it.n_elem + e];
+        v = wave_sum(v);
+        if (lane == 0) it.dw[e] = v;
+        return;
+    }
+    // kind 2: wgrad_lds partial images [nblk][unit][32 a][32 b] -> torch layout dw[b][a][tap] (as wgrad_lds_sum_kernel)
+    const int b = threadIdx.x & 31, k = threadIdx.x >> 5;
+    const int unit = blk >> 5, arow = blk & 31;
+    const int a_tiles = it.A / 32;
+    const size_t per_blk = (size_t)it.taps * a_tiles * 1024;
+    const float* p = it.part + ((size_t)unit * 32 + arow) * 32 + b;
+    float sacc = 0.f;
+    int j = k;
+    for (; j + 24 < it.nblk; j += 32) {
+        const float v0 = p[(size_t)j * per_blk], v1 = p[(size_t)(j + 8) * per_blk], v2 = p[(size_t)(j + 16) * per_blk],
+                    v3 = p[(size_t)(j + 24) * per_blk];
+        sacc += v0; sacc += v1; sacc += v2; sacc += v3;
+    }
+    for (; j < it.nblk; j += 8) sacc += p[(size_t)j * per_blk];
+    red[k][b] = sacc;
+    __syncthreads();
+    if (k == 0 && b < it.B) {
+        float tot = red[0][b];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) tot += red[q][b];
+        const int tap = unit / a_tiles, a = (unit - tap * a_tiles) * 32 + arow;
+        it.dw[((size_t)b * it.A + a) * it.taps + tap] = tot;
+    }
+}
+
+extern "C" int senas_wgrad_sum_batched(const senas_sum_item* items, int n, void* stream) {
+    SENAS_REQUIRE(items && n >= 1 && n <= SENAS_MAX_SUMS, "wgrad_sum_batched: 1..SENAS_MAX_SUMS items");
+    SumTab tab{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const senas_sum_item& it = items[i];
+        SENAS_REQUIRE(it.part && it.dw && it.nblk >= 1 && (it.kind == 1 || it.kind == 2), "wgrad_sum_batched: bad item");
+        tab.it[i] = it;
+        tab.first[i] = total;
+        if (it.kind == 1) { SENAS_REQUIRE(it.n_elem >= 1, "wgrad_sum_batched: bad item"); total += (it.n_elem + 3) / 4; }
+        else { SENAS_REQUIRE(it.A % 32 == 0 && it.A >= 32 && it.B >= 1 && it.B <= 32 && it.taps >= 1, "wgrad_sum_batched: bad item"); total += it.taps * (it.A / 32) * 32; }
+    }
+    tab.first[n] = total;
+    tab.n = n;
+    hipLaunchKernelGGL(wgrad_sum_batched_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), tab);
+    return launch_status("wgrad_sum_batched");
+}
+
+static void flat_sum(const float* part, float* dw, int n_elem, int nblk, senas_sum_item* defer, hipStream_t st) {
+    if (defer != nullptr) {
+        *defer = senas_sum_item{part, dw, 1, 0, 0, 0, n_elem, nblk};
+        return;
+    }
+    hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, part, dw, n_elem, nblk);
+}
+
 extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw,
                                        void* ws, int ws_is_zero, void* stream) {
+    return senas_conv2d_bwd_weight_deferred(g, x, in_relu, dy, dw, ws, ws_is_zero, nullptr, stream);
+}
+
+extern "C" int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw,
+                                                void* ws, int ws_is_zero, senas_sum_item* defer, void* stream) {
+    if (defer != nullptr) defer->kind = 0;
     SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_weight: inconsistent geometry");
     SENAS_REQUIRE(x && dy && dw, "conv2d_bwd_weight: null pointer");
     hipStream_t st = as_stream(stream);
@@ -879,8 +959,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
             const size_t lds = (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 4 * sizeof(float);     // [waves x row slots][c4][taps][4]
             if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_kernel<3>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
             else hipLaunchKernelGGL((dwconv_wgrad_part_kernel<5>), dim3((unsigned)nblk), dim3(256), lds, st, wg, I, G, part, i_relu, g_relu);
-            const int n_elem = g->ci * taps;
-            hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, part, dw, n_elem, (int)nblk);
+            flat_sum(part, dw, g->ci * taps, (int)nblk, defer, st);
             return launch_status("dwconv_wgrad");
         }
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)g->ci * taps * sizeof(float), st);
@@ -898,9 +977,7 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         int nblk = 0;
         const int rc = launch_thin_n_wgrad(wg, I, G, reinterpret_cast<float*>(ws), i_relu, g_relu, &nblk, st);
         if (rc != SENAS_OK) return rc;
-        const int n_elem = g->ci * g->co * taps;
-        hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw,
-                           n_elem, nblk);
+        flat_sum(reinterpret_cast<const float*>(ws), dw, g->ci * g->co * taps, nblk, defer, st);
         return launch_status("wgrad_thin_n sum");
     }
     if (wgrad_c8_ok(wg)) {
@@ -908,14 +985,12 @@ extern "C" int senas_conv2d_bwd_weight(const senas_conv_geom* g, const float* x,
         int nblk = 0;
         const int rc = launch_wgrad_c8(wg, I, G, reinterpret_cast<float*>(ws), i_relu, g_relu, &nblk, st);
         if (rc != SENAS_OK) return rc;
-        const int n_elem = g->ci * g->co * taps;
-        hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw,
-                           n_elem, nblk);
+        flat_sum(reinterpret_cast<const float*>(ws), dw, g->ci * g->co * taps, nblk, defer, st);
         return launch_status("wgrad_c8 sum");
     }
     if (lds_wgrad_ok(wg) && !g_relu) {        // ConvTranspose2d: I = dy on the fine grid; a ReLU on the coarse operand is not in the kernel
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
-        return launch_lds_wgrad(wg, I, G, reinterpret_cast<float*>(ws), dw, i_relu, st);      // ws need not be zero here
+        return launch_lds_wgrad(wg, I, G, reinterpret_cast<float*>(ws), dw, i_relu, defer, st);      // ws need not be zero here
     }
     if (mfma_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
@@ -1099,6 +1174,11 @@ extern "C" int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k) 
 
 extern "C" int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
                                              void* ws, void* stream) {
+    return senas_dwconv_multi_bwd_weight_deferred(g, k, x, dy, dw, ws, nullptr, stream);
+}
+
+extern "C" int senas_dwconv_multi_bwd_weight_deferred(const senas_conv_geom* g, int k, const float* x, const float* const* dy,
+                                                      float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
     using namespace senas;
     if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
     SENAS_REQUIRE(x && dy && dw && ws, "dwconv_multi_bwd_weight: null pointer");
@@ -1122,6 +1202,10 @@ extern "C" int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, co
     if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<3>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
     else hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<5>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
     const int n_elem = g->ci * taps;
+    if (defer != nullptr) {
+        for (int p = 0; p < k; ++p) defer[p] = senas_sum_item{tab.part[p], tab.dw[p], 1, 0, 0, 0, n_elem, (int)nblk};
+        return launch_status("dwconv_multi_bwd_weight");
+    }
     hipLaunchKernelGGL(dwconv_wgrad_sum_multi_kernel, dim3((n_elem + 3) / 4, k), dim3(256), 0, st, tab, n_elem, (int)nblk);
     return launch_status("dwconv_multi_bwd_weight");
 }

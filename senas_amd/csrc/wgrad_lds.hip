@@ -395,7 +395,8 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
 }
 
 // part: lds_wgrad_ws_bytes(g) of scratch (need not be zeroed); dw: torch layout, overwritten
-int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, hipStream_t st) {
+int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                     hipStream_t st) {
     const int units = g.kh * g.kw * (g.A / 32);
     const int twl = wgrad_tile_width(g);
     int rc = SENAS_EINVAL;
@@ -418,6 +419,10 @@ int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* 
 #undef SENAS_CASE
     if (!found) { set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
     if (rc != SENAS_OK) return rc;
+    if (defer != nullptr) {              // the caller folds the partial images later, together with other convolutions' (senas_wgrad_sum_batched)
+        *defer = senas_sum_item{part, dw, 2, g.A, g.B, g.kh * g.kw, 0, wgrad_lds_blocks(g)};
+        return SENAS_OK;
+    }
     hipLaunchKernelGGL(wgrad_lds_sum_kernel, dim3(units * 32), dim3(256), 0, st, part, dw, g.A, g.B, g.kh * g.kw, wgrad_lds_blocks(g));
     return launch_status("wgrad_lds sum");
 }

@@ -157,6 +157,24 @@ def _packed(w, direction):
 SINK = None
 
 
+# Between GradSink.begin() and .finish(): a list that collects the second stage of two-stage weight gradients
+# ((senas_sum_item, workspace kept alive)); finish() folds them all in a few launches.  None: every call sums at once.
+DEFER = None
+
+
+def flush_deferred():
+    """Run the deferred weight-gradient sums (senas_wgrad_sum_batched, up to 64 per launch) and release their partials."""
+    global DEFER
+    items, DEFER = DEFER, None
+    if not items:
+        return
+    L = _lib.lib()
+    for i in range(0, len(items), _lib.MAX_SUMS):
+        chunk = items[i:i + _lib.MAX_SUMS]
+        arr = (_lib.SumItem * len(chunk))(*[it for it, _ in chunk])
+        _lib.check(L.senas_wgrad_sum_batched(arr, len(chunk), _stream()), 'senas_wgrad_sum_batched')
+
+
 def wgrad_dest(w):
     """Where a backward kernel writes d loss / d w, and what autograd is handed for it: the parameter's view in the
     flat gradient buffer and None (first gradient of the pass under a step driver), or a fresh tensor twice."""
@@ -241,8 +259,16 @@ class _Conv2d(torch.autograd.Function):
             # scratch where it writes per-block partials
             wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
             with _span('conv_wgrad', g, x, w, dy):
-                _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
-                                                     wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
+                if DEFER is not None:
+                    item = _lib.SumItem()
+                    _lib.check(L.senas_conv2d_bwd_weight_deferred(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
+                                                                  wsw.data_ptr(), int(zero.value), C.byref(item), _stream()),
+                               'senas_conv2d_bwd_weight_deferred')
+                    if item.kind:
+                        DEFER.append((item, wsw))             # the partial images stay alive until the batched sum has run
+                else:
+                    _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
+                                                         wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
         return dx, dw, None, None, None, None, None, None, None, None
 
 
@@ -540,8 +566,17 @@ class _DwMulti(torch.autograd.Function):
             dwt, dws = zip(*[wgrad_dest(w) for w in ws])
             scratch = torch.empty(int(L.senas_dwconv_multi_ws_bytes(C.byref(g), k)), device=x.device, dtype=torch.uint8)
             dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            _lib.check(L.senas_dwconv_multi_bwd_weight(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), _stream()),
-                       'senas_dwconv_multi_bwd_weight')
+            if DEFER is not None:
+                items = (_lib.SumItem * k)()
+                _lib.check(L.senas_dwconv_multi_bwd_weight_deferred(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
+                           'senas_dwconv_multi_bwd_weight_deferred')
+                for t in range(k):
+                    one = _lib.SumItem()
+                    C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
+                    DEFER.append((one, scratch))
+            else:
+                _lib.check(L.senas_dwconv_multi_bwd_weight(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), _stream()),
+                           'senas_dwconv_multi_bwd_weight')
         return (dx, None, None) + tuple(dws)
 
 

@@ -94,6 +94,14 @@ class GradSink(object):
             live |= set(k for k, sw in self._stack_by_ptr.items() if any(p.data_ptr() in live for p in sw.params))
             self.written -= live
         self._stacks_written = []
+        self.resume()
+
+    def resume(self):
+        """(Re)open the window in which two-stage weight gradients leave their sums to ``finish()`` (functional.DEFER);
+        ``begin()`` does it, and so does the second half of a backward pass that is cut in two."""
+        if self.flat.is_cuda:
+            from . import functional as F
+            F.DEFER = []
 
     def dest(self, w):
         """Tensor the kernel should write d loss / d w into, or None: not registered, frozen, detached from its view, or
@@ -117,12 +125,15 @@ class GradSink(object):
         return None
 
     def finish(self):
-        """After backward: add the slices of the stacked weight gradients written in this pass to their parameters'
-        views (one launch; the table is built once per set of stacks -- under graph replay, once)."""
+        """After backward: fold the deferred weight-gradient sums (a few launches for all convolutions of the pass), then
+        add the slices of the stacked weight gradients written in this pass to their parameters' views (one launch; the
+        table is built once per set of stacks -- under graph replay, once)."""
+        from . import functional as F
+        if self.flat.is_cuda:
+            F.flush_deferred()
         if not self._stacks_written:
             return
         from . import _lib
-        from . import functional as F
         from .packing import _CopyItem, copy_table
         key = tuple(self._stacks_written)
         if key not in self._scatter:
@@ -155,3 +166,4 @@ class GradSink(object):
         from . import functional as F
         if F.SINK is self:
             F.SINK = None
+            F.DEFER = None

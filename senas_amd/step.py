@@ -104,6 +104,7 @@ class GraphedForwardBackward(object):
 
     def _tail(self):
         """The rest of backward below the cut."""
+        self.reducer.sink.resume()
         try:
             leaves = [l for l in self._cut_leaf if l.requires_grad]
             pairs = [(s, l.grad) for s, l in zip(self._cut_src, leaves) if l.grad is not None]

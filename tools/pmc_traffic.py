@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py into profiles/r1_pmc_traffic.json:
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py into profiles/r2_pmc_traffic.json:
 average FETCH_SIZE / WRITE_SIZE (KB) per launch, keyed by kernel symbol (senas:: prefix and argument list
 stripped, i.e. the name bench.py / senas_conv2d_kernel_name use).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcF -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcW -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW profiles/r1_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW profiles/r2_pmc_traffic.json
 """
 import collections
 import csv
@@ -21,7 +21,7 @@ def load(path, counter):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue
-            name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('senas::', '').strip()
+            name = r['Kernel_Name'].split('(')[0].replace("void ", "").replace("senas::", "").strip()
             acc[name].append(float(r['Counter_Value']))
     return acc
 

@@ -192,7 +192,7 @@ int senas_bn_finalize(int n, int64_t hw, int c, const double* stats, const float
  * k pointers, k <= SENAS_MAX_DWMULTI.  g describes ONE of the convolutions (groups == ci == co).  Returns
  * SENAS_EUNSUPPORTED (nothing launched) off the fast path (channels not a power-of-two multiple of 4, taps not 3x3 / 5x5);
  * ws: senas_dwconv_multi_ws_bytes(g, k) bytes of scratch (per-block partial sums, overwritten).                       */
-#define SENAS_MAX_DWMULTI 4
+#define SENAS_MAX_DWMULTI 8
 int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
                            double* const* stats, void* stream);
 int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
@@ -203,6 +203,18 @@ int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* 
 /* as above with the k sums deferred (defer: k items, see senas_wgrad_sum_batched)                                       */
 int senas_dwconv_multi_bwd_weight_deferred(const senas_conv_geom* g, int k, const float* x, const float* const* dy,
                                            float* const* dw, void* ws, senas_sum_item* defer, void* stream);
+
+/* The same for TWO groups of problems that differ in the kernel size only: ka problems of geometry ga (3x3) followed by kb
+ * of geometry gb (5x5) -- dep_sep_conv_3 and dep_sep_conv_5 of the same edges (utils/operations.py:73-76) share every
+ * launch; ka + kb <= SENAS_MAX_DWMULTI, gb == NULL with kb == 0 is the single-group form.  bwd_weight: defer == NULL sums at
+ * once, else leaves the ka + kb second stages to senas_wgrad_sum_batched.                                                 */
+int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                          const float* const* w, float* const* y, double* const* stats, void* stream);
+int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* const* dy,
+                               const float* const* w, float* dx, void* stream);
+int64_t senas_dwconv_pair_ws_bytes(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb);
+int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                 const float* const* dy, float* const* dw, void* ws, senas_sum_item* defer, void* stream);
 
 /* ---- k independent pointwise convolutions of one shape ------------------------------------------------------------
  * The 1x1 halves of the DepSepConv candidates (utils/operations.py:107-115) of the edges that leave one state: each
@@ -354,10 +366,12 @@ typedef struct senas_node_desc {
  *   coef   float[nterms][n][c]  shiftc float[nterms][n][c]        (scratch of the forward pass)
  *   se_m   float[nterms][n][c], se_a1 float[nterms][n][16]        (only touched for SE terms; may be NULL without)
  *   mask8  uint8[n*hw*c/4] or NULL: with relu and c % 4 == 0, byte k holds (y > 0) of the 4 floats of 16-byte
- *          piece k in bits 0..3 -- lets the backward pass read 1 byte where it would read 16 of y          */
+ *          piece k in bits 0..3 -- lets the backward pass read 1 byte where it would read 16 of y
+ *   out_stats (optional, c = 4 * 2^k): double[n][c][2], the per-image channel sums of y itself are ADDED into it (caller
+ *          zeroes) -- the statistics the BatchNorm2d of an 'identity' candidate reading this node needs                */
 int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                    float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, uint8_t* mask8,
-                   void* stream);
+                   double* out_stats, void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
  *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
  *   dmix: float[nterms] or NULL, overwritten -- or, with dmix_accumulate != 0, added to: the cells of one kind share

@@ -52,7 +52,7 @@ class SumItem(C.Structure):
 MAX_SUMS = 64
 MAX_DSTAIL = 8
 MAX_BNRELU = 8
-MAX_DWMULTI = 4
+MAX_DWMULTI = 8
 MAX_PWMULTI = 8
 UNSUPPORTED = -3
 
@@ -105,6 +105,10 @@ SIGNATURES = {
     'senas_dwconv_multi_ws_bytes': (C.c_int64, [_G, _I]),
     'senas_dwconv_multi_bwd_weight': (_I, [_G, _I, _P, _PP, _PP, _P, _P]),
     'senas_dwconv_multi_bwd_weight_deferred': (_I, [_G, _I, _P, _PP, _PP, _P, C.POINTER(SumItem), _P]),
+    'senas_dwconv_pair_fwd': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _PP, _P]),
+    'senas_dwconv_pair_bwd_data': (_I, [_G, _I, _G, _I, _PP, _PP, _P, _P]),
+    'senas_dwconv_pair_ws_bytes': (C.c_int64, [_G, _I, _G, _I]),
+    'senas_dwconv_pair_bwd_weight': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _P, C.POINTER(SumItem), _P]),
     'senas_pw_multi_fwd': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _PP, _P]),
     'senas_pw_multi_bwd_data': (_I, [_I, _I, _L, _I, _I, _PP, _PP, _PP, _P]),
     'senas_pw_multi_ws_bytes': (C.c_int64, [_I, _I, _L, _I, _I]),
@@ -122,7 +126,7 @@ SIGNATURES = {
     'senas_dice_ce_bwd': (_I, [_L, _I, _P, _P, _P, _P, _P, _P]),
     'senas_seg_metric_update': (_I, [_I, _L, _I, _P, _P, _F, _P, _P, _P, _P]),
     'senas_sgd_clip_step': (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
-    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_kernel_name': (C.c_char_p, [_G, _I]),
     'senas_last_error': (C.c_char_p, []),

@@ -144,12 +144,9 @@ class Cell(nn.Module):
         """DepSepConv candidates (edge, position, module) that read one state: their depthwise convolutions, ONE batched
         BatchNorm + ReLU over all the depthwise outputs (functional.bnrelu_multi), their pointwise convolutions."""
         from .operations import run_conv
-        # depthwise convolutions of the same geometry (dep_sep_conv_3 of every edge, dep_sep_conv_5 of every edge) read the
-        # same state: one batched launch per group (functional.dwconv_multi), one alias of the state per group
-        groups = {}
-        for idx, (_, p, _) in enumerate(items):
-            groups.setdefault(p, []).append(idx)
-        groups = list(groups.values())
+        # the depthwise convolutions of all of them read the same state and differ in nothing but the kernel size: one batched
+        # launch for dep_sep_conv_3 and dep_sep_conv_5 of every edge together (functional.dwconv_multi), one alias of the state
+        groups = [list(range(len(items)))]
 
         def job(xs):
             zs, sts = [None] * len(items), [None] * len(items)
@@ -256,7 +253,8 @@ class Cell(nn.Module):
                 by_pos = terms.pop(offset + j)
                 node_terms += [by_pos[p] for p in sorted(by_pos)]
             offset += nin + i
-            add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True))
+            # a node that feeds later nodes is read by their 'identity' candidates, whose BatchNorm2d needs its channel sums
+            add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True, out_stats=self.training and i < nodes - 1))
         return self._post(states[nin:nin + nodes])
 
     def _post(self, outs):

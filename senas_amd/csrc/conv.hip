@@ -343,26 +343,37 @@ struct DwTab {
     double* stats[SENAS_MAX_DWMULTI];
 };
 
+// Two groups of problems may share a launch: problems [0, ka) have geometry ga (3x3 in the mixed launches), the rest gb
+// (5x5) -- dep_sep_conv_3 and dep_sep_conv_5 of the same edges differ in nothing but the kernel size (and its padding).
 template <bool TG>
-__global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom g, const float* __restrict__ in, DwTab tab, long total, int P) {
+__global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
+                                                               long total, int P) {
     const int p = blockIdx.y;
-    dwconv_body<TG, 4, false>(g, in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
+    dwconv_body<TG, 4, false>(p < ka ? ga : gb, in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
 }
 
-template <int KS, int S>
-__global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom g, const float* __restrict__ in, DwTab tab, long total, int P) {
+template <int KSA, int KSB, int S>
+__global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
+                                                                  long total, int P) {
     const int p = blockIdx.y;
-    dwconv_x4_body<KS, S>(g, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
+    if (KSA == KSB || p < ka) dwconv_x4_body<KSA, S>(ga, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
+    else dwconv_x4_body<KSB, S>(gb, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
 }
 
 // data gradient of the same: dx = sum over problems of the (transposed / plain) gather of dy_p with w_p, one pass
 template <bool TG>
-__global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom g, DwTab tab, int k, float* __restrict__ out, long total) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C]
-    const int taps = g.kh * g.kw, C = g.cout;
-    for (int i = threadIdx.x; i < k * taps * C; i += 256) {
-        const int p = i / (taps * C), r = i - p * taps * C, t = r / C, cc = r - t * C;
-        wl[i] = tab.w[p][cc * taps + t];
+__global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom ga, GatherGeom gb, int ka, DwTab tab, int k, float* __restrict__ out,
+                                                                 long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C], group a first
+    const int C = ga.cout, tapsa = ga.kh * ga.kw, tapsb = gb.kh * gb.kw;
+    const int na = ka * tapsa * C, nb = (k - ka) * tapsb * C;
+    for (int i = threadIdx.x; i < na; i += 256) {
+        const int p = i / (tapsa * C), r = i - p * tapsa * C, t = r / C, cc = r - t * C;
+        wl[i] = tab.w[p][cc * tapsa + t];
+    }
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int p = i / (tapsb * C), r = i - p * tapsb * C, t = r / C, cc = r - t * C;
+        wl[na + i] = tab.w[ka + p][cc * tapsb + t];
     }
     __syncthreads();
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -370,27 +381,33 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom g, D
     const int cv = C / 4;
     const int c = (int)(idx % cv) * 4;
     long pix = idx / cv;
-    const int ox = (int)(pix % g.wout);
-    pix /= g.wout;
-    const int oy = (int)(pix % g.hout), n = (int)(pix / g.hout);
+    const int ox = (int)(pix % ga.wout);
+    pix /= ga.wout;
+    const int oy = (int)(pix % ga.hout), n = (int)(pix / ga.hout);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int ky = 0; ky < g.kh; ++ky) {
-        int iy;
-        if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
-        for (int kx = 0; kx < g.kw; ++kx) {
-            int ix;
-            if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
-            const size_t off = ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
-            for (int p = 0; p < k; ++p) {
-                float v[4], wt[4];
-                ldv<4>(tab.a[p] + off, v);
-                ldv<4>(wl + ((size_t)p * taps + ky * g.kw + kx) * C + c, wt);
+    for (int grp = 0; grp < 2; ++grp) {
+        const GatherGeom& g = grp == 0 ? ga : gb;
+        const int p0 = grp == 0 ? 0 : ka, p1 = grp == 0 ? ka : k, taps = g.kh * g.kw;
+        const float* wg = wl + (grp == 0 ? 0 : na);
+        if (p0 == p1) continue;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            int iy;
+            if (!tap_src<TG>(g, oy, ky, g.hin, iy)) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                int ix;
+                if (!tap_src<TG>(g, ox, kx, g.win, ix)) continue;
+                const size_t off = ((size_t)(n * g.hin + iy) * g.win + ix) * g.cin + c;
+                for (int p = p0; p < p1; ++p) {
+                    float v[4], wt[4];
+                    ldv<4>(tab.a[p] + off, v);
+                    ldv<4>(wg + ((size_t)(p - p0) * taps + ky * g.kw + kx) * C + c, wt);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
+                }
             }
         }
     }
-    stv<4>(out + (((size_t)n * g.hout + oy) * g.wout + ox) * C + c, acc);
+    stv<4>(out + (((size_t)n * ga.hout + oy) * ga.wout + ox) * C + c, acc);
 }
 
 // depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
@@ -453,31 +470,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const fl
 // stage 2: dw[c][tap] = sum over blocks (fixed order: bitwise reproducible)
 // the same sum over problems as a 4-columns-per-thread PLAIN gather (dilation 1): the data gradient of k transposed
 // depthwise convolutions (gather over dy_p at the convolution's stride) or of k stride-1 ones (flip: kernels turned by 180 degrees)
+// the taps of problems [p0, p1) (KS x KS, weights at wl: [problem][tap][C]) added to the 4 x 4 outputs of this thread
 template <int KS, int S>
-__global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g, DwTab tab, int k, int flip, float* __restrict__ out, long total) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C]
+__device__ __forceinline__ void dw_dgrad_x4_accumulate(const GatherGeom& g, const DwTab& tab, int p0, int p1, const float* wl, int C, int c,
+                                                       int n, int oy, int ox0, float (&acc)[4][4]) {
     constexpr int TAPS = KS * KS, COLS = 3 * S + KS;
-    const int C = g.cout;
-    for (int i = threadIdx.x; i < k * TAPS * C; i += 256) {
-        const int p = i / (TAPS * C), r = i - p * TAPS * C, t = r / C, cc = r - t * C;
-        wl[i] = tab.w[p][cc * TAPS + (flip ? TAPS - 1 - t : t)];
-    }
-    __syncthreads();
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cv = C >> 2, wq = g.wout >> 2;
-    const int c = (int)(idx % cv) * 4;
-    long r = idx / cv;
-    const int ox0 = (int)(r % wq) * 4;
-    r /= wq;
-    const int oy = (int)(r % g.hout), n = (int)(r / g.hout);
-    float acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
     const int ix0 = ox0 * S - g.pad;
-    for (int p = 0; p < k; ++p) {
+    for (int p = p0; p < p1; ++p) {
         const float* __restrict__ in = tab.a[p];
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
@@ -492,7 +491,7 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g
             }
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
-                const float4 wt = *reinterpret_cast<const float4*>(wl + ((size_t)p * TAPS + ky * KS + kx) * C + c);
+                const float4 wt = *reinterpret_cast<const float4*>(wl + ((size_t)(p - p0) * TAPS + ky * KS + kx) * C + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 v = col[j * S + kx];
@@ -502,7 +501,40 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g
             }
         }
     }
-    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox0) * C + c;
+}
+
+template <int KSA, int KSB, int S>
+__global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom ga, GatherGeom gb, int ka, DwTab tab, int k, int flip,
+                                                                    float* __restrict__ out, long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C], group a first
+    constexpr int TA = KSA * KSA, TB = KSB * KSB;
+    const int C = ga.cout;
+    const int na = ka * TA * C, nb = (k - ka) * TB * C;
+    for (int i = threadIdx.x; i < na; i += 256) {
+        const int p = i / (TA * C), r = i - p * TA * C, t = r / C, cc = r - t * C;
+        wl[i] = tab.w[p][cc * TA + (flip ? TA - 1 - t : t)];
+    }
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int p = i / (TB * C), r = i - p * TB * C, t = r / C, cc = r - t * C;
+        wl[na + i] = tab.w[ka + p][cc * TB + (flip ? TB - 1 - t : t)];
+    }
+    __syncthreads();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C >> 2, wq = ga.wout >> 2;
+    const int c = (int)(idx % cv) * 4;
+    long r = idx / cv;
+    const int ox0 = (int)(r % wq) * 4;
+    r /= wq;
+    const int oy = (int)(r % ga.hout), n = (int)(r / ga.hout);
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
+    dw_dgrad_x4_accumulate<KSA, S>(ga, tab, 0, ka, wl, C, c, n, oy, ox0, acc);
+    if (k > ka) dw_dgrad_x4_accumulate<KSB, S>(gb, tab, ka, k, wl + na, C, c, n, oy, ox0, acc);
+    const size_t o = (((size_t)n * ga.hout + oy) * ga.wout + ox0) * C + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) stv<4>(out + o + (size_t)j * C, acc[j]);
 }
@@ -598,10 +630,11 @@ struct DwWgradTab {
     float* dw[SENAS_MAX_DWMULTI];
 };
 
-template <int KS>
-__global__ __launch_bounds__(256) void dwconv_wgrad_part_multi_kernel(WgradGeom g, DwWgradTab tab) {
+template <int KSA, int KSB>
+__global__ __launch_bounds__(256) void dwconv_wgrad_part_multi_kernel(WgradGeom ga, WgradGeom gb, int ka, DwWgradTab tab) {
     const int p = blockIdx.y;
-    dwconv_wgrad_part_body<KS>(g, tab.I[p], tab.G[p], tab.part[p], 0, 0);
+    if (KSA == KSB || p < ka) dwconv_wgrad_part_body<KSA>(ga, tab.I[p], tab.G[p], tab.part[p], 0, 0);
+    else dwconv_wgrad_part_body<KSB>(gb, tab.I[p], tab.G[p], tab.part[p], 0, 0);
 }
 
 // one wave per output element: lanes stride over the blocks' partials, fixed-order shuffle tree at the end
@@ -1085,13 +1118,28 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
 }
 
 // ---- k depthwise convolutions of one input (the same-named DepSepConv candidates of the edges leaving a state) ------------
+// ka problems of geometry ga followed by kb of geometry gb (gb may be NULL with kb == 0): the mixed launches run the 3x3
+// and the 5x5 candidates of the same edges together.
 namespace {
-bool dw_multi_ok(const senas_conv_geom* g, int k) {
-    if (!senas::geom_ok(g) || g->groups == 1 || k < 1 || k > SENAS_MAX_DWMULTI) return false;
+bool dw_geom_ok(const senas_conv_geom* g) {
+    if (!senas::geom_ok(g) || g->groups == 1) return false;
     const int c4 = g->ci / 4, taps = g->kh * g->kw;
     if (g->ci % 4 != 0 || (c4 & (c4 - 1)) != 0 || c4 > 64) return false;
     if (g->kh != g->kw || (g->kh != 3 && g->kh != 5)) return false;
-    return (size_t)k * taps * g->ci * sizeof(float) <= 60 * 1024 && (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 16 <= 64 * 1024;
+    return (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 16 <= 64 * 1024;
+}
+
+bool dw_pair_ok(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb) {
+    if (ka < 1 || kb < 0 || ka + kb > SENAS_MAX_DWMULTI || !dw_geom_ok(ga)) return false;
+    size_t wbytes = (size_t)ka * ga->kh * ga->kw * ga->ci * sizeof(float);
+    if (kb > 0) {
+        if (gb == nullptr || !dw_geom_ok(gb)) return false;
+        if (ga->n != gb->n || ga->hi != gb->hi || ga->wi != gb->wi || ga->ci != gb->ci || ga->ho != gb->ho || ga->wo != gb->wo ||
+            ga->co != gb->co || ga->stride != gb->stride || ga->transposed != gb->transposed || ga->groups != gb->groups) return false;
+        if (!(ga->kh == 3 && gb->kh == 5 && ga->dil == 1 && gb->dil == 1)) return false;     // the one mix there is: 3x3 then 5x5
+        wbytes += (size_t)kb * gb->kh * gb->kw * gb->ci * sizeof(float);
+    }
+    return wbytes <= 60 * 1024;
 }
 
 long dw_multi_wgrad_blocks(const senas_conv_geom* g, int* chunk) {
@@ -1102,110 +1150,150 @@ long dw_multi_wgrad_blocks(const senas_conv_geom* g, int* chunk) {
     *chunk = (int)((total + nblk - 1) / nblk);
     return (total + *chunk - 1) / *chunk;
 }
+
+senas::GatherGeom fwd_geom(const senas_conv_geom* g) {
+    return senas::GatherGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+}
+senas::GatherGeom bwd_geom(const senas_conv_geom* g) {
+    return senas::GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+}
+senas::WgradGeom wgrad_geom(const senas_conv_geom* g) {
+    return !g->transposed ? senas::WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
+                          : senas::WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+}
 }  // namespace
 
-extern "C" int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
-                                      double* const* stats, void* stream) {
+extern "C" int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                     const float* const* w, float* const* y, double* const* stats, void* stream) {
     using namespace senas;
-    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
-    SENAS_REQUIRE(x && w && y, "dwconv_multi_fwd: null pointer");
-    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!dw_pair_ok(ga, ka, gb, kb)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && w && y, "dwconv_pair_fwd: null pointer");
+    const int k = ka + kb;
+    const senas_conv_geom* g = ga;
+    const GatherGeom gga = fwd_geom(ga), ggb = kb > 0 ? fwd_geom(gb) : gga;
     DwTab tab{};
     bool want = stats != nullptr;
     for (int p = 0; p < k; ++p) {
-        SENAS_REQUIRE(w[p] && y[p], "dwconv_multi_fwd: null pointer");
+        SENAS_REQUIRE(w[p] && y[p], "dwconv_pair_fwd: null pointer");
         tab.w[p] = w[p]; tab.out[p] = y[p]; tab.stats[p] = want ? stats[p] : nullptr;
         want = want && tab.stats[p] != nullptr;
     }
-    const size_t lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
-    if (dw_x4_ok(gg, g->transposed)) {
+    const int kmax = kb > 0 ? gb->kh : ga->kh;
+    const size_t lds = (size_t)kmax * kmax * g->co * sizeof(float);
+    if (dw_x4_ok(gga, g->transposed) && dw_x4_ok(ggb, g->transposed)) {
         const long per_img4 = (long)g->ho * (g->wo / 4) * (g->co / 4), total4 = per_img4 * g->n;
         const int P4 = want ? stats_chunks_per_block(per_img4, g->co, total4) : 0;
         dim3 grid4((unsigned)((total4 + 256L * (P4 > 0 ? P4 : 1) - 1) / (256L * (P4 > 0 ? P4 : 1))), k);
-#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_multi_fwd_x4_kernel<KS_, S_>), grid4, dim3(256), lds, as_stream(stream), gg, x, tab, total4, P4)
-        if (g->kh == 3) { if (g->stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
-        else { if (g->stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#define SENAS_X4(KA_, KB_, S_) hipLaunchKernelGGL((dwconv_multi_fwd_x4_kernel<KA_, KB_, S_>), grid4, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, total4, P4)
+        if (kb > 0) { if (g->stride == 1) SENAS_X4(3, 5, 1); else SENAS_X4(3, 5, 2); }
+        else if (g->kh == 3) { if (g->stride == 1) SENAS_X4(3, 3, 1); else SENAS_X4(3, 3, 2); }
+        else { if (g->stride == 1) SENAS_X4(5, 5, 1); else SENAS_X4(5, 5, 2); }
 #undef SENAS_X4
-        return launch_status("dwconv_multi_fwd (x4)");
+        return launch_status("dwconv_pair_fwd (x4)");
     }
     const long per_img = (long)g->ho * g->wo * (g->co / 4);
     const long total = per_img * g->n;
     const int P = want ? stats_chunks_per_block(per_img, g->co, total) : 0;
     dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))), k);
-    if (g->transposed) hipLaunchKernelGGL((dwconv_multi_fwd_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
-    else hipLaunchKernelGGL((dwconv_multi_fwd_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, x, tab, total, P);
-    return launch_status("dwconv_multi_fwd");
+    if (g->transposed) hipLaunchKernelGGL((dwconv_multi_fwd_kernel<true>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, total, P);
+    else hipLaunchKernelGGL((dwconv_multi_fwd_kernel<false>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, total, P);
+    return launch_status("dwconv_pair_fwd");
 }
 
-extern "C" int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
-                                           void* stream) {
+extern "C" int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* const* dy,
+                                          const float* const* w, float* dx, void* stream) {
     using namespace senas;
-    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
-    SENAS_REQUIRE(dy && w && dx, "dwconv_multi_bwd_data: null pointer");
-    GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!dw_pair_ok(ga, ka, gb, kb)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(dy && w && dx, "dwconv_pair_bwd_data: null pointer");
+    const int k = ka + kb;
+    const senas_conv_geom* g = ga;
+    const GatherGeom gga = bwd_geom(ga), ggb = kb > 0 ? bwd_geom(gb) : gga;
     DwTab tab{};
     for (int p = 0; p < k; ++p) {
-        SENAS_REQUIRE(dy[p] && w[p], "dwconv_multi_bwd_data: null pointer");
+        SENAS_REQUIRE(dy[p] && w[p], "dwconv_pair_bwd_data: null pointer");
         tab.a[p] = dy[p]; tab.w[p] = w[p];
     }
-    const size_t lds = (size_t)k * g->kh * g->kw * g->ci * sizeof(float);
-    const bool flip = !g->transposed && g->stride == 1 && g->hi == g->ho && g->wi == g->wo && g->pad == g->dil * (g->kh / 2);
-    if ((g->transposed || flip) && dw_x4_ok(gg, 0)) {                  // a plain gather: four output columns per thread
+    const size_t lds = ((size_t)ka * ga->kh * ga->kw + (kb > 0 ? (size_t)kb * gb->kh * gb->kw : 0)) * g->ci * sizeof(float);
+    auto flips = [](const senas_conv_geom* q) {
+        return !q->transposed && q->stride == 1 && q->hi == q->ho && q->wi == q->wo && q->pad == q->dil * (q->kh / 2);
+    };
+    const bool flip = flips(ga) && (kb == 0 || flips(gb));
+    if ((g->transposed || flip) && dw_x4_ok(gga, 0) && dw_x4_ok(ggb, 0)) {                  // a plain gather: four output columns per thread
         const long total4 = (long)g->n * g->hi * (g->wi / 4) * (g->ci / 4);
         dim3 grid4((unsigned)((total4 + 255) / 256));
-#define SENAS_X4(KS_, S_) hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KS_, S_>), grid4, dim3(256), lds, as_stream(stream), gg, tab, k, flip ? 1 : 0, dx, total4)
-        if (g->kh == 3) { if (gg.stride == 1) SENAS_X4(3, 1); else SENAS_X4(3, 2); }
-        else { if (gg.stride == 1) SENAS_X4(5, 1); else SENAS_X4(5, 2); }
+#define SENAS_X4(KA_, KB_, S_) hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KA_, KB_, S_>), grid4, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, flip ? 1 : 0, dx, total4)
+        if (kb > 0) { if (gga.stride == 1) SENAS_X4(3, 5, 1); else SENAS_X4(3, 5, 2); }
+        else if (g->kh == 3) { if (gga.stride == 1) SENAS_X4(3, 3, 1); else SENAS_X4(3, 3, 2); }
+        else { if (gga.stride == 1) SENAS_X4(5, 5, 1); else SENAS_X4(5, 5, 2); }
 #undef SENAS_X4
-        return launch_status("dwconv_multi_bwd_data (x4)");
+        return launch_status("dwconv_pair_bwd_data (x4)");
     }
     const long total = (long)g->n * g->hi * g->wi * (g->ci / 4);
     dim3 grid((unsigned)((total + 255) / 256));
-    if (!g->transposed) hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<true>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);
-    else hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<false>), grid, dim3(256), lds, as_stream(stream), gg, tab, k, dx, total);
-    return launch_status("dwconv_multi_bwd_data");
+    if (!g->transposed) hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<true>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, dx, total);
+    else hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<false>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, dx, total);
+    return launch_status("dwconv_pair_bwd_data");
 }
 
-extern "C" int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k) {
-    if (!dw_multi_ok(g, k)) return 0;
+extern "C" int64_t senas_dwconv_pair_ws_bytes(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb) {
+    if (!dw_pair_ok(ga, ka, gb, kb)) return 0;
     int chunk;
-    return (int64_t)k * dw_multi_wgrad_blocks(g, &chunk) * g->ci * g->kh * g->kw * sizeof(float) + 256;
+    const int64_t nblk = dw_multi_wgrad_blocks(ga, &chunk);
+    return nblk * ga->ci * ((int64_t)ka * ga->kh * ga->kw + (kb > 0 ? (int64_t)kb * gb->kh * gb->kw : 0)) * sizeof(float) + 256;
 }
 
-extern "C" int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
-                                             void* ws, void* stream) {
-    return senas_dwconv_multi_bwd_weight_deferred(g, k, x, dy, dw, ws, nullptr, stream);
-}
-
-extern "C" int senas_dwconv_multi_bwd_weight_deferred(const senas_conv_geom* g, int k, const float* x, const float* const* dy,
-                                                      float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
+extern "C" int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                            const float* const* dy, float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
     using namespace senas;
-    if (!dw_multi_ok(g, k)) return SENAS_EUNSUPPORTED;
-    SENAS_REQUIRE(x && dy && dw && ws, "dwconv_multi_bwd_weight: null pointer");
-    const int taps = g->kh * g->kw, c4 = g->ci / 4;
-    WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
-                                  : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (!dw_pair_ok(ga, ka, gb, kb)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && dy && dw && ws, "dwconv_pair_bwd_weight: null pointer");
+    const int k = ka + kb, c4 = ga->ci / 4;
+    WgradGeom wga = wgrad_geom(ga), wgb = kb > 0 ? wgrad_geom(gb) : wga;
     int chunk;
-    const long nblk = dw_multi_wgrad_blocks(g, &chunk);
-    wg.chunk = chunk;
+    const long nblk = dw_multi_wgrad_blocks(ga, &chunk);
+    wga.chunk = wgb.chunk = chunk;
     DwWgradTab tab{};
-    const size_t per = (size_t)nblk * g->ci * taps;
+    int n_elem[SENAS_MAX_DWMULTI];
+    float* part = reinterpret_cast<float*>(ws);
     for (int p = 0; p < k; ++p) {
-        SENAS_REQUIRE(dy[p] && dw[p], "dwconv_multi_bwd_weight: null pointer");
+        const senas_conv_geom* g = p < ka ? ga : gb;
+        SENAS_REQUIRE(dy[p] && dw[p], "dwconv_pair_bwd_weight: null pointer");
         tab.I[p] = g->transposed ? dy[p] : x;              // fine-grid operand
         tab.G[p] = g->transposed ? x : dy[p];              // coarse-grid operand
-        tab.part[p] = reinterpret_cast<float*>(ws) + (size_t)p * per;
+        tab.part[p] = part;
         tab.dw[p] = dw[p];
+        n_elem[p] = g->ci * g->kh * g->kw;
+        part += (size_t)nblk * n_elem[p];
     }
     hipStream_t st = as_stream(stream);
-    const size_t lds = (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 4 * sizeof(float);
-    if (g->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<3>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
-    else hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<5>), dim3((unsigned)nblk, k), dim3(256), lds, st, wg, tab);
-    const int n_elem = g->ci * taps;
-    if (defer != nullptr) {
-        for (int p = 0; p < k; ++p) defer[p] = senas_sum_item{tab.part[p], tab.dw[p], 1, 0, 0, 0, n_elem, (int)nblk};
-        return launch_status("dwconv_multi_bwd_weight");
+    const int tmax = kb > 0 ? gb->kh * gb->kw : ga->kh * ga->kw;
+    const size_t lds = (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * tmax * 4 * sizeof(float);
+    dim3 grid((unsigned)nblk, k);
+    if (kb > 0) hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<3, 5>), grid, dim3(256), lds, st, wga, wgb, ka, tab);
+    else if (ga->kh == 3) hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<3, 3>), grid, dim3(256), lds, st, wga, wgb, ka, tab);
+    else hipLaunchKernelGGL((dwconv_wgrad_part_multi_kernel<5, 5>), grid, dim3(256), lds, st, wga, wgb, ka, tab);
+    for (int p = 0; p < k; ++p) {
+        if (defer != nullptr) defer[p] = senas_sum_item{tab.part[p], tab.dw[p], 1, 0, 0, 0, n_elem[p], (int)nblk};
+        else hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem[p] + 3) / 4), dim3(256), 0, st, tab.part[p], tab.dw[p], n_elem[p], (int)nblk);
     }
-    hipLaunchKernelGGL(dwconv_wgrad_sum_multi_kernel, dim3((n_elem + 3) / 4, k), dim3(256), 0, st, tab, n_elem, (int)nblk);
-    return launch_status("dwconv_multi_bwd_weight");
+    return launch_status("dwconv_pair_bwd_weight");
+}
+
+// the single-geometry forms (include/senas_hip.h)
+extern "C" int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
+                                      double* const* stats, void* stream) {
+    return senas_dwconv_pair_fwd(g, k, nullptr, 0, x, w, y, stats, stream);
+}
+extern "C" int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
+                                           void* stream) {
+    return senas_dwconv_pair_bwd_data(g, k, nullptr, 0, dy, w, dx, stream);
+}
+extern "C" int64_t senas_dwconv_multi_ws_bytes(const senas_conv_geom* g, int k) { return senas_dwconv_pair_ws_bytes(g, k, nullptr, 0); }
+extern "C" int senas_dwconv_multi_bwd_weight(const senas_conv_geom* g, int k, const float* x, const float* const* dy, float* const* dw,
+                                             void* ws, void* stream) {
+    return senas_dwconv_pair_bwd_weight(g, k, nullptr, 0, x, dy, dw, ws, nullptr, stream);
+}
+extern "C" int senas_dwconv_multi_bwd_weight_deferred(const senas_conv_geom* g, int k, const float* x, const float* const* dy,
+                                                      float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
+    return senas_dwconv_pair_bwd_weight(g, k, nullptr, 0, x, dy, dw, ws, defer, stream);
 }

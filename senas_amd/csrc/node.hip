@@ -171,8 +171,13 @@ static size_t prepare_fwd_lds(const NodeDesc& d) {
 template <int V>
 __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n, const ZTable& z, const float* lds,
                                                const float* bias, const float* __restrict__ residual, int relu,
-                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
+                                               float* __restrict__ y, uint8_t* __restrict__ mask8, double* __restrict__ out_stats) {
+    // out_stats (V == 4 only): per-image channel sums of y itself, for the BatchNorm2d of an 'identity' candidate that
+    // reads this node (search cell inner edges, utils/operations.py:167-183 without a 1x1 adapter) -- saves its own pass
+    Stats4 ost;
+    stats_init4(ost);
     const int cv = c / V;
+    int ch_thr = (int)(threadIdx.x % cv) * V;            // (every element of this thread has that channel: 256 % cv == 0)
     const long per_img = hw * cv;
     const size_t img_off = (size_t)n * hw * c;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
@@ -201,7 +206,12 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
         stv<V>(y + off, acc);
+        if constexpr (V == 4) {
+            ch_thr = ch;
+            stats_accumulate4(ost, out_stats, true, n, c, ch, acc, true);
+        }
     }
+    if constexpr (V == 4) stats_flush4(ost, out_stats, true, n, c, ch_thr);
 }
 
 // ------------------------------------------------------------------------------------------ forward combine
@@ -210,7 +220,8 @@ template <int V>
 __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, int nterms, int nimg, ZTable z,
                                                                const float* __restrict__ coef, const float* __restrict__ shiftc,
                                                                const float* __restrict__ residual, int relu,
-                                                               float* __restrict__ y, uint8_t* __restrict__ mask8) {
+                                                               float* __restrict__ y, uint8_t* __restrict__ mask8,
+                                                               double* __restrict__ out_stats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
     const int n = blockIdx.y;
     float* bias = lds + nterms * c;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
         bias[ch] = b;
     }
     __syncthreads();
-    combine_stream<V>(hw, c, nterms, n, z, lds, bias, residual, relu, y, mask8);
+    combine_stream<V>(hw, c, nterms, n, z, lds, bias, residual, relu, y, mask8, out_stats);
 }
 
 // ------------------------------------------------------------------------------------------ forward, fused
@@ -239,7 +250,8 @@ template <int V>
 __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable z, const float* __restrict__ residual,
                                                              float* __restrict__ y, uint8_t* __restrict__ mask8,
                                                              float* __restrict__ coefs, float* __restrict__ gate,
-                                                             float* __restrict__ se_m, float* __restrict__ se_a1) {
+                                                             float* __restrict__ se_m, float* __restrict__ se_a1,
+                                                             double* __restrict__ out_stats) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int n = blockIdx.y, nimg = d.n, c = d.c, T = d.nterms;
     const bool first = blockIdx.x == 0, writer0 = first && n == 0;
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
     }
     if (owner) bias[ch] = bsum;
     __syncthreads();
-    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8);
+    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8, out_stats);
 }
 
 static size_t fused_fwd_lds(const NodeDesc& d) {
@@ -856,7 +868,7 @@ static bool fill_ztable(const NodeDesc& d, const float* const* z, const int32_t*
 
 extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                               float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1,
-                              uint8_t* mask8, void* stream) {
+                              uint8_t* mask8, double* out_stats, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_fwd: bad descriptor");
     SENAS_REQUIRE(z && y && coefs && gate && coef && shiftc, "node_fwd: null pointer");
@@ -868,12 +880,16 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
         SENAS_REQUIRE(!(d.training && z[t] && !d.stats[t]), "node_fwd: training-mode term without statistics");
     }
     SENAS_REQUIRE(!any_se || (se_m && se_a1), "node_fwd: SE scratch missing");
+    {
+        const int cq = d.c / 4;
+        SENAS_REQUIRE(out_stats == nullptr || (d.c % 4 == 0 && (cq & (cq - 1)) == 0 && cq <= 64), "node_fwd: output statistics need c = 4 * 2^k <= 256");
+    }
     hipStream_t st = as_stream(stream);
     if (d.nterms <= kFuseTerms && fused_fwd_lds(d) <= 48 * 1024) {          // one launch: prologue + stream
         const int V = (d.c % 4 == 0) ? 4 : 1;
         dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
-        if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1);
-        else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1);
+        if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats);
+        else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr);
         return launch_status("node_fwd (fused)");
     }
     const size_t lds1 = prepare_fwd_lds(d);
@@ -882,8 +898,8 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     const int V = (d.c % 4 == 0) ? 4 : 1;
     dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
     const size_t lds2 = ((size_t)d.nterms * d.c + d.c) * sizeof(float);
-    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr);
-    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr);
+    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr, out_stats);
+    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr, (double*)nullptr);
     return launch_status("node_fwd");
 }
 

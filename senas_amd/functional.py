@@ -521,27 +521,36 @@ class _FanOut(torch.autograd.Function):
 
 
 def fan_out(x, n):
-    """n aliases of x (n > 1), or [x]."""
-    return list(_FanOut.apply(x, n)) if n > 1 else [x]
+    """n aliases of x (n > 1), or [x]; producer-side statistics riding on x (``_senas_stats``) ride on the aliases too."""
+    if n <= 1:
+        return [x]
+    out = list(_FanOut.apply(x, n))
+    st = getattr(x, '_senas_stats', None)
+    if st is not None:
+        for a in out:
+            a._senas_stats = st
+    return out
 
 
 class _DwMulti(torch.autograd.Function):
-    """k depthwise convolutions of ONE input (senas_dwconv_multi_*): outputs z_1..z_k (+ their statistics); the backward
-    pass produces dx = sum_p dgrad_p in one launch and the k weight gradients in two."""
+    """k depthwise convolutions of ONE input (senas_dwconv_pair_*): ka of geometry ga followed by kb of geometry gb (the 3x3
+    and the 5x5 DepSepConv candidates of the same edges; kb may be 0).  Outputs z_1..z_k (+ their statistics); the
+    backward pass produces dx = sum_p dgrad_p in one launch and the k weight gradients in one (+ their deferred sums)."""
 
     @staticmethod
-    def forward(ctx, x, geom, want_stats, *ws):
-        k = len(ws)
+    def forward(ctx, x, ga, ka, gb, kb, want_stats, *ws):
+        k = ka + kb
         x = nhwc(x)
         ws = [_dev(w).contiguous() for w in ws]
-        g = geom
+        g = ga
         ys = [new_nhwc(g.n, g.co, g.ho, g.wo, x) for _ in range(k)]
         stats = [new_stats(g.n, g.co, x) for _ in range(k)] if want_stats else []
         wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
         yp = (C.c_void_p * k)(*[y.data_ptr() for y in ys])
         sp = (C.c_void_p * k)(*[s.data_ptr() for s in stats]) if want_stats else None
-        _lib.check(_lib.lib().senas_dwconv_multi_fwd(C.byref(g), k, x.data_ptr(), wp, yp, sp, _stream()), 'senas_dwconv_multi_fwd')
-        ctx.g, ctx.k = g, k
+        gbp = C.byref(gb) if kb else None
+        _lib.check(_lib.lib().senas_dwconv_pair_fwd(C.byref(ga), ka, gbp, kb, x.data_ptr(), wp, yp, sp, _stream()), 'senas_dwconv_pair_fwd')
+        ctx.geoms, ctx.k = (ga, ka, gb, kb), k
         ctx.save_for_backward(x, *ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*stats)
@@ -549,58 +558,75 @@ class _DwMulti(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        g, k, L = ctx.g, ctx.k, _lib.lib()
+        (ga, ka, gb, kb), k, L = ctx.geoms, ctx.k, _lib.lib()
+        g = ga
+        gbp = C.byref(gb) if kb else None
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         dys = list(grads[:k])
         if all(d is None for d in dys):
-            return (None,) * (3 + k)
+            return (None,) * (6 + k)
         dys = [nhwc(d) if d is not None else torch.zeros((g.n, g.co, g.ho, g.wo), device=x.device).contiguous(memory_format=CL) for d in dys]
         dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
             wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
-            _lib.check(L.senas_dwconv_multi_bwd_data(C.byref(g), k, dyp, wp, dx.data_ptr(), _stream()), 'senas_dwconv_multi_bwd_data')
+            _lib.check(L.senas_dwconv_pair_bwd_data(C.byref(ga), ka, gbp, kb, dyp, wp, dx.data_ptr(), _stream()), 'senas_dwconv_pair_bwd_data')
         dws = [None] * k
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[6:]):
             dwt, dws = zip(*[wgrad_dest(w) for w in ws])
-            scratch = torch.empty(int(L.senas_dwconv_multi_ws_bytes(C.byref(g), k)), device=x.device, dtype=torch.uint8)
+            scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=x.device, dtype=torch.uint8)
             dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            if DEFER is not None:
-                items = (_lib.SumItem * k)()
-                _lib.check(L.senas_dwconv_multi_bwd_weight_deferred(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
-                           'senas_dwconv_multi_bwd_weight_deferred')
+            items = (_lib.SumItem * k)() if DEFER is not None else None
+            _lib.check(L.senas_dwconv_pair_bwd_weight(C.byref(ga), ka, gbp, kb, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
+                       'senas_dwconv_pair_bwd_weight')
+            if items is not None:
                 for t in range(k):
                     one = _lib.SumItem()
                     C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
                     DEFER.append((one, scratch))
-            else:
-                _lib.check(L.senas_dwconv_multi_bwd_weight(C.byref(g), k, x.data_ptr(), dyp, dwp, scratch.data_ptr(), _stream()),
-                           'senas_dwconv_multi_bwd_weight')
-        return (dx, None, None) + tuple(dws)
+        return (dx, None, None, None, None, None) + tuple(dws)
 
 
-def dwconv_multi(x, convs, want_stats):
-    """[(z_p, stats_p)] of k same-geometry depthwise convolutions of one tensor, or None when the shape is off the
-    batched path (the caller then runs them one by one)."""
-    k = len(convs)
-    c0 = convs[0]
-    if not 2 <= k <= _lib.MAX_DWMULTI or c0.groups != c0.in_channels or c0.in_channels != c0.out_channels:
-        return None
+def _dw_geom(x, c0):
     tr = isinstance(c0, torch.nn.ConvTranspose2d)
-    for c in convs[1:]:
-        if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride, c0.padding,
-                                                                                 c0.dilation, c0.groups):
-            return None
     n, ci, hi, wi = x.shape
     kk, s, p, d = c0.kernel_size[0], c0.stride[0], c0.padding[0], c0.dilation[0]
     op = c0.output_padding[0] if tr else 0
     ho, wo = conv_out_size(hi, kk, s, p, d, tr, op), conv_out_size(wi, kk, s, p, d, tr, op)
-    g = ConvGeom(n, hi, wi, ci, ho, wo, ci, kk, kk, s, p, d, int(tr), ci)
-    if _lib.lib().senas_dwconv_multi_ws_bytes(C.byref(g), k) == 0:
+    return ConvGeom(n, hi, wi, ci, ho, wo, ci, kk, kk, s, p, d, int(tr), ci)
+
+
+def dwconv_multi(x, convs, want_stats):
+    """[(z_p, stats_p)] (in the order of ``convs``) of k depthwise convolutions of one tensor that agree in everything but --
+    at most two -- kernel sizes, or None when the shape is off the batched path (the caller then runs them one by one)."""
+    k = len(convs)
+    if not 2 <= k <= _lib.MAX_DWMULTI:
         return None
-    out = _DwMulti.apply(x, g, bool(want_stats), *[c.weight for c in convs])
-    return [(out[i], out[k + i] if want_stats else None) for i in range(k)]
+    sizes = sorted(set(c.kernel_size[0] for c in convs))
+    if len(sizes) > 2 or (len(sizes) == 2 and sizes != [3, 5]):
+        return None
+    order = sorted(range(k), key=lambda i: convs[i].kernel_size[0])             # 3x3 problems first
+    groups = [[i for i in order if convs[i].kernel_size[0] == sz] for sz in sizes]
+    for grp in groups:
+        c0 = convs[grp[0]]
+        if c0.groups != c0.in_channels or c0.in_channels != c0.out_channels or c0.in_channels != x.shape[1]:
+            return None
+        for i in grp[1:]:
+            c = convs[i]
+            if (type(c), c.weight.shape, c.stride, c.padding, c.dilation, c.groups) != (type(c0), c0.weight.shape, c0.stride, c0.padding,
+                                                                                     c0.dilation, c0.groups):
+                return None
+    ga = _dw_geom(x, convs[groups[0][0]])
+    gb = _dw_geom(x, convs[groups[1][0]]) if len(groups) == 2 else None
+    ka, kb = len(groups[0]), len(groups[1]) if gb is not None else 0
+    if _lib.lib().senas_dwconv_pair_ws_bytes(C.byref(ga), ka, C.byref(gb) if kb else None, kb) == 0:
+        return None
+    out = _DwMulti.apply(x, ga, ka, gb, kb, bool(want_stats), *[convs[i].weight for i in order])
+    res = [None] * k
+    for pos, i in enumerate(order):
+        res[i] = (out[pos], out[k + pos] if want_stats else None)
+    return res
 
 
 class _PwMulti(torch.autograd.Function):
@@ -1110,7 +1136,7 @@ class Term(object):
         self.grad_slot = grad_slot
 
 
-def bn_combine(terms, mix=None, residual=None, relu=False):
+def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False):
     """See senas_amd.node.bn_combine (the fused cell node)."""
     from .node import bn_combine as _impl
-    return _impl(terms, mix=mix, residual=residual, relu=relu)
+    return _impl(terms, mix=mix, residual=residual, relu=relu, out_stats=out_stats)

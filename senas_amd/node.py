@@ -96,7 +96,7 @@ class _Node(torch.autograd.Function):
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         _lib.check(L.senas_node_fwd(C.byref(d), zp, zstrides, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
                                     scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._p(mask8),
-                                    F._stream()),
+                                    F._p(meta.get('out_stats')), F._stream()),
                    'senas_node_fwd')
         ctx.meta = meta
         ctx.has_mix, ctx.has_res, ctx.nflat = mix is not None, residual is not None, len(flat)
@@ -186,10 +186,11 @@ class _Node(torch.autograd.Function):
         return (None, dmix, ds_out) + tuple(grads)
 
 
-def bn_combine(terms, mix=None, residual=None, relu=False):
+def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False):
     """Normalise every term with its own BatchNorm2d (train or eval mode as the module says), apply
     SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
-    and optionally ReLU -- one read of every term, one write."""
+    and optionally ReLU -- one read of every term, one write.  ``out_stats``: also leave the per-image channel
+    sums of the result on it (``y._senas_stats``), for a consumer that batch-normalises it directly."""
     T = len(terms)
     if T == 0 or T > _lib.MAX_TERMS:
         raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))
@@ -218,4 +219,10 @@ def bn_combine(terms, mix=None, residual=None, relu=False):
     flat += [tm.bn.weight for tm in terms] + [tm.bn.bias for tm in terms]
     flat += [terms[t].se.excitation[0].weight for t in se_ids] + [terms[t].se.excitation[2].weight for t in se_ids]
     flat += passengers
-    return _Node.apply(meta, mix, residual, *flat)
+    c = ref.shape[1]
+    if out_stats and c % 4 == 0 and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
+        meta['out_stats'] = F.new_stats(ref.shape[0], c, ref)
+    y = _Node.apply(meta, mix, residual, *flat)
+    if meta.get('out_stats') is not None:
+        y._senas_stats = meta['out_stats']
+    return y

@@ -174,7 +174,8 @@ class AdapterBlock(nn.Module):
         """y, or (y, stats-or-None) with want_stats (the resampling kernels produce the next norm's statistics)."""
         m = self.module
         if isinstance(m, nn.Identity):
-            return (x, None) if want_stats else x
+            # (a search-cell node leaves its own channel sums on its output: node.bn_combine(out_stats=True))
+            return (x, getattr(x, '_senas_stats', None)) if want_stats else x
         if isinstance(m, nn.AvgPool2d):
             if (m.kernel_size, m.padding, m.count_include_pad) != (3, 1, False):
                 raise NotImplementedError('only AvgPool2d(3, s, 1, count_include_pad=False) is on the path')

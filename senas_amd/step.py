@@ -56,8 +56,11 @@ class GraphedForwardBackward(object):
     the rest of backward."""
 
     def __init__(self, model, criterion, x, y, reducer, warmup=2, use_graph=True, packer=None, frozen=(), early=None,
-                 count_nodes=False):
+                 count_nodes=False, refresh=True):
         self.model, self.criterion, self.reducer = model, criterion, reducer
+        # refresh=False: the caller guarantees that the packed / stacked weight images are current when the pass starts
+        # (the weight pass of a search step right after the architecture pass: the weights have not moved in between)
+        self.refresh = refresh
         self.count_nodes, self.nodes = count_nodes, None
         self.x, self.y = x, y                      # static buffers; refill with .copy_() between steps
         self.loss = None
@@ -78,7 +81,8 @@ class GraphedForwardBackward(object):
     def _head(self):
         """zero_grad, forward, loss and -- without a cut -- all of backward; with a cut, backward down to the cut."""
         self.reducer.zero_grad()
-        self.packer.refresh()
+        if self.refresh:
+            self.packer.refresh()
         for p in self.frozen:
             p.requires_grad_(False)
         cut = self.early is not None
@@ -167,7 +171,8 @@ class GraphedForwardBackward(object):
             self.loss = self._eager()
         else:
             self.graph.replay()
-            self.packer.mark_refreshed()           # the replay starts with the packer's refresh launches
+            if self.refresh:
+                self.packer.mark_refreshed()       # the replay starts with the packer's refresh launches
             if self.graph_tail is not None:
                 self._launch_early()
                 self.graph_tail.replay()
@@ -235,8 +240,11 @@ class SearchStep(object):
         early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and last >= 2) else None
         self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, packer=packer,
                                               frozen=weights, count_nodes=count_nodes)
+        # the weight pass does not repack: either the architecture pass just did, or __call__ does it (before alpha_begin)
+        packer.refresh()
+        self.packer = packer
         self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph, packer=packer, early=early,
-                                         count_nodes=count_nodes and early is None)
+                                         count_nodes=count_nodes and early is None, refresh=False)
         self.graphed = self.fb.graph is not None
         # static gradient addresses -> clip + SGD in two launches instead of ~110
         self.fused = optim.FusedClipSGD(weight_optimizer, grad_clip) if optim.supported(weight_optimizer) else None
@@ -258,6 +266,8 @@ class SearchStep(object):
             self.fb_arch()
             self.fb_arch.finish()
             self.opt_a.step()
+        elif self.packer.stale():                  # no architecture pass in front (before alpha_begin): repack here
+            self.packer.refresh()
         fb.x.copy_(x_train, non_blocking=True)
         fb.y.copy_(y_train, non_blocking=True)
         loss = fb()

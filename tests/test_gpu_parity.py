@@ -1303,16 +1303,24 @@ def test_bnrelu_multi_vs_torch(case):
 
 
 @pytest.mark.parametrize('case', [(3, 2, 32, 16, 20, 5, 1, False), (2, 2, 32, 16, 16, 3, 2, False), (3, 2, 32, 8, 12, 5, 2, True),
-                                  (4, 1, 8, 12, 12, 3, 1, False), (2, 4, 16, 9, 11, 5, 1, False), (3, 2, 32, 12, 12, 3, 2, True)])
+                                  (4, 1, 8, 12, 12, 3, 1, False), (2, 4, 16, 9, 11, 5, 1, False), (3, 2, 32, 12, 12, 3, 2, True),
+                                  # kernel size 0: dep_sep_conv_3 and dep_sep_conv_5 of the same edges share the launches (3, 5, 3, 5, ...)
+                                  (6, 4, 32, 16, 16, 0, 1, False), (6, 2, 32, 16, 24, 0, 2, False), (6, 2, 32, 8, 12, 0, 2, True),
+                                  (2, 2, 8, 12, 12, 0, 1, False), (4, 3, 8, 9, 11, 0, 1, False), (8, 1, 16, 8, 8, 0, 2, True)])
 def test_dwconv_multi_vs_single(case):
-    """senas_dwconv_multi_* (k depthwise convolutions of one input: one forward launch, one data-gradient launch summing
-    over the problems, two weight-gradient launches) against the same convolutions run one by one through torch (float64)."""
+    """senas_dwconv_pair_* (k depthwise convolutions of one input, 3x3 and 5x5 mixed: one forward launch, one data-gradient
+    launch summing over the problems, one weight-gradient launch + sums) against the same convolutions run one by one
+    through torch (float64)."""
     from senas_amd import functional as F
-    k, n, c, h, w, ks, stride, tr = case
+    k, n, c, h, w, ks0, stride, tr = case
     gen = torch.Generator().manual_seed(sum(case[:7]))
-    mk = (lambda: nn.ConvTranspose2d(c, c, ks, stride=stride, padding=ks // 2, output_padding=stride - 1, groups=c, bias=False)) if tr else \
-         (lambda: nn.Conv2d(c, c, ks, stride=stride, padding=ks // 2, groups=c, bias=False))
-    convs = [mk() for _ in range(k)]
+
+    def mk(t):
+        ks = ks0 if ks0 else (3, 5)[t % 2]
+        if tr:
+            return nn.ConvTranspose2d(c, c, ks, stride=stride, padding=ks // 2, output_padding=stride - 1, groups=c, bias=False)
+        return nn.Conv2d(c, c, ks, stride=stride, padding=ks // 2, groups=c, bias=False)
+    convs = [mk(t) for t in range(k)]
     for cv in convs:
         with torch.no_grad():
             cv.weight.copy_(torch.randn(cv.weight.shape, generator=gen) * 0.3)

@@ -391,6 +391,11 @@ int senas_node_bwd(const senas_node_desc* desc, const float* const* z, const int
 /* out = sum of n dense fp32 tensors of numel elements (n <= SENAS_MAX_TERMS, 16-byte aligned): the gradient of a
  * tensor with n consumers (a cell state feeding several edges) in one pass instead of n-1 binary accumulations.  */
 int senas_sum_n(int n, int64_t numel, const float* const* srcs, float* out, void* stream);
+/* The same for NHWC tensors [npix][c] whose sources may be channel slices of wider tensors: src_pixel_stride[k] floats
+ * between consecutive pixels of source k (>= c, multiple of 4) -- the gradient that torch.cat along channels hands one of
+ * its inputs (models/senas_model.py:64, search/cell.py:110 concatenate the node outputs) is read in place.            */
+int senas_sum_n_strided(int n, int64_t npix, int c, const float* const* srcs, const int32_t* src_pixel_stride, float* out,
+                        void* stream);
 
 /* ---- loss and metric ------------------------------------------------
  * DiceCrossEntropyLoss (utils/loss/loss.py:45-70,124-228): w_ce * CrossEntropy(mean over pixels) +

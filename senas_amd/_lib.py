@@ -122,6 +122,7 @@ SIGNATURES = {
     'senas_combine_bwd_reduce': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P]),
     'senas_combine_bwd_apply': (_I, [_I, _L, _I, _I, _PP, _P, _P, _I, _P, _P, _P, _PP, _P, _P]),
     'senas_sum_n': (_I, [_I, _L, _PP, _P, _P]),
+    'senas_sum_n_strided': (_I, [_I, _L, _I, _PP, _P, _P, _P]),
     'senas_dice_ce_fwd': (_I, [_L, _I, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P]),
     'senas_dice_ce_bwd': (_I, [_L, _I, _P, _P, _P, _P, _P, _P]),
     'senas_seg_metric_update': (_I, [_I, _L, _I, _P, _P, _F, _P, _P, _P, _P]),

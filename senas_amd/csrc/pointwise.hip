@@ -253,6 +253,25 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumTable t, int n, long n4, 
     }
 }
 
+// the same with sources that are channel slices of wider NHWC tensors (pixel stride s_k floats >= c): the gradient of a
+// tensor one of whose consumers is a torch.cat along channels arrives as such a slice
+struct SumTableS {
+    const float* p[SENAS_MAX_TERMS];
+    int s4[SENAS_MAX_TERMS];            // pixel stride in 16-byte pieces
+};
+__global__ __launch_bounds__(256) void sum_n_strided_kernel(SumTableS t, int n, long total4, int cq, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long pix = i / cq;
+        const int q = (int)(i - pix * cq);
+        float4 a = reinterpret_cast<const float4*>(t.p[0])[pix * t.s4[0] + q];
+        for (int k = 1; k < n; ++k) {
+            const float4 b = reinterpret_cast<const float4*>(t.p[k])[pix * t.s4[k] + q];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
+}
+
 // ---- gamma-gated blend of two skip candidates (search/senas_search.py:98-102): y = g[0] * x1 + g[1] * x2, g on the device
 __global__ __launch_bounds__(256) void blend2_fwd_kernel(const float4* __restrict__ x1, const float4* __restrict__ x2,
                                                          const float* __restrict__ g, float4* __restrict__ y, long n4) {
@@ -402,6 +421,24 @@ extern "C" int senas_combine_bwd_apply(int n, int64_t hw, int c, int nterms, con
     if (V == 4) hipLaunchKernelGGL((combine_bwd_apply_kernel<4>), grid, dim3(256), 0, as_stream(stream), (long)hw, c, nterms, n, tab, dy, y, relu, a, b, k, out, ds_out);
     else hipLaunchKernelGGL((combine_bwd_apply_kernel<1>), grid, dim3(256), 0, as_stream(stream), (long)hw, c, nterms, n, tab, dy, y, relu, a, b, k, out, ds_out);
     return launch_status("combine_bwd_apply");
+}
+
+extern "C" int senas_sum_n_strided(int n, int64_t npix, int c, const float* const* srcs, const int32_t* src_pixel_stride, float* out,
+                                   void* stream) {
+    SENAS_REQUIRE(n >= 1 && n <= SENAS_MAX_TERMS && npix > 0 && c >= 4 && c % 4 == 0 && srcs && src_pixel_stride && out, "sum_n_strided: bad argument");
+    senas::SumTableS t{};
+    for (int k = 0; k < n; ++k) {
+        SENAS_REQUIRE(srcs[k] && (reinterpret_cast<uintptr_t>(srcs[k]) & 15) == 0 && src_pixel_stride[k] >= c && src_pixel_stride[k] % 4 == 0,
+                      "sum_n_strided: null, misaligned or too narrow source");
+        t.p[k] = srcs[k];
+        t.s4[k] = src_pixel_stride[k] / 4;
+    }
+    SENAS_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "sum_n_strided: misaligned destination");
+    const long total4 = (long)npix * (c / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(senas::sum_n_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, senas::as_stream(stream), t, n, total4, c / 4, out);
+    return senas::launch_status("sum_n_strided");
 }
 
 extern "C" int senas_sum_n(int n, int64_t numel, const float* const* srcs, float* out, void* stream) {

@@ -454,6 +454,63 @@ def blend2(x1, x2, g):
     return _Blend2.apply(x1, x2, g)
 
 
+class _GammaRows(torch.autograd.Function):
+    """softmax(gamma) as a table whose rows the skip blends of one forward pass read in place; they ADD their d loss / d row
+    into one fp64 buffer (senas_blend2_bwd accumulates), which this backward hands on once -- instead of a select, a
+    zero-fill, a copy, a cast and an add per blend."""
+
+    @staticmethod
+    def forward(ctx, table, acc):
+        ctx.save_for_backward(acc)
+        ctx.set_materialize_grads(False)
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        (acc,) = ctx.saved_tensors
+        d = acc.float()
+        return (d if g is None else d + g), None
+
+
+class GammaRows(object):
+    def __init__(self, table):
+        t = _dev(table).contiguous()
+        self.acc = zeros64(tuple(t.shape), t.device)
+        self.table = _GammaRows.apply(t, self.acc)
+
+
+class _Blend2Row(torch.autograd.Function):
+    """_Blend2 with the mixing pair given as row ``idx`` of a GammaRows table."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, table, idx, acc):
+        x1, x2 = nhwc(x1), nhwc(x2)
+        if x1.shape != x2.shape or x1.numel() % 4 != 0 or table.shape[1] != 2:
+            raise SenasHipError('blend2: shapes %s / %s / %s' % (tuple(x1.shape), tuple(x2.shape), tuple(table.shape)))
+        y = torch.empty_like(x1, memory_format=CL)
+        gp = table.data_ptr() + 8 * idx
+        _lib.check(_lib.lib().senas_blend2_fwd(x1.numel(), x1.data_ptr(), x2.data_ptr(), gp, y.data_ptr(), _stream()), 'senas_blend2_fwd')
+        ctx.save_for_backward(x1, x2, table, acc)
+        ctx.idx = idx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, table, acc = ctx.saved_tensors
+        dy = nhwc(dy)
+        need = ctx.needs_input_grad
+        dx1 = torch.empty_like(x1, memory_format=CL) if need[0] else None
+        dx2 = torch.empty_like(x2, memory_format=CL) if need[1] else None
+        _lib.check(_lib.lib().senas_blend2_bwd(x1.numel(), dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), table.data_ptr() + 8 * ctx.idx,
+                                               _p(dx1), _p(dx2), acc.data_ptr() + 16 * ctx.idx, _stream()), 'senas_blend2_bwd')
+        return dx1, dx2, None, None, None
+
+
+def blend2_row(x1, x2, rows, idx):
+    """rows.table[idx][0] * x1 + rows.table[idx][1] * x2 (rows: GammaRows)."""
+    return _Blend2Row.apply(x1, x2, rows.table, idx, rows.acc)
+
+
 class _EdgeMix(torch.autograd.Function):
     """M[e][k] = beta[e] * (w_norm[e][k] if edge e is a NORM edge else w_chg[e][k]) for all edges of a cell kind at once
     (search/cell.py:33-36,100-106: every MixedOp scales its candidates by its alpha row, every node scales the edge by
@@ -503,11 +560,33 @@ class _FanOut(torch.autograd.Function):
             return None, None
         if len(gs) == 1:
             return gs[0], None
-        ref = gs[0]
-        dense = [g for g in gs if g.is_cuda and g.dtype == torch.float32 and g.stride() == ref.stride() and
-                 (g.is_contiguous(memory_format=CL) or g.is_contiguous()) and g.data_ptr() % 16 == 0]
-        rest = [g for g in gs if not any(g is d for d in dense)]
+        ref = next((g for g in gs if g.dim() == 4 and (g.is_contiguous(memory_format=CL) or g.is_contiguous())), gs[0])
+
+        def stride_of(g):
+            """Pixel stride of g if it is (a channel slice of) an NHWC tensor laid out like ``ref``, else None."""
+            if not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 4 and g.shape == ref.shape and g.data_ptr() % 16 == 0):
+                return None
+            n, c, h, w = g.shape
+            ct = g.stride(3) if c > 1 else 0
+            if c % 4 == 0 and ct >= c and ct % 4 == 0 and g.stride() == (h * w * ct, 1, w * ct, ct):
+                return ct
+            return None
+
+        same = [g for g in gs if g.is_cuda and g.dtype == torch.float32 and g.stride() == ref.stride() and g.shape == ref.shape and
+                (g.is_contiguous(memory_format=CL) or g.is_contiguous()) and g.data_ptr() % 16 == 0]
+        strides = [stride_of(g) for g in gs]
         out = None
+        if len(same) < len(gs) and ref.dim() == 4 and ref.is_contiguous(memory_format=CL) and all(st is not None for st in strides) \
+                and len(gs) <= _lib.MAX_TERMS:
+            # some gradients are channel slices (the torch.cat consumer's): one strided n-ary sum instead of binary adds
+            n, c, h, w = ref.shape
+            dst = torch.empty((n, c, h, w), device=ref.device, dtype=torch.float32, memory_format=CL)
+            ptrs = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            st = (C.c_int32 * len(gs))(*strides)
+            _lib.check(_lib.lib().senas_sum_n_strided(len(gs), n * h * w, c, ptrs, st, dst.data_ptr(), _stream()), 'senas_sum_n_strided')
+            return dst, None
+        dense = same
+        rest = [g for g in gs if not any(g is d for d in dense)]
         while dense:
             take = _lib.MAX_TERMS - (1 if out is not None else 0)
             chunk, dense = ([out] if out is not None else []) + dense[:take], dense[take:]
@@ -515,7 +594,7 @@ class _FanOut(torch.autograd.Function):
             ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
             _lib.check(_lib.lib().senas_sum_n(len(chunk), ref.numel(), ptrs, dst.data_ptr(), _stream()), 'senas_sum_n')
             out = dst
-        for g in rest:                                    # odd layouts (e.g. a strided slice): let torch add them
+        for g in rest:                                    # odd layouts: let torch add them
             out = g if out is None else out + g
         return out, None
 

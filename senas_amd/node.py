@@ -181,7 +181,8 @@ class _Node(torch.autograd.Function):
         grads += list(dgs) + list(dbs)
         grads += list(dw1s) + list(dw2s)
         # exactly-zero gradients: the zeroed view of the flat buffer already is one
-        grads += [None if (F.SINK is not None and F.SINK.dest(q) is not None) else torch.zeros_like(q) for q in meta['passengers']]
+        grads += [None if (not q.requires_grad or (F.SINK is not None and F.SINK.dest(q) is not None)) else torch.zeros_like(q)
+                  for q in meta['passengers']]
         assert len(grads) == ctx.nflat
         return (None, dmix, ds_out) + tuple(grads)
 

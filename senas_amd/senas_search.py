@@ -40,12 +40,12 @@ class SenasSearch(MacroGrid):
         for j in range(1, self._depth):
             outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1], alpha_dn_nm, alpha_dn, beta_dn))
         s0, outs = self._down_done(s0, outs)
+        rows = F.GammaRows(gamma)                    # the blends read their gamma pair in place and accumulate its gradient
         for j in reversed(range(self._depth - 1)):
             for i in range(1, self._depth - j):
                 skips = [outs[j]]
                 for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
-                    g = gamma[gamma_index(k, j)]
-                    skips.append(F.blend2(outs[j + k - 1], outs[j + k], g))
+                    skips.append(F.blend2_row(outs[j + k - 1], outs[j + k], rows, gamma_index(k, j)))
                 outs[i + j] = self.blocks[i][j](torch.cat(skips, dim=1), outs[i + j], alpha_up_nm, alpha_up, beta_up)
         head = self.head_block[-1]
         tails = outs if self._supervision else outs[-1:]

@@ -232,6 +232,13 @@ int launch_thin_k4(const GatherGeom& g, const float* in, const float* w, int d1,
 template <bool TG>
 int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   const float* mask, double* stats, hipStream_t st);
+// conv_c8.hip (the 8-channel inner-edge convolutions of the search cell on 16 x 16 x 4 fp32 MFMA tiles)
+bool c8_mfma_ok(const GatherGeom& g);
+int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, double* stats,
+                   hipStream_t st);
+bool c8_mfma_wgrad_ok(const WgradGeom& g);
+int64_t c8_mfma_wgrad_ws_bytes(const WgradGeom& g);
+int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st);
 bool thin_n_ok(const GatherGeom& g);
 template <bool TG>
 int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,

@@ -699,6 +699,7 @@ extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* byt
     WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
                                   : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
     if (thin_n_wgrad_ok(wg)) { *bytes = thin_n_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
+    if (!g->transposed && c8_mfma_wgrad_ok(wg)) { *bytes = c8_mfma_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (wgrad_c8_ok(wg)) { *bytes = wgrad_c8_ws_bytes(wg) + 256; return SENAS_OK; }
     if (lds_wgrad_ok(wg)) { *bytes = lds_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }      // (a superset of the launcher's condition)
     if (mfma_wgrad_ok(wg)) *needs_zero = 1;                        // split-K image accumulated with atomics
@@ -746,6 +747,8 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     }
     // the stem (1..4 input channels, stride 1): (tap, channel) pairs on the K axis of the fp32 MFMA
     if (!g->transposed && stem_mfma_ok(gg)) return launch_stem_mfma(gg, x, w, y, in_relu, stats, st);
+    // the search cell's 8-channel inner edges (5x5 dilated, 8 -> 8 / 16): 16 x 16 x 4 MFMA tiles
+    if (!g->transposed && !in_relu && c8_mfma_ok(gg)) return launch_c8_mfma(gg, x, w, g->ci, 1, 0, y, stats, st);
     // thin shapes (stem, head): single-pass HBM-bound kernels that read the torch-layout weights directly
     if (thin_k_ok(gg)) {
         if (!g->transposed && thin_k4_ok(gg)) return launch_thin_k4(gg, x, w, g->ci, 1, 0, y, in_relu, stats, st);
@@ -848,6 +851,8 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
         }
         return launch_status("dwconv_bwd_data");
     }
+    // the data gradient of an 8-channel inner-edge convolution (8 or 16 stacked outputs -> 8): the same gather, taps mirrored
+    if (!g->transposed && mask == nullptr && c8_mfma_ok(gg)) return launch_c8_mfma(gg, dy, w, g->ci, 0, 1, dx, nullptr, st);
     if (thin_k_ok(gg)) {
         // a stride-1 "same" Conv2d: its data gradient is the plain gather over dy with the kernel turned by 180 degrees
         if (!g->transposed && mask == nullptr && thin_k4_ok(gg)) return launch_thin_k4(gg, dy, w, g->ci, 0, 1, dx, 0, nullptr, st);
@@ -1013,6 +1018,14 @@ extern "C" int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const 
         flat_sum(reinterpret_cast<const float*>(ws), dw, g->ci * g->co * taps, nblk, defer, st);
         return launch_status("wgrad_thin_n sum");
     }
+    if (!g->transposed && !i_relu && !g_relu && c8_mfma_wgrad_ok(wg)) {     // the search cell's 8-channel inner edges: 16 x 16 x 4 MFMA tiles
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        int nblk = 0;
+        const int rc = launch_c8_mfma_wgrad(wg, I, G, reinterpret_cast<float*>(ws), &nblk, st);
+        if (rc != SENAS_OK) return rc;
+        flat_sum(reinterpret_cast<const float*>(ws), dw, g->ci * g->co * taps, nblk, defer, st);
+        return launch_status("wgrad_c8_mfma sum");
+    }
     if (wgrad_c8_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         int nblk = 0;
@@ -1058,6 +1071,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
             if (g->kh == 3) return wg.B <= 2 ? "wgrad_thin_n_kernel<3, 2>" : "wgrad_thin_n_kernel<3, 4>";
             return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";
         }
+        if (!tr && c8_mfma_wgrad_ok(wg)) return "wgrad_c8_mfma_kernel";        // (callers without a ReLU on load)
         if (wgrad_c8_ok(wg)) return wg.B <= 8 ? "wgrad_c8_kernel<8>" : "wgrad_c8_kernel<16>";
         if (lds_wgrad_ok(wg)) {
             static char buf[8][48];
@@ -1084,6 +1098,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         snprintf(b, 48, "conv_stem_mfma_kernel<%d, %d>", gg.kh, gg.cin);
         return b;
     }
+    if (!tr && c8_mfma_ok(gg)) return gg.cin == 8 ? "conv_c8_mfma_kernel<8>" : "conv_c8_mfma_kernel<16>";     // (callers without a ReLU on load)
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && thin_n_ok(gg) && (gg.cout <= 4 || tr || !lds_gather_ok(gg))) {
         static char buf[8][48];

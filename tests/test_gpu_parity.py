@@ -519,6 +519,13 @@ _CONV_CASES = [
     (2, 32, 24, 32, 32, 5, 2, 2, False, False),     # ... stride 2 (down cell)
     (2, 32, 24, 16, 16, 3, 2, 1, True, False),      # ... transposed (up cell)
     (2, 32, 24, 24, 24, 1, 1, 1, False, False),     # ... the stacked 1x1 adapters
+    # the 8-channel inner edges on 16 x 16 x 4 MFMA tiles (conv_c8.hip): forward 8 -> 8 / 16, data gradient 8 / 16 -> 8, weight gradient
+    (2, 8, 8, 20, 36, 5, 1, 3, False, False),       # ragged in both directions, several tiles
+    (3, 8, 8, 8, 8, 5, 1, 2, False, False),         # one partly empty tile per image
+    (4, 8, 16, 64, 64, 5, 1, 2, False, False),      # two stacked edges, 64 tiles (the weight gradient's blocks loop over none)
+    (2, 8, 16, 13, 37, 5, 1, 3, False, False),      # stacked, ragged
+    (4, 8, 16, 256, 256, 5, 1, 3, False, False),    # head cell size: 1 024 tiles, the weight gradient's 256 blocks take 4 each
+    (2, 8, 8, 16, 16, 5, 1, 1, False, False),       # dilation 1
     # BASELINE sizes, single layers against the oracle (the whole nets at this size are property-checked only): the tile
     # seams of a 256 x 256 map, 8 images
     (8, 32, 32, 256, 256, 5, 1, 3, False, False),   # dil_3_conv_5 of the derived head cell

@@ -368,10 +368,13 @@ typedef struct senas_node_desc {
  *   mask8  uint8[n*hw*c/4] or NULL: with relu and c % 4 == 0, byte k holds (y > 0) of the 4 floats of 16-byte
  *          piece k in bits 0..3 -- lets the backward pass read 1 byte where it would read 16 of y
  *   out_stats (optional, c = 4 * 2^k): double[n][c][2], the per-image channel sums of y itself are ADDED into it (caller
- *          zeroes) -- the statistics the BatchNorm2d of an 'identity' candidate reading this node needs                */
+ *          zeroes) -- the statistics the BatchNorm2d of an 'identity' candidate reading this node needs
+ *   y2 (optional): y is ALSO written as a channel slice of a wider NHWC tensor (y2_pixel_stride floats between pixels) --
+ *          the node's place in the concatenation the cell's post-process convolution reads (models/senas_model.py:64),
+ *          instead of a torch.cat copy; y may then be NULL (a node that nothing but the concatenation reads)            */
 int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                    float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, uint8_t* mask8,
-                   double* out_stats, void* stream);
+                   double* out_stats, float* y2, int64_t y2_pixel_stride, void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
  *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
  *   dmix: float[nterms] or NULL, overwritten -- or, with dmix_accumulate != 0, added to: the cells of one kind share

@@ -127,7 +127,7 @@ SIGNATURES = {
     'senas_dice_ce_bwd': (_I, [_L, _I, _P, _P, _P, _P, _P, _P]),
     'senas_seg_metric_update': (_I, [_I, _L, _I, _P, _P, _F, _P, _P, _P, _P]),
     'senas_sgd_clip_step': (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
-    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_kernel_name': (C.c_char_p, [_G, _I]),
     'senas_last_error': (C.c_char_p, []),

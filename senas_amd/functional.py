@@ -1215,7 +1215,27 @@ class Term(object):
         self.grad_slot = grad_slot
 
 
-def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False):
+class _CatSlices(torch.autograd.Function):
+    """The concatenation buffer of a cell as a function of the node outputs that were written into its channel slices by
+    their own kernels (node.bn_combine(cat=...)): no copy forward; backward hands every node its slice of d buffer."""
+
+    @staticmethod
+    def forward(ctx, buf, width, *ys):
+        ctx.width, ctx.k = width, len(ys)
+        out = torch.empty(0, device=buf.device, dtype=buf.dtype).set_(buf.untyped_storage(), buf.storage_offset(), buf.shape, buf.stride())
+        return out
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        c = ctx.width
+        return (None, None) + tuple(dbuf[:, i * c:(i + 1) * c] for i in range(ctx.k))
+
+
+def cat_slices(buf, width, ys):
+    return _CatSlices.apply(buf, width, *ys)
+
+
+def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=None):
     """See senas_amd.node.bn_combine (the fused cell node)."""
     from .node import bn_combine as _impl
-    return _impl(terms, mix=mix, residual=residual, relu=relu, out_stats=out_stats)
+    return _impl(terms, mix=mix, residual=residual, relu=relu, out_stats=out_stats, cat=cat)

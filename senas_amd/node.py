@@ -87,16 +87,24 @@ class _Node(torch.autograd.Function):
         scratch = torch.empty((2, T, n, c), device=dev, dtype=torch.float32)
         se_m = torch.empty((T, n, c), device=dev, dtype=torch.float32) if ns else None
         se_a1 = torch.empty((T, n, SE_MID_MAX), device=dev, dtype=torch.float32) if ns else None
-        y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL)
+        # the node's output: a dense tensor, and / or its channel slice of the cell's concatenation buffer (meta['cat'])
+        cat = meta.get('cat')
+        y2, y2s = None, 0
+        if cat is not None:
+            buf, off, dense = cat
+            y2s = buf.shape[1]
+            y2 = torch.empty(0, device=dev, dtype=torch.float32).set_(buf.untyped_storage(), buf.storage_offset() + off, (n, c, h, w),
+                                                                     (h * w * y2s, 1, w * y2s, y2s))
+        y = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL) if (cat is None or cat[2]) else None
         # ReLU mask for the backward pass: one byte per 16-byte piece of y instead of y itself
         # (not kept when nothing will be differentiated: inference)
         tracked = any(ctx.needs_input_grad)
         mask8 = torch.empty(n * h * w * (c // 4), device=dev, dtype=torch.uint8) if (meta['relu'] and c % 4 == 0 and tracked) else None
         res = F.nhwc(residual) if residual is not None else None
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
-        _lib.check(L.senas_node_fwd(C.byref(d), zp, zstrides, F._p(res), y.data_ptr(), coefs.data_ptr(), gate.data_ptr(),
+        _lib.check(L.senas_node_fwd(C.byref(d), zp, zstrides, F._p(res), F._p(y), coefs.data_ptr(), gate.data_ptr(),
                                     scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._p(mask8),
-                                    F._p(meta.get('out_stats')), F._stream()),
+                                    F._p(meta.get('out_stats')), F._p(y2), y2s, F._stream()),
                    'senas_node_fwd')
         ctx.meta = meta
         ctx.has_mix, ctx.has_res, ctx.nflat = mix is not None, residual is not None, len(flat)
@@ -104,8 +112,10 @@ class _Node(torch.autograd.Function):
         ctx.se_buf = (se_m, se_a1)
         ctx.mask8 = mask8
         ctx.out_shape = (n, c, h, w)
+        if y is None:
+            y = y2                                   # nothing but the concatenation reads this node: its slice IS the output
         # y itself is only needed for the mask when there is no byte map
-        ysave = y if (meta['relu'] and mask8 is None) else coefs
+        ysave = y.contiguous(memory_format=CL) if (meta['relu'] and mask8 is None) else coefs
         ctx.save_for_backward(ysave, coefs, gate, mixc if mixc is not None else coefs, *zs, *gammas, *betas, *w1s, *w2s)
         return y
 
@@ -187,11 +197,13 @@ class _Node(torch.autograd.Function):
         return (None, dmix, ds_out) + tuple(grads)
 
 
-def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False):
+def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=None):
     """Normalise every term with its own BatchNorm2d (train or eval mode as the module says), apply
     SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
     and optionally ReLU -- one read of every term, one write.  ``out_stats``: also leave the per-image channel
-    sums of the result on it (``y._senas_stats``), for a consumer that batch-normalises it directly."""
+    sums of the result on it (``y._senas_stats``), for a consumer that batch-normalises it directly.
+    ``cat = (buffer [n, C, h, w] NHWC, channel offset, dense)``: the result is (also) written into that channel slice of
+    the cell's concatenation buffer; with ``dense`` False nothing else is written and the slice itself is returned."""
     T = len(terms)
     if T == 0 or T > _lib.MAX_TERMS:
         raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))
@@ -221,6 +233,8 @@ def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False):
     flat += [terms[t].se.excitation[0].weight for t in se_ids] + [terms[t].se.excitation[2].weight for t in se_ids]
     flat += passengers
     c = ref.shape[1]
+    if cat is not None:
+        meta['cat'] = cat
     if out_stats and c % 4 == 0 and (c // 4) & (c // 4 - 1) == 0 and c <= 256:
         meta['out_stats'] = F.new_stats(ref.shape[0], c, ref)
     y = _Node.apply(meta, mix, residual, *flat)

@@ -55,10 +55,29 @@ class BuildCell(nn.Module):
 
         add_state(self.preprocess0(in0))
         add_state(self.preprocess1(in1))
+        # Nodes that sit in the output concatenation write their result straight into its channel slice (node.bn_combine
+        # cat=...): no torch.cat launch; a node that nothing else reads is not stored anywhere else.
+        concat = list(self._concat)
+        direct = all(k >= self._input_num for k in concat) and len(set(concat)) == len(concat)
+        catbuf = None
         for i in range(self._num_meta_node):
             pair = [self._ops[e].raw(next(states[self._indices[e]])) for e in (2 * i, 2 * i + 1)]
-            add_state(F.bn_combine(pair, relu=True))               # ReLU(op_a(.) + op_b(.)) in one pass
-        return self.post_process(torch.cat([next(states[i]) for i in self._concat], dim=1))
+            k = self._input_num + i
+            cat = None
+            if direct and k in concat:
+                ref = next((t.z for t in pair if t.z is not None), None)
+                if ref is not None and ref.shape[1] % 4 == 0:
+                    n, c, h, w = ref.shape
+                    if catbuf is None:
+                        catbuf = F.new_nhwc(n, c * len(concat), h, w, ref)
+                    cat = (catbuf, concat.index(k) * c, uses[k] > 1)
+                else:
+                    direct = False
+            add_state(F.bn_combine(pair, relu=True, cat=cat))               # ReLU(op_a(.) + op_b(.)) in one pass
+        outs = [next(states[i]) for i in concat]
+        if direct and catbuf is not None:
+            return self.post_process(F.cat_slices(catbuf, catbuf.shape[1] // len(concat), outs))
+        return self.post_process(torch.cat(outs, dim=1))
 
 
 class Head(nn.Module):

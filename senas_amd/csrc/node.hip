@@ -415,8 +415,15 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
     const int n = blockIdx.y;
     long q0 = (long)blockIdx.x * chunk, q1 = q0 + chunk;
     if (q1 > hw) q1 = hw;
-    // `tt` terms starting at t0, TT at a time: nodes with more than TT terms (the search cell: 12 - 24) loop here instead
-    // of costing one launch per group -- the re-read of dy / the mask comes from L2
+    // `tt` terms starting at t0, TT at a time.  Nodes with more than TT terms (the search cell: 12 - 24): blockIdx.z takes
+    // one group of TT each -- side by side instead of one after the other (every group ends in a fold through LDS and a
+    // round of atomics: ~5 us of latency each on a small map); the re-read of dy / the mask comes from L2
+    if (gridDim.z > 1) {
+        const int first = t0 + (int)blockIdx.z * TT, left = t0 + tt_all - first;
+        t0 = first;
+        tt_all = left < TT ? left : TT;
+        do_p1 = do_p1 && blockIdx.z == 0;
+    }
     const int tend = t0 + tt_all;
     for (; t0 < tend; t0 += TT, do_p1 = 0) {
     const int tt = tend - t0 < TT ? tend - t0 : TT;
@@ -962,10 +969,13 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
             // at most 64 blocks contend for one (n, c) accumulator
             const int U = tt <= 2 ? 4 : (tt <= 4 ? 2 : 1);
             const long per_iter = (long)(256 / Q) * U;
-            const int iters = d.hw <= 4096 ? 1 : (d.hw <= 16384 ? 2 : 8);
+            // blocks per image: every block ends in one fp64 atomic per (term, channel) on the image's accumulators; 256
+            // blocks per image measured 93 us at 256 x 256 where 64 take 36 (contention), 128 are the best at 128 x 128
+            const int iters = d.hw <= 16384 ? 1 : 8;
+            const long cap = d.hw <= 4096 ? 64 : (d.hw <= 16384 ? 128 : 64);
             long chunk = per_iter * iters;
-            if ((d.hw + chunk - 1) / chunk > 64) chunk = ((d.hw + 63) / 64 + per_iter - 1) / per_iter * per_iter;
-            dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n);
+            if ((d.hw + chunk - 1) / chunk > cap) chunk = ((d.hw + cap - 1) / cap + per_iter - 1) / per_iter * per_iter;
+            dim3 rgrid((unsigned)((d.hw + chunk - 1) / chunk), d.n, tt > 8 ? (unsigned)((tt + 7) / 8) : 1u);
 #define SENAS_RV(TT, UU) hipLaunchKernelGGL((node_reduce_vec_kernel<TT, UU>), rgrid, dim3(256), (size_t)4 * (Q <= 16 ? 4 : 64 / Q) * (1 + TT) * d.c * sizeof(double), st, \
                                              d.hw, d.c, chunk, t0, tt, d.n, zt, dy, dys, y, mask8, d.relu, first, p1, p2)
             if (tt > 4) SENAS_RV(8, 1);

@@ -95,7 +95,12 @@ class GradAllReducer(object):
         missing = [v for v, p in zip(self.views, self._order) if p.grad is None]
         if have:
             self._gather(have)
-        for v in missing:                                 # a parameter unused this step contributes zeros
+        # A parameter without a gradient on this rank contributes zeros and comes back with the (possibly non-zero)
+        # mean of the other ranks' gradients -- or an exact zero, which the optimizer then treats like any gradient
+        # (weight decay, momentum), where torch on one GPU would skip a parameter whose .grad is None.  The step
+        # drivers (gradsink.GradSink) behave the same way on any number of ranks: every registered parameter always
+        # has a gradient, exactly zero if nothing reached it -- as the reference's 'none' candidates get from autograd.
+        for v in missing:
             v.zero_()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
@@ -113,7 +118,7 @@ class GradAllReducer(object):
         from . import _lib
         from . import functional as F
         from .packing import _CopyItem
-        key = tuple(g.data_ptr() for _, g in have)
+        key = tuple((g.data_ptr(), v.data_ptr(), g.numel()) for v, g in have)       # sources, destinations and sizes
         if getattr(self, '_gather_key', None) != key:
             items = [_CopyItem(g.data_ptr(), v.data_ptr(), 1, g.numel(), g.numel(), g.numel(), 0) for v, g in have]
             raw = bytes((_CopyItem * len(items))(*items))

@@ -58,58 +58,79 @@ __device__ __forceinline__ void bn1_coefficients(const senas_dstail_item& it, in
     }
 }
 
-// grid = (blocks of P x 256 output quads, k).  thread = 4 output channels of one pixel, as pw_multi_fwd
-__global__ __launch_bounds__(256) void dstail_fwd_kernel(DsItems items, int nimg, long hw, int cin, int cout, long total, int P,
-                                                         int training, float momentum, float eps) {
+// grid = (pixel chunks of one image, n, k).  thread = ONE pixel, all COUT outputs: a lane reads its 4 * Q-float row once
+// (consecutive lanes, consecutive rows), applies BN1 + ReLU and multiplies by W from LDS (broadcast reads).
+template <int COUT>
+__global__ __launch_bounds__(256) void dstail_fwd_kernel(DsItems items, int nimg, long hw, int cin, long chunk, int training,
+                                                         float momentum, float eps) {
     __shared__ __attribute__((aligned(16))) float wl[kMaxCout * kMaxCin];
     __shared__ __attribute__((aligned(16))) float sc[2 * kMaxCin];
-    const senas_dstail_item& it = items.it[blockIdx.y];
-    const bool writer = blockIdx.x == 0;
+    __shared__ double red[16][2 * kMaxCout];
+    const senas_dstail_item& it = items.it[blockIdx.z];
+    const int n = blockIdx.y;
+    const bool writer = blockIdx.x == 0 && n == 0;
     bn1_coefficients(it, nimg, hw, cin, training, momentum, eps, writer, true, sc);
     if (writer && threadIdx.x == 0 && training && it.num_batches_tracked1 != nullptr) *it.num_batches_tracked1 += 1;
-    for (int i = threadIdx.x; i < cout * cin; i += 256) wl[i] = it.w[i];
+    for (int i = threadIdx.x; i < COUT * cin; i += 256) wl[i] = it.w[i];
     __syncthreads();
-    const float* __restrict__ x = it.z1;
-    float* __restrict__ y = it.z2;
-    double* __restrict__ stats = it.stats2;
-    Stats4 acc_st;
-    stats_init4(acc_st);
-    const bool uniform = P > 0;
-    const int chunks = uniform ? P : 1, cv = cout >> 2;
-    int n_blk = 0, ch_thr = 0;
-    for (int kk = 0; kk < chunks; ++kk) {
-        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
-        const bool active = idx < total;
-        if (!active) idx = total - 1;
-        const int ch = (int)(idx % cv) * 4;
-        const long pix = idx / cv;
-        const int n = (int)(pix / hw);
-        n_blk = n; ch_thr = ch;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float4* xp = reinterpret_cast<const float4*>(x + (size_t)pix * cin);
-        for (int c4 = 0; c4 < (cin >> 2); ++c4) {
+    long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk;
+    if (p1 > hw) p1 = hw;
+    double s1[COUT], s2[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) s1[co] = s2[co] = 0.0;
+    const size_t img = (size_t)n * hw;
+    const int Q = cin >> 2;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float4* xp = reinterpret_cast<const float4*>(it.z1 + (img + p) * cin);
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        for (int c4 = 0; c4 < Q; ++c4) {
             float4 xv = xp[c4];
             const float4 s4 = *reinterpret_cast<const float4*>(sc + 4 * c4), b4 = *reinterpret_cast<const float4*>(sc + cin + 4 * c4);
             xv.x = fmaxf(fmaf(xv.x, s4.x, b4.x), 0.f); xv.y = fmaxf(fmaf(xv.y, s4.y, b4.y), 0.f);
             xv.z = fmaxf(fmaf(xv.z, s4.z, b4.z), 0.f); xv.w = fmaxf(fmaf(xv.w, s4.w, b4.w), 0.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 wv = *reinterpret_cast<const float4*>(wl + (ch + j) * cin + 4 * c4);
-                acc[j] = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, acc[j]))));
+            for (int co = 0; co < COUT; ++co) {
+                const float4 wv = *reinterpret_cast<const float4*>(wl + co * cin + 4 * c4);
+                acc[co] = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, acc[co]))));
             }
         }
-        if (active) stv<4>(y + (size_t)pix * cout + ch, acc);
-        stats_accumulate4(acc_st, stats, uniform, n, cout, ch, acc, active);
+        float* yp = it.z2 + (img + p) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4) stv<4>(yp + co, reinterpret_cast<float(&)[4]>(acc[co]));
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) { s1[co] += (double)acc[co]; s2[co] += (double)acc[co] * (double)acc[co]; }
     }
-    stats_flush4(acc_st, stats, uniform, n_blk, cout, ch_thr);
+    if (it.stats2 == nullptr) return;                              // block-uniform
+    // per-image channel sums of z2: 16-lane rows with DPP (VALU speed), the 16 rows of the block through LDS, one fp64 atomic
+    // pair per channel and block
+    const int row = threadIdx.x >> 4;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const double a = row_strided_sum(s1[co], 1), b = row_strided_sum(s2[co], 1);
+        if ((threadIdx.x & 15) == 0) { red[row][2 * co] = a; red[row][2 * co + 1] = b; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * COUT) {
+        double tot = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += red[r][threadIdx.x];
+        atomicAdd(it.stats2 + (size_t)n * COUT * 2 + threadIdx.x, tot);
+    }
 }
 
 // ds quad of one pixel: dmid = W^T dz2 for the thread's 4 input channels, masked by BN1(z1) > 0; mid = relu(BN1(z1))
 template <int COUT>
-__device__ __forceinline__ void ds_quad(const float* __restrict__ dp, const float* wl, int cin, int q, const float4& z, const float4& s4,
+__device__ __forceinline__ void ds_quad(const float* __restrict__ dp, bool vec, const float* wl, int cin, int q, const float4& z, const float4& s4,
                                         const float4& b4, float (&d)[COUT], float (&ds)[4], float (&mid)[4]) {
+    if (vec) {                                                   // (block-uniform: dz2 rows are 16-byte aligned)
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) d[co] = dp[co];
+        for (int co = 0; co < COUT; co += 4) ldv<4>(dp + co, reinterpret_cast<float(&)[4]>(d[co]));
+    } else {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) d[co] = dp[co];
+    }
     float dm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
@@ -138,6 +159,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
     __syncthreads();
     const int Q = cin >> 2, q = threadIdx.x % Q, pl = threadIdx.x / Q, lanes = 256 / Q;
     const int dst = (int)it.dz2_pixel_stride;
+    const bool vec = (dst & 3) == 0 && (reinterpret_cast<uintptr_t>(it.dz2) & 15) == 0;
     const float4 s4 = *reinterpret_cast<const float4*>(sc + 4 * q), b4 = *reinterpret_cast<const float4*>(sc + cin + 4 * q);
     long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk;
     if (p1 > hw) p1 = hw;
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
     for (long p = p0 + pl; p < p1; p += lanes) {
         const float4 z = reinterpret_cast<const float4*>(it.z1)[(img + p) * Q + q];
         float d[COUT], ds[4], mid[4];
-        ds_quad<COUT>(it.dz2 + (img + p) * dst, wl, cin, q, z, s4, b4, d, ds, mid);
+        ds_quad<COUT>(it.dz2 + (img + p) * dst, vec, wl, cin, q, z, s4, b4, d, ds, mid);
         const float zz[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[j] += (double)ds[j]; s2[j] += (double)ds[j] * (double)zz[j]; }
@@ -234,6 +256,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_apply_kernel(DsItems items, in
     if (it.dz1 == nullptr) return;
     const int Q = cin >> 2, q = threadIdx.x % Q, pl = threadIdx.x / Q, lanes = 256 / Q;
     const int dst = (int)it.dz2_pixel_stride;
+    const bool vec = (dst & 3) == 0 && (reinterpret_cast<uintptr_t>(it.dz2) & 15) == 0;
     const float4 s4 = *reinterpret_cast<const float4*>(sc + 4 * q), b4 = *reinterpret_cast<const float4*>(sc + cin + 4 * q);
     const float4 a4 = *reinterpret_cast<const float4*>(abk + 4 * q), bb4 = *reinterpret_cast<const float4*>(abk + cin + 4 * q),
                  k4 = *reinterpret_cast<const float4*>(abk + 2 * cin + 4 * q);
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_apply_kernel(DsItems items, in
         const size_t o4 = (img + p) * Q + q;
         const float4 z = reinterpret_cast<const float4*>(it.z1)[o4];
         float d[COUT], ds[4], mid[4];
-        ds_quad<COUT>(it.dz2 + (img + p) * dst, wl, cin, q, z, s4, b4, d, ds, mid);
+        ds_quad<COUT>(it.dz2 + (img + p) * dst, vec, wl, cin, q, z, s4, b4, d, ds, mid);
         float4 r;
         r.x = fmaf(a4.x, ds[0], fmaf(bb4.x, z.x, k4.x));
         r.y = fmaf(a4.y, ds[1], fmaf(bb4.y, z.y, k4.y));
@@ -288,10 +311,15 @@ extern "C" int senas_dstail_fwd(const senas_dstail_item* items, int k, int n, in
         want = want && b.it[t].stats2 != nullptr;
     }
     if (!want) for (int t = 0; t < k; ++t) b.it[t].stats2 = nullptr;
-    const long per_img = hw * (cout / 4), total = per_img * n;
-    const int P = want ? stats_chunks_per_block(per_img, cout, total) : 0;
-    dim3 grid((unsigned)((total + 256L * (P > 0 ? P : 1) - 1) / (256L * (P > 0 ? P : 1))), k);
-    hipLaunchKernelGGL(dstail_fwd_kernel, grid, dim3(256), 0, as_stream(stream), b, n, (long)hw, cin, cout, total, P, training, momentum, eps);
+    // one pixel per thread; enough blocks to fill the chip, at most 64 per image (every block ends in 2 * cout atomics)
+    long blocks = 2048 / ((long)n * k);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    long chunk = (hw + blocks - 1) / blocks;
+    chunk = (chunk + 255) / 256 * 256;
+    dim3 grid((unsigned)((hw + chunk - 1) / chunk), n, k);
+    if (cout == 8) hipLaunchKernelGGL((dstail_fwd_kernel<8>), grid, dim3(256), 0, as_stream(stream), b, n, (long)hw, cin, chunk, training, momentum, eps);
+    else hipLaunchKernelGGL((dstail_fwd_kernel<4>), grid, dim3(256), 0, as_stream(stream), b, n, (long)hw, cin, chunk, training, momentum, eps);
     return launch_status("dstail_fwd");
 }
 

@@ -198,3 +198,48 @@ def test_config5_rgb_4class_512(tmp_path):
     assert bool(torch.isfinite(loss)) and abs(float(loss) - l0) <= 1e-4 * abs(l0)
     assert not torch.equal(before, net.stem0[0].weight.detach())
     step.close()
+
+
+def test_packers_do_not_revalidate_each_other():
+    """Several packed-weight caches coexist (a validation Evaluator built first, a TrainStep built later): a fused optimizer
+    step makes ALL of them stale; refreshing one must not make another one's images count again, and an evaluator that is
+    reused after training steps must see the new weights (the drivers validate between epochs, train_model.py:306-340)."""
+    import copy
+    from senas_amd import functional as F
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.infer import Evaluator
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.step import TrainStep
+    torch.manual_seed(31)
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 1, 64, 64, generator=gen).to(dev())
+    y = torch.randint(0, 2, (2, 64, 64), generator=gen).to(dev())
+    crit = SegmentationLosses('dice_ce')
+    net = SenasModel(2, 1, c=32, depth=3, genotype=senas_node_4).to(dev()).train()
+    ev = Evaluator(net, 2, x, y, crit, use_graph=True)              # its packer is installed first ...
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=5e-2, momentum=0.9)
+    step = TrainStep(net, crit, opt, x, y, use_graph=True)          # ... and replaced by the train step's
+    for _ in range(2):
+        step()                                                      # fused SGD: weights move behind torch's version counters
+    assert ev.packer.stale() and step.fb.packer.stale()
+    ev.packer.refresh()                                             # the evaluator's images are current now; the INSTALLED ones are not
+    assert not ev.packer.stale() and step.fb.packer.stale()
+    net.eval()
+    with torch.no_grad():
+        got = net(x)[-1]                                            # eager: must repack on its own, not trust the train packer's images
+        twin = copy.deepcopy(net)
+        want = twin(x)[-1]
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    net.train()
+    step()
+    logits, mask = ev(x, y)                                         # reused after another step: refreshes itself
+    with torch.no_grad():
+        twin = copy.deepcopy(net).eval()
+        want = twin(x)[-1]
+    assert float((logits - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert bool((mask == want.argmax(1)).all())
+    step.close()
+    ev.packer.uninstall()
+    assert F.SINK is None

@@ -768,7 +768,8 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     // once per step (senas_pack_batched) instead of once per launch
     const bool use_lds = !g->transposed && lds_gather_ok(gg);
     const bool use_s2 = !g->transposed && lds_gather_s2_ok(gg);
-    if (use_lds || use_s2 || mfma_gather_ok(gg, g->transposed != 0)) {
+    const bool use_t2 = g->transposed && !in_relu && t2_lds_ok(gg);          // ConvTranspose2d stride 2: the four output phases share one LDS window
+    if (use_lds || use_s2 || use_t2 || mfma_gather_ok(gg, g->transposed != 0)) {
         const float* img = packed;
         if (img == nullptr) {
             if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 1, st);
@@ -777,6 +778,7 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
         }
         if (use_lds) return launch_lds_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
         if (use_s2) return launch_lds_gather_s2(gg, x, img, y, in_relu, nullptr, stats, st);
+        if (use_t2) return launch_t2_lds(gg, x, img, y, stats, st);
         if (!g->transposed) return launch_mfma_gather<false>(gg, x, img, y, in_relu, nullptr, stats, st);
         return launch_mfma_gather<true>(gg, x, img, y, in_relu, nullptr, stats, st);
     }
@@ -864,7 +866,8 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     const int taps = g->kh * g->kw, total = taps * g->ci * g->co;
     const bool use_lds = !g->transposed && lds_gather_ok(gg);
     const bool use_s2 = g->transposed && lds_gather_s2_ok(gg);          // ConvTranspose2d: dx is a stride-2 plain gather over dy
-    if (use_lds || use_s2 || mfma_gather_ok(gg, g->transposed == 0)) {
+    const bool use_t2 = !g->transposed && mask == nullptr && t2_lds_ok(gg);      // stride-2 Conv2d: dx is a transposed gather over dy
+    if (use_lds || use_s2 || use_t2 || mfma_gather_ok(gg, g->transposed == 0)) {
         const float* img = packed;
         if (img == nullptr) {
             if (!g->transposed) launch_pack_mfma(w, wp, g->co, g->ci, taps, 0, st);
@@ -873,6 +876,7 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
         }
         if (use_lds) return launch_lds_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
         if (use_s2) return launch_lds_gather_s2(gg, dy, img, dx, 0, mask, nullptr, st);
+        if (use_t2) return launch_t2_lds(gg, dy, img, dx, nullptr, st);
         if (!g->transposed) return launch_mfma_gather<true>(gg, dy, img, dx, 0, mask, nullptr, st);
         return launch_mfma_gather<false>(gg, dy, img, dx, 0, mask, nullptr, st);
     }
@@ -1121,6 +1125,7 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         snprintf(b, 64, "conv_lds_kernel<false, 1, 4, %d, 0, 1, %d, 2, false>", gg.kh * gg.kw <= 9 ? 3 : 7, gg.wout >= 16 ? 16 : 8);
         return b;
     }
+    if (tg && t2_lds_ok(gg)) return "conv_t2_lds_kernel";               // (callers without a ReLU on load / mask)
     if (mfma_gather_ok(gg, tg)) {
         const bool s2 = tg && gg.stride == 2;
         const long per_phase = (long)gg.n * (s2 ? (gg.hout / 2) * (gg.wout / 2) : gg.hout * gg.wout);

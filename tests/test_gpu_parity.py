@@ -526,6 +526,12 @@ _CONV_CASES = [
     (2, 8, 16, 13, 37, 5, 1, 3, False, False),      # stacked, ragged
     (4, 8, 16, 256, 256, 5, 1, 3, False, False),    # head cell size: 1 024 tiles, the weight gradient's 256 blocks take 4 each
     (2, 8, 8, 16, 16, 5, 1, 1, False, False),       # dilation 1
+    # transposed gathers at stride 2 with the window in LDS (conv_t2.hip): ConvTranspose2d forward, stride-2 Conv2d data gradient
+    (2, 32, 32, 9, 13, 5, 2, 3, True, False),       # ragged position tiles, dilation 3 (9 + 6 + 6 + 4 taps in the four phases)
+    (2, 16, 32, 7, 20, 3, 2, 1, True, False),       # one 16-channel pass, 3x3
+    (2, 64, 32, 12, 12, 5, 2, 2, True, False),      # four passes, dilation 2: three of the four output phases are zero
+    (2, 32, 40, 10, 10, 3, 2, 1, True, False),      # two output-channel tiles
+    (2, 32, 32, 24, 40, 5, 2, 1, False, False),     # stride-2 Conv2d 5x5 dilation 1: its data gradient
     # BASELINE sizes, single layers against the oracle (the whole nets at this size are property-checked only): the tile
     # seams of a 256 x 256 map, 8 images
     (8, 32, 32, 256, 256, 5, 1, 3, False, False),   # dil_3_conv_5 of the derived head cell

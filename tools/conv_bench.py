@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--shape', default='')
+    ap.add_argument('--zeros', action='store_true', help='all-zero operands: the clock the chip holds without data-dependent switching')
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in args.shape.split(','))] if args.shape else SHAPES
     dev = torch.device('cuda:0')
@@ -56,6 +57,9 @@ def main():
         g = torch.Generator(device='cuda').manual_seed(0)
         x = torch.randn(n, ci, h, w, device=dev, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         wt = (torch.randn(co, ci, k, k, device=dev, generator=g) * 0.05).requires_grad_(True)
+        if args.zeros:
+            x = torch.zeros_like(x).requires_grad_(True)
+            wt = torch.zeros_like(wt).requires_grad_(True)
         pad = (k // 2) * d
         y, _ = F.conv2d(x, wt, stride=s, pad=pad, dil=d, want_stats=True)
         gy = torch.randn(y.shape, device=dev, generator=g).contiguous(memory_format=torch.channels_last)

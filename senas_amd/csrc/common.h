@@ -233,11 +233,6 @@ template <bool TG>
 int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   const float* mask, double* stats, hipStream_t st);
 // conv_t2.hip (transposed gather at stride 2 with the input window in LDS: ConvTranspose2d forward, stride-2 Conv2d data gradient)
-bool pipe_gather_ok(const GatherGeom& g);
-template <bool TG>
-int launch_pipe_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,
-                       double* stats, hipStream_t st);
-void pipe_gather_name(const GatherGeom& g, bool tg, char* buf, int len);
 bool t2_lds_ok(const GatherGeom& g);
 int launch_t2_lds(const GatherGeom& g, const float* in, const float* wp, float* out, double* stats, hipStream_t st);
 // conv_c8.hip (the 8-channel inner-edge convolutions of the search cell on 16 x 16 x 4 fp32 MFMA tiles)

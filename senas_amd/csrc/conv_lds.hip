@@ -494,7 +494,6 @@ void lds_gather_shape(const GatherGeom& g, int& mt, int& ks, int& rw, int& twl) 
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st) {
-    if (pipe_gather_ok(g)) return launch_pipe_gather<TG>(g, in, wp, out, in_relu, mask, stats, st);   // maps that fill the chip: conv_pipe.hip
     int mt, ks, rw, twl;
     lds_gather_shape(g, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;
@@ -517,7 +516,6 @@ int launch_lds_gather_epi(const GatherGeom& g, const float* in, const float* wp,
 
 // the kernel symbol launch_lds_gather picks (for senas_conv2d_kernel_name)
 void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len) {
-    if (pipe_gather_ok(g)) { pipe_gather_name(g, tg, buf, len); return; }
     int mt, ks, rw, twl;
     lds_gather_shape(g, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;

@@ -12,6 +12,40 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // 32x32x2 with NV integer VALU instructions (v_mad_u32_u24-class, independent of the MFMAs) per 16 MFMAs, and optionally
 // LDS: 4 ds_read_b128 per 16 MFMAs whose results feed the next round's A operands
+// 32x32x2 with NG global_load_dwordx4 (L2-resident, 1 KiB per wave-instruction) per 16 MFMAs; the data feeds the next round
+template <int NG>
+__global__ __launch_bounds__(256) void probe_vmem(const float* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* stamps) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = src[(tid * 16 + i) & 0xfffff]; b[i] = src[(tid * 16 + 8 + i) & 0xfffff]; }
+    unsigned long long c0 = 0, r0 = 0;
+    if (threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    f32x16 acc[2];
+    for (int m = 0; m < 2; ++m) for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + (threadIdx.x & 63);
+    float4 g[NG > 0 ? NG : 1];
+    for (int it = 0; it < iters; ++it) {
+        const float4* p = s4 + ((it & 63) << 6) * 4;                  // 64 KiB-wide slice of the buffer, shared by all waves: L2 hits
+#pragma unroll
+        for (int k = 0; k < NG; ++k) g[k] = p[k * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[i], a[i], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NG; ++k) { a[k & 7] = g[k].x; b[k & 7] = g[k].w; }
+    }
+    float sum = 0.f;
+    for (int m = 0; m < 2; ++m) for (int v = 0; v < 16; ++v) sum += acc[m][v];
+    if (threadIdx.x == 0) {
+        stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    dst[tid] = sum;
+}
+
 template <int NV, int LDSR>
 __global__ __launch_bounds__(256) void probe_mix(const float* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* stamps) {
     __shared__ float4 sh[1024];
@@ -145,5 +179,13 @@ int main() {
     run_k(probe_mix<0, 1>, "32x32x2 random, 2 waves/SIMD, +4 ds_read_b128 per 16 MFMA", src, dst, stamps, blocks, iters);
     run_k(probe_mix<32, 1>, "32x32x2 random, 2 waves/SIMD, +32 VALU +4 ds_read_b128", src, dst, stamps, blocks, iters);
     run_k(probe_mix<32, 1>, "32x32x2 random, 1 wave/SIMD,  +32 VALU +4 ds_read_b128", src, dst, stamps, 256, iters);
+    run_k(probe_vmem<0>, "32x32x2 random, 1 wave/SIMD, vmem kernel, no loads", src, dst, stamps, 256, iters);
+    run_k(probe_vmem<3>, "32x32x2 random, 1 wave/SIMD, +3 global_load_dwordx4 per 16 MFMA", src, dst, stamps, 256, iters);
+    run_k(probe_vmem<6>, "32x32x2 random, 1 wave/SIMD, +6 global_load_dwordx4 per 16 MFMA", src, dst, stamps, 256, iters);
+    run_k(probe_vmem<3>, "32x32x2 random, 2 waves/SIMD, +3 global_load_dwordx4 per 16 MFMA", src, dst, stamps, 512, iters);
+    run_k(probe_mix<0, 1>, "32x32x2 random, 1 wave/SIMD, +4 ds_read_b128 per 16 MFMA", src, dst, stamps, 256, iters);
+    {   // short launches: what the clock governor does with 0.25 ms dispatches
+        run_k(probe<32>, "32x32x2 random, 1 wave/SIMD, 0.25 ms launches", src, dst, stamps, 256, 580);
+    }
     return 0;
 }

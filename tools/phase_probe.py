@@ -36,24 +36,6 @@ def main():
         rc = lib.senas_conv2d_fwd(C.byref(g), x.data_ptr(), wt.data_ptr(), y.data_ptr(), 1, stats.data_ptr(), ws.data_ptr(), None, None)
         assert rc == 0, lib.senas_last_error()
         torch.cuda.synchronize()
-    if len(sys.argv) > 2 and sys.argv[2] == 'pipe':        # conv_pipe.hip: five stamps per (tile, pass) step of block 0
-        assert lib.senas_debug_read_phases_conv_pipe(buf) == 0
-        t = [int(v) for v in buf]
-        prev = t[0]
-        for sidx in range(12):
-            row = t[1 + sidx * 5: 6 + sidx * 5]
-            if not row[0]:
-                break
-            names = ('entered', 'window in LDS', 'barrier', 'taps done', 'stores done')
-            print('step %2d  ' % sidx + '  '.join('%s +%6.2f' % (nm, (v - prev) / 100.0) for nm, v in zip(names, row)) + '   (us since the previous stamp: %s)' %
-                  ' '.join('%.2f' % ((b - a) / 100.0) for a, b in zip([prev] + row[:-1], row)))
-            prev = row[-1]
-        if t[50]:
-            print('step 1 epilogue: stores issued +%.2f, partial sums in LDS +%.2f, barrier +%.2f (us after "taps done")' %
-                  tuple((t[k_] - t[9]) / 100.0 for k_ in (50, 51, 52)))
-        if t[62] > t[61]:
-            print('shader clock over the taps of step 1: %.0f MHz' % ((t[62] - t[61]) / ((t[9] - t[8]) / 100.0)))
-        return
     assert lib.senas_debug_read_phases_conv_lds(buf) == 0
     t = [int(v) for v in buf]
     t0 = t[0]

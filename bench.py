@@ -41,7 +41,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--search-steps', type=int, default=60, help='timed supernet search steps (0 = skip)')
+    ap.add_argument('--search-steps', type=int, default=80, help='timed supernet search steps (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run forward+backward eagerly instead of replaying a HIP graph')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')

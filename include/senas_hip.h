@@ -278,7 +278,7 @@ int senas_bnrelu_multi_bwd(const senas_bnrelu_item* items, int k, int n, int64_t
  *             double[n][cin][2], ZERO on entry; writes dz1 (NULL: skipped), dgamma1, dbeta1 (float[cin]) and -- when dw
  *             is given (for all problems or none) -- dw [cout][cin], accumulated in dw_acc (double[cout][cin] =
  *             senas_dstail_ws_bytes(...) bytes per problem, ZERO on entry).                                          */
-#define SENAS_MAX_DSTAIL 8
+#define SENAS_MAX_DSTAIL 12
 typedef struct senas_dstail_item {
     const float* z1;
     const double* stats1;

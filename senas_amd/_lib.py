@@ -50,7 +50,7 @@ class SumItem(C.Structure):
 
 
 MAX_SUMS = 64
-MAX_DSTAIL = 8
+MAX_DSTAIL = 12
 MAX_BNRELU = 8
 MAX_DWMULTI = 8
 MAX_PWMULTI = 8

@@ -91,6 +91,7 @@ class Cell(nn.Module):
     # ------------------------------------------------------------------ state-major execution
     stacked = True      # run same-named candidates of the edges LEAVING one state as one convolution (class-wide switch)
     fused_tail = True   # DepSepConv candidates: batch-norm + ReLU + 1x1 convolution as one pass (functional.dstail)
+    pair_tails = True   # ... and the tails of BOTH input states' candidates as one launch (Cell.forward)
 
     def _out_edges(self, j):
         """Flat indices of the edges that read state j (one per later node)."""
@@ -148,7 +149,7 @@ class Cell(nn.Module):
         # launch for dep_sep_conv_3 and dep_sep_conv_5 of every edge together (functional.dwconv_multi), one alias of the state
         groups = [list(range(len(items)))]
 
-        def job(xs):
+        def stage1(xs):                                      # the depthwise halves: [(z1, producer statistics)] per item
             zs, sts = [None] * len(items), [None] * len(items)
             for idxs, x in zip(groups, xs):
                 mods = [items[i][2] for i in idxs]
@@ -157,19 +158,36 @@ class Cell(nn.Module):
                     parts = [run_conv(m[0], x, want_stats=m[1].training) for m in mods]
                 for i, (z, st) in zip(idxs, parts):
                     zs[i], sts[i] = z, st
-            bns = [m[1] for _, _, m in items]
-            # batch-norm + ReLU + pointwise convolution of all of them: one launch, the activated tensors never stored
-            pws = F.dstail(zs, bns, sts, [m[3] for _, _, m in items], items[0][2][4].training) if self.fused_tail else None
-            if pws is None:
-                if F.bnrelu_multi_ok(zs, bns):
-                    mids = F.bnrelu_multi(zs, bns, sts)
-                else:
-                    mids = [F.bn_combine([F.Term(z, bn, stats=st)], relu=True) for z, bn, st in zip(zs, bns, sts)]
-                pws = F.pw_multi(mids, [m[3] for _, _, m in items], items[0][2][4].training)      # the pointwise halves, batched
-            if pws is None:
-                pws = [run_conv(m[3], mid, want_stats=m[4].training) for (_, _, m), mid in zip(items, mids)]
-            return [(e, p, F.Term(z2, m[4], stats=st2)) for (e, p, m), (z2, st2) in zip(items, pws)]
+            return zs, sts
+
+        def job(xs):
+            return self._depsep_tail(items, *stage1(xs))
+        job.stages = (stage1, items)                          # (Cell.forward runs the tails of both input states as one launch)
         return job, len(groups)
+
+    def _depsep_tail(self, items, zs, sts):
+        """BatchNorm2d + ReLU + pointwise convolution of DepSepConv candidates whose depthwise halves are done: ONE fused
+        launch (functional.dstail) when the shapes allow, else in chunks of batched batch-norm + pointwise launches."""
+        from .operations import run_conv
+        out = []
+        fused = self.fused_tail and len(items) <= F.MAX_DSTAIL
+        pws = F.dstail(zs, [m[1] for _, _, m in items], sts, [m[3] for _, _, m in items], items[0][2][4].training) if fused else None
+        if pws is not None:
+            return [(e, p, F.Term(z2, m[4], stats=st2)) for (e, p, m), (z2, st2) in zip(items, pws)]
+        for i in range(0, len(items), F.MAX_BNRELU):
+            it, z, st = items[i:i + F.MAX_BNRELU], zs[i:i + F.MAX_BNRELU], sts[i:i + F.MAX_BNRELU]
+            bns = [m[1] for _, _, m in it]
+            pws = F.dstail(z, bns, st, [m[3] for _, _, m in it], it[0][2][4].training) if self.fused_tail else None
+            if pws is None:
+                if F.bnrelu_multi_ok(z, bns):
+                    mids = F.bnrelu_multi(z, bns, st)
+                else:
+                    mids = [F.bn_combine([F.Term(zz, bn, stats=s_)], relu=True) for zz, bn, s_ in zip(z, bns, st)]
+                pws = F.pw_multi(mids, [m[3] for _, _, m in it], it[0][2][4].training)      # the pointwise halves, batched
+                if pws is None:
+                    pws = [run_conv(m[3], mid, want_stats=m[4].training) for (_, _, m), mid in zip(it, mids)]
+            out += [(e, p, F.Term(z2, m[4], stats=st2)) for (e, p, m), (z2, st2) in zip(it, pws)]
+        return out
 
     def _plan(self, j):
         """What has to run on state j: ``jobs`` -- pairs ``(fn, a)`` with ``fn(list of a aliases of the state) ->
@@ -229,6 +247,8 @@ class Cell(nn.Module):
         terms = {}                                  # flat edge index -> [Term per candidate]
         states = []
 
+        held = []                                   # DepSepConv candidates of the FIRST input state whose tails wait for the second's
+
         def add_state(h):
             # everything that reads this state runs now; every reader (and the output concat) gets its own alias of
             # it, so that the state's gradient is ONE n-ary sum (functional.fan_out)
@@ -239,9 +259,31 @@ class Cell(nn.Module):
                 terms.setdefault(e, {})[p] = t
             taken = 0
             for job, a in jobs:
-                for e, p, t in job(aliases[taken:taken + a]):
-                    terms.setdefault(e, {})[p] = t
+                xs = aliases[taken:taken + a]
                 taken += a
+                stages = getattr(job, 'stages', None)
+                if stages is not None and self.pair_tails and nin == 2 and j < 2:
+                    # the two input states' DepSepConv candidates have one shape: their depthwise halves run per state,
+                    # their fused tails (and the two backward passes of those) as ONE launch over both states' candidates
+                    stage1, items = stages
+                    zs, sts = stage1(xs)
+                    if j == 0:
+                        held.append((items, zs, sts))
+                        continue
+                    if held and len(held[0][0]) + len(items) <= F.MAX_DSTAIL and held[0][1][0].shape == zs[0].shape:
+                        i0, z0, s0 = held.pop(0)
+                        out = self._depsep_tail(i0 + items, z0 + zs, s0 + sts)
+                    else:
+                        out = self._depsep_tail(items, zs, sts)
+                else:
+                    out = job(xs)
+                for e, p, t in out:
+                    terms.setdefault(e, {})[p] = t
+            if j == 1:
+                for items, zs, sts in held:               # (no partner: on their own)
+                    for e, p, t in self._depsep_tail(items, zs, sts):
+                        terms.setdefault(e, {})[p] = t
+                del held[:]
             states.append(aliases[-1] if j >= nin else None)
 
         add_state(self.preprocess0(in0))

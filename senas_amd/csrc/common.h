@@ -97,33 +97,60 @@ __device__ __forceinline__ bool lane_holds_partial(int lane, int stride) { retur
 // flushes ONCE with stats_flush4: shuffles over the pixel lanes of a wave, LDS over the 4 waves, one fp64 atomic
 // pair per channel -- so a 256x256 map costs ~64 atomics per (image, channel), not 2048.
 // `uniform` (block lies inside one image, c = 4*cv with cv a power of two <= 64) is decided on the host side of the
-// launch and checked per block; otherwise every element falls back to its own atomics.
+// launch and checked per block; otherwise the block keys its sums by (image, channel) in LDS (stats_flush4).
 struct Stats4 {
     double s[4], q[4];
+    int n;              // off the uniform layout: the image of this thread's (single) element, -1 = none
 };
 __device__ __forceinline__ void stats_init4(Stats4& a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a.s[j] = a.q[j] = 0.0;
+    a.n = -1;
 }
 __device__ __forceinline__ void stats_accumulate4(Stats4& a, double* __restrict__ stats, bool uniform, int n, int c, int ch,
                                                   const float (&v)[4], bool active) {
     if (stats == nullptr || !active) return;
-    if (uniform) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a.s[j] += (double)v[j]; a.q[j] += (double)v[j] * (double)v[j]; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double* st = stats + ((size_t)n * c + ch + j) * 2;
-            atomicAdd(st, (double)v[j]);
-            atomicAdd(st + 1, (double)v[j] * v[j]);
-        }
-    }
+    for (int j = 0; j < 4; ++j) { a.s[j] += (double)v[j]; a.q[j] += (double)v[j] * (double)v[j]; }
+    if (!uniform) a.n = n;                                          // (one chunk per block there: one image per thread)
 }
 // every thread of the block calls it once, after its last element (n: the block's image, ch: the thread's first channel)
 __device__ __forceinline__ void stats_flush4(Stats4& a, double* __restrict__ stats, bool uniform, int n, int c, int ch) {
-    if (stats == nullptr || !uniform) return;                       // block-uniform
+    if (stats == nullptr) return;                                   // block-uniform
     __shared__ double red_stats[2048];                              // [wave * slots + slot][channel][2]: 4 * slots * 2c <= 2048
+    if (!uniform) {
+        // maps so small that a block of 256 elements straddles images (or c / 4 is not a power of two): the block's sums
+        // are keyed by (image, channel) in LDS and leave as one atomic pair per key -- per-element global atomics made
+        // the 8x8 maps of the deepest cells the slowest depthwise launches of the search step (62 us for 2 blocks)
+        __shared__ int n_lo, n_hi;
+        if (threadIdx.x == 0) { n_lo = 0x7fffffff; n_hi = -1; }
+        __syncthreads();
+        if (a.n >= 0) { atomicMin(&n_lo, a.n); atomicMax(&n_hi, a.n); }
+        __syncthreads();
+        const int lo = n_lo, span = n_hi - lo + 1;                  // block-uniform; span <= 0: no active thread
+        if (span <= 0) return;
+        if ((long)span * 2 * c > 2048) {                            // (cannot happen with >= c/4 elements per image; kept safe)
+            if (a.n >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double* st = stats + ((size_t)a.n * c + ch + j) * 2;
+                    atomicAdd(st, a.s[j]);
+                    atomicAdd(st + 1, a.q[j]);
+                }
+            }
+            return;
+        }
+        for (int i = threadIdx.x; i < span * 2 * c; i += blockDim.x) red_stats[i] = 0.0;
+        __syncthreads();
+        if (a.n >= 0) {
+            double* dst = red_stats + (size_t)(a.n - lo) * 2 * c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { atomicAdd(dst + (ch + j) * 2, a.s[j]); atomicAdd(dst + (ch + j) * 2 + 1, a.q[j]); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < span * 2 * c; i += blockDim.x) atomicAdd(stats + (size_t)lo * c * 2 + i, red_stats[i]);
+        return;
+    }
     const int cv = c >> 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

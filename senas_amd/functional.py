@@ -124,6 +124,7 @@ class _NoSpan(object):
 TIMER = None
 MAX_STACK = _lib.MAX_STACK
 MAX_BNRELU = _lib.MAX_BNRELU
+MAX_DSTAIL = _lib.MAX_DSTAIL
 _NOSPAN = _NoSpan()
 
 # (weight data_ptr, direction) -> packed fragment image kept fresh by the INSTALLED senas_amd.packing.WeightPacker;

@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(WgradGeom g, const fl
 // the taps of problems [p0, p1) (KS x KS, weights at wl: [problem][tap][C]) added to the 4 x 4 outputs of this thread
 template <int KS, int S>
 __device__ __forceinline__ void dw_dgrad_x4_accumulate(const GatherGeom& g, const DwTab& tab, int p0, int p1, const float* wl, int C, int c,
-                                                       int n, int oy, int ox0, float (&acc)[4][4]) {
+                                                       int n, int oy, int ox0, float (&acc)[4][4], int first = 0, int step = 1) {
     constexpr int TAPS = KS * KS, COLS = 3 * S + KS;
     const int ix0 = ox0 * S - g.pad;
-    for (int p = p0; p < p1; ++p) {
+    for (int p = p0 + first; p < p1; p += step) {
         const float* __restrict__ in = tab.a[p];
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
@@ -503,7 +503,10 @@ __device__ __forceinline__ void dw_dgrad_x4_accumulate(const GatherGeom& g, cons
     }
 }
 
-template <int KSA, int KSB, int S>
+// PS = 4 (small maps: the launch is a handful of blocks and each thread's walk over all problems and taps IS the launch
+// time): four adjacent lanes share one output and deal the problems among themselves -- lane q takes problems q, q + 4, ..
+// of the 3x3 group and, shifted by ka, of the 5x5 group -- then add up over the quad.
+template <int KSA, int KSB, int S, int PS>
 __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom ga, GatherGeom gb, int ka, DwTab tab, int k, int flip,
                                                                     float* __restrict__ out, long total) {
     extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C], group a first
@@ -519,8 +522,9 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g
         wl[na + i] = tab.w[ka + p][cc * TB + (flip ? TB - 1 - t : t)];
     }
     __syncthreads();
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) / PS;
+    const int sp = PS > 1 ? (int)(threadIdx.x % PS) : 0;
+    if (idx >= total) return;                                        // (the PS lanes of an output leave together)
     const int cv = C >> 2, wq = ga.wout >> 2;
     const int c = (int)(idx % cv) * 4;
     long r = idx / cv;
@@ -532,8 +536,20 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
-    dw_dgrad_x4_accumulate<KSA, S>(ga, tab, 0, ka, wl, C, c, n, oy, ox0, acc);
-    if (k > ka) dw_dgrad_x4_accumulate<KSB, S>(gb, tab, ka, k, wl + na, C, c, n, oy, ox0, acc);
+    dw_dgrad_x4_accumulate<KSA, S>(ga, tab, 0, ka, wl, C, c, n, oy, ox0, acc, sp, PS);
+    if (k > ka) dw_dgrad_x4_accumulate<KSB, S>(gb, tab, ka, k, wl + na, C, c, n, oy, ox0, acc, PS > 1 ? (sp + ka) % PS : 0, PS);
+    if (PS > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[j][q];
+#pragma unroll
+                for (int m = 1; m < PS; m <<= 1) v += __shfl_xor(v, m, 64);
+                acc[j][q] = v;
+            }
+        if (sp != 0) return;
+    }
     const size_t o = (((size_t)n * ga.hout + oy) * ga.wout + ox0) * C + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) stv<4>(out + o + (size_t)j * C, acc[j]);
@@ -1240,8 +1256,13 @@ extern "C" int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, con
     const bool flip = flips(ga) && (kb == 0 || flips(gb));
     if ((g->transposed || flip) && dw_x4_ok(gga, 0) && dw_x4_ok(ggb, 0)) {                  // a plain gather: four output columns per thread
         const long total4 = (long)g->n * g->hi * (g->wi / 4) * (g->ci / 4);
-        dim3 grid4((unsigned)((total4 + 255) / 256));
-#define SENAS_X4(KA_, KB_, S_) hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KA_, KB_, S_>), grid4, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, flip ? 1 : 0, dx, total4)
+        const bool split = k >= 3 && total4 <= 128L * 256;              // at most 128 blocks: latency-bound, four lanes per output
+        dim3 grid4((unsigned)(((split ? 4 : 1) * total4 + 255) / 256));
+#define SENAS_X4(KA_, KB_, S_)                                                                                                          \
+    do {                                                                                                                                 \
+        if (split) hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KA_, KB_, S_, 4>), grid4, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, flip ? 1 : 0, dx, total4); \
+        else hipLaunchKernelGGL((dwconv_multi_dgrad_x4_kernel<KA_, KB_, S_, 1>), grid4, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, flip ? 1 : 0, dx, total4); \
+    } while (0)
         if (kb > 0) { if (gga.stride == 1) SENAS_X4(3, 5, 1); else SENAS_X4(3, 5, 2); }
         else if (g->kh == 3) { if (gga.stride == 1) SENAS_X4(3, 3, 1); else SENAS_X4(3, 3, 2); }
         else { if (gga.stride == 1) SENAS_X4(5, 5, 1); else SENAS_X4(5, 5, 2); }

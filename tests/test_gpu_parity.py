@@ -1319,7 +1319,9 @@ def test_bnrelu_multi_vs_torch(case):
                                   (4, 1, 8, 12, 12, 3, 1, False), (2, 4, 16, 9, 11, 5, 1, False), (3, 2, 32, 12, 12, 3, 2, True),
                                   # kernel size 0: dep_sep_conv_3 and dep_sep_conv_5 of the same edges share the launches (3, 5, 3, 5, ...)
                                   (6, 4, 32, 16, 16, 0, 1, False), (6, 2, 32, 16, 24, 0, 2, False), (6, 2, 32, 8, 12, 0, 2, True),
-                                  (2, 2, 8, 12, 12, 0, 1, False), (4, 3, 8, 9, 11, 0, 1, False), (8, 1, 16, 8, 8, 0, 2, True)])
+                                  (2, 2, 8, 12, 12, 0, 1, False), (4, 3, 8, 9, 11, 0, 1, False), (8, 1, 16, 8, 8, 0, 2, True),
+                                  # past 128 blocks of outputs the data gradient is one thread per output again (no problem split)
+                                  (6, 4, 8, 128, 144, 0, 1, False), (6, 4, 8, 128, 144, 0, 2, False)])
 def test_dwconv_multi_vs_single(case):
     """senas_dwconv_pair_* (k depthwise convolutions of one input, 3x3 and 5x5 mixed: one forward launch, one data-gradient
     launch summing over the problems, one weight-gradient launch + sums) against the same convolutions run one by one

@@ -78,10 +78,18 @@ def _geometry(kind: str):
     return (1 if kind == 'norm' else 2), kind == 'up'
 
 
-def conv_bn(p: View, x, k, kind, dil, training):
-    """ConvBn -- utils/operations.py:89-95 (Sequential: 0 = conv, 1 = norm)."""
+def dropout2d(x, dp, training):
+    """nn.Dropout2d(dp, inplace=False) in front of a convolution when dp > 0 -- utils/operations.py:121-122 (whole
+    channels of an image are zeroed, the rest scaled by 1 / (1 - dp); the identity in eval mode)."""
+    return F.dropout2d(x, dp, training) if dp > 0 else x
+
+
+def conv_bn(p: View, x, k, kind, dil, training, dp=0.0):
+    """ConvBn -- utils/operations.py:89-95 (Sequential: [dropout,] conv, norm: the child indices shift by d = 1 with
+    dropout, build_weight :118-130)."""
     stride, tr = _geometry(kind)
-    return batch_norm(p.sub(1), conv(x, p['0.weight'], k, stride, dil, tr), training)
+    d = 1 if dp > 0 else 0
+    return batch_norm(p.sub(d + 1), conv(dropout2d(x, dp, training), p['%d.weight' % d], k, stride, dil, tr), training)
 
 
 def se_block(p: View, x):
@@ -92,19 +100,21 @@ def se_block(p: View, x):
     return x * y.view(n, c, 1, 1)
 
 
-def conv_bn_se(p: View, x, k, kind, training):
-    """ConvBnSe -- utils/operations.py:98-104 (0 conv, 1 norm, 2 se)."""
-    return se_block(p.sub(2), conv_bn(p, x, k, kind, 1, training))
+def conv_bn_se(p: View, x, k, kind, training, dp=0.0):
+    """ConvBnSe -- utils/operations.py:98-104 ([dropout,] conv, norm, se)."""
+    return se_block(p.sub((1 if dp > 0 else 0) + 2), conv_bn(p, x, k, kind, 1, training, dp))
 
 
-def dep_sep_conv(p: View, x, k, kind, training):
-    """DepSepConv -- utils/operations.py:107-115 (0 dw conv, 1 norm, 2 relu, 3 1x1 conv, 4 norm)."""
+def dep_sep_conv(p: View, x, k, kind, training, dp=0.0):
+    """DepSepConv -- utils/operations.py:107-115 ([dropout,] dw conv, norm, relu, [dropout,] 1x1 conv, norm: children
+    0 1 2 3 4 without dropout, 1 2 3 5 6 with)."""
     stride, tr = _geometry(kind)
     c = x.shape[1]
-    y = conv(x, p['0.weight'], k, stride, 1, tr, groups=c)
-    y = F.relu(batch_norm(p.sub(1), y, training))
-    y = conv(y, p['3.weight'], 1)
-    return batch_norm(p.sub(4), y, training)
+    d = 1 if dp > 0 else 0
+    y = conv(dropout2d(x, dp, training), p['%d.weight' % d], k, stride, 1, tr, groups=c)
+    y = F.relu(batch_norm(p.sub(d + 1), y, training))
+    y = conv(dropout2d(y, dp, training), p['%d.weight' % (2 * d + 3)], 1)
+    return batch_norm(p.sub(2 * d + 4), y, training)
 
 
 def adapter(p: View, y, training):
@@ -122,8 +132,9 @@ def bilinear_x2(x):
     return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
 
 
-def candidate(name: str, kind: str, p: View, x, training: bool):
-    """OPS[name](c_in, c_ot, op_type, dp=0).forward(x) -- utils/operations.py:8-21,57-78."""
+def candidate(name: str, kind: str, p: View, x, training: bool, dp: float = 0.0):
+    """OPS[name](c_in, c_ot, op_type, dp).forward(x) -- utils/operations.py:8-21,57-78 (dp reaches the weighted
+    candidates only: build_ops :61-77; the search cell passes 0, search/cell.py:29)."""
     stride, _ = _geometry(kind)
     if name == 'none':            # ZeroOp(stride=1): x.mul(0.) -- operations.py:9,155-164
         return adapter(p, x.mul(0.), training)
@@ -136,17 +147,17 @@ def candidate(name: str, kind: str, p: View, x, training: bool):
     if name == 'up_sample':
         return adapter(p, bilinear_x2(x), training)
     if name == 'conv_3':
-        return conv_bn(p, x, 3, kind, 1, training)
+        return conv_bn(p, x, 3, kind, 1, training, dp)
     if name == 'se_conv_3':
-        return conv_bn_se(p, x, 3, kind, training)
+        return conv_bn_se(p, x, 3, kind, training, dp)
     if name == 'dil_3_conv_5':
-        return conv_bn(p, x, 5, kind, 3, training)
+        return conv_bn(p, x, 5, kind, 3, training, dp)
     if name == 'dil_2_conv_5':
-        return conv_bn(p, x, 5, kind, 2, training)
+        return conv_bn(p, x, 5, kind, 2, training, dp)
     if name == 'dep_sep_conv_3':
-        return dep_sep_conv(p, x, 3, kind, training)
+        return dep_sep_conv(p, x, 3, kind, training, dp)
     if name == 'dep_sep_conv_5':
-        return dep_sep_conv(p, x, 5, kind, training)
+        return dep_sep_conv(p, x, 5, kind, training, dp)
     raise NotImplementedError(name)
 
 
@@ -203,8 +214,8 @@ def search_cell(p: View, in0, in1, w_norm, w_chg, betas, cell_type, nodes, train
     return post_process(p.sub('post_process'), torch.cat(states[-nodes:], 1), training)
 
 
-def build_cell(p: View, in0, in1, genotype: Genotype, cell_type, training):
-    """BuildCell.forward -- models/senas_model.py:50-64."""
+def build_cell(p: View, in0, in1, genotype: Genotype, cell_type, training, dropout_prob=0.0):
+    """BuildCell.forward -- models/senas_model.py:50-64 (dropout_prob goes to every candidate op, :38-46)."""
     gene = genotype.up if cell_type == 'up' else genotype.down
     concat = genotype.up_concat if cell_type == 'up' else genotype.down_concat
     states = [preprocess0(p.sub('preprocess0'), in0, cell_type, training), F.relu(in1)]
@@ -212,7 +223,7 @@ def build_cell(p: View, in0, in1, genotype: Genotype, cell_type, training):
         hs = []
         for e in (2 * i, 2 * i + 1):
             name, idx = gene[e]
-            hs.append(candidate(name, edge_kind(cell_type, idx), p.sub('_ops.%d' % e), states[idx], training))
+            hs.append(candidate(name, edge_kind(cell_type, idx), p.sub('_ops.%d' % e), states[idx], training, dropout_prob))
         states.append(F.relu(hs[0] + hs[1]))
     return post_process(p.sub('post_process'), torch.cat([states[i] for i in concat], 1), training)
 
@@ -284,14 +295,15 @@ def nas_forward(sd, x, depth=5, nodes=3, supervision=False, training=True):
     return [run_head(o) for o in outs] if supervision else [run_head(outs[-1])]
 
 
-def derived_forward(sd, x, genotype: Genotype, depth=5, supervision=False, training=True):
-    """SenasModel.forward -- models/senas_model.py:146-179."""
+def derived_forward(sd, x, genotype: Genotype, depth=5, supervision=False, training=True, dropout_prob=0.0):
+    """SenasModel.forward -- models/senas_model.py:146-179 (dropout_prob: the down and up cells, :110-111,133-134; the
+    head's cell is built without, :143)."""
     net = View(sd, '')
     s0, c0 = stem(net, x, training)
     outs: List[Optional[torch.Tensor]] = [c0]
     for j in range(1, depth):
         prev = s0 if j == 1 else outs[-2]
-        outs.append(build_cell(net.sub('blocks.0.%d' % j), prev, outs[-1], genotype, 'down', training))
+        outs.append(build_cell(net.sub('blocks.0.%d' % j), prev, outs[-1], genotype, 'down', training, dropout_prob))
     for j in reversed(range(depth - 1)):
         for i in range(1, depth - j):
             gi = sum(range(i + j)) + j
@@ -299,7 +311,7 @@ def derived_forward(sd, x, genotype: Genotype, depth=5, supervision=False, train
                 outs[i + j] = None
                 continue
             in0 = torch.cat([outs[t] for t in range(j, i + j) if outs[t] is not None], 1)
-            outs[i + j] = build_cell(net.sub('blocks.%d.%d' % (i, j)), in0, outs[i + j], genotype, 'up', training)
+            outs[i + j] = build_cell(net.sub('blocks.%d.%d' % (i, j)), in0, outs[i + j], genotype, 'up', training, dropout_prob)
     head = net.sub('head_block.0')
 
     def run_head(o):

@@ -287,7 +287,7 @@ class FoldedForward(object):
     def term(self, op, x):
         if isinstance(op, ConvBnSe):
             # the gate needs the per-image mean of the normalised output: raw convolution with channel sums
-            conv, bn, se = op[0], op[1], op[2]
+            conv, bn, se = op.conv, op.norm, op.se          # (eval mode: a Dropout2d in front of the convolution is the identity)
             g = self._geom(conv, x)
             stats = F.new_stats(g.n, g.co, x)
             z = self._conv_plain(conv, x, False, stats)
@@ -297,13 +297,13 @@ class FoldedForward(object):
             gate = torch.sigmoid(hid @ se.excitation[2].weight.t())
             return _Raw(z, gate * scale, gate * shift)
         if isinstance(op, ConvBn):
-            return _Lazy(op[0], x, False, *self._aff(op[1]))
+            return _Lazy(op.conv, x, False, *self._aff(op.norm))
         if isinstance(op, DepSepConv):
-            s1, b1 = self._aff(op[1])
-            mid = self._conv_epilogue(op[0], x, False, s1, b1, relu=True)
+            s1, b1 = self._aff(op.norm1)
+            mid = self._conv_epilogue(op.dw, x, False, s1, b1, relu=True)
             if mid is None:
-                mid = self._combine([_Raw(self._conv_plain(op[0], x, False), s1, b1)], relu=True)
-            return _Lazy(op[3], mid, False, *self._aff(op[4]))
+                mid = self._combine([_Raw(self._conv_plain(op.dw, x, False), s1, b1)], relu=True)
+            return _Lazy(op.pw, mid, False, *self._aff(op.norm2))
         if isinstance(op, AdapterBlock):
             scale, shift = self._aff(op.norm)
             if isinstance(op.module, ZeroOp):

@@ -78,13 +78,25 @@ def build_norm(c_ot, affine):
 
 
 def build_weight(c_in, c_ot, kernel_size, stride, dilation, use_transpose, output_padding, dropout_rate, groups=1):
-    if dropout_rate > 0:
-        raise NotImplementedError('dropout > 0 is not wired (every shipped config and driver uses dp = 0)')
+    """utils/operations.py:118-130: [Dropout2d(p) when p > 0,] bias-free Conv2d / ConvTranspose2d.  The Dropout2d keeps its
+    place in the Sequential (the reference's numeric child names, hence its state_dict keys, shift by one with it)."""
     pad = get_same_padding(kernel_size) * dilation
+    ops = [nn.Dropout2d(dropout_rate, inplace=False)] if dropout_rate > 0 else []
     if use_transpose:
-        return [nn.ConvTranspose2d(c_in, c_ot, kernel_size, stride=stride, padding=pad, output_padding=output_padding,
-                                   groups=groups, bias=False, dilation=dilation)]
-    return [nn.Conv2d(c_in, c_ot, kernel_size, stride=stride, padding=pad, dilation=dilation, groups=groups, bias=False)]
+        return ops + [nn.ConvTranspose2d(c_in, c_ot, kernel_size, stride=stride, padding=pad, output_padding=output_padding,
+                                         groups=groups, bias=False, dilation=dilation)]
+    return ops + [nn.Conv2d(c_in, c_ot, kernel_size, stride=stride, padding=pad, dilation=dilation, groups=groups, bias=False)]
+
+
+def _dropped(drop, x, in_relu=False):
+    """x as the convolution behind a Dropout2d sees it, and whether the ReLU is still to be applied on load.  The mask is
+    torch's (one Bernoulli draw per (image, channel), scaled by 1 / (1 - p), graph-safe Philox state); an identity in
+    eval mode.  Only the derived network can ask for it (models/senas_model.py:40-46; the search cell builds dp = 0)."""
+    if drop is None or not drop.training or drop.p == 0:
+        return x, in_relu
+    if in_relu:
+        x = F.relu(x)
+    return drop(x), False
 
 
 class ZeroOp(nn.Module):
@@ -129,10 +141,16 @@ class ConvBn(_Op):
                  dropout=0):
         super().__init__(*build_weight(c_in, c_ot, kernel_size, stride, dilation, transpose, output_padding, dropout),
                          build_norm(c_ot, affine))
+        self._d = 1 if dropout > 0 else 0                # children: [Dropout2d,] conv, norm
+
+    drop = property(lambda self: self[0] if self._d else None)
+    conv = property(lambda self: self[self._d])
+    norm = property(lambda self: self[self._d + 1])
 
     def raw(self, x, in_relu=False):
-        z, st = run_conv(self[0], x, in_relu, want_stats=self[1].training)
-        return Term(z, self[1], stats=st)
+        x, in_relu = _dropped(self.drop, x, in_relu)
+        z, st = run_conv(self.conv, x, in_relu, want_stats=self.norm.training)
+        return Term(z, self.norm, stats=st)
 
 
 class ConvBnSe(_Op):
@@ -140,10 +158,17 @@ class ConvBnSe(_Op):
                  dropout=0):
         super().__init__(*build_weight(c_in, c_ot, kernel_size, stride, dilation, transpose, output_padding, dropout),
                          build_norm(c_ot, affine), SEBlock(c_ot))
+        self._d = 1 if dropout > 0 else 0                # children: [Dropout2d,] conv, norm, se
+
+    drop = property(lambda self: self[0] if self._d else None)
+    conv = property(lambda self: self[self._d])
+    norm = property(lambda self: self[self._d + 1])
+    se = property(lambda self: self[self._d + 2])
 
     def raw(self, x):
-        z, st = run_conv(self[0], x)
-        return Term(z, self[1], se=self[2], stats=st)
+        x, _ = _dropped(self.drop, x)
+        z, st = run_conv(self.conv, x)
+        return Term(z, self.norm, se=self.se, stats=st)
 
 
 class DepSepConv(_Op):
@@ -152,12 +177,22 @@ class DepSepConv(_Op):
         depth = build_weight(c_in, c_in, kernel_size, stride, dilation, transpose, output_padding, dropout, groups=c_in)
         point = build_weight(c_in, c_ot, 1, 1, 1, False, 0, dropout)
         super().__init__(*depth, build_norm(c_in, affine), build_activation(), *point, build_norm(c_ot, affine))
+        self._d = 1 if dropout > 0 else 0                # children: [Dropout2d,] dw conv, norm, relu, [Dropout2d,] 1x1 conv, norm
+
+    drop = property(lambda self: self[0] if self._d else None)
+    dw = property(lambda self: self[self._d])
+    norm1 = property(lambda self: self[self._d + 1])
+    drop2 = property(lambda self: self[self._d + 3] if self._d else None)
+    pw = property(lambda self: self[2 * self._d + 3])
+    norm2 = property(lambda self: self[2 * self._d + 4])
 
     def raw(self, x):
-        z1, st1 = run_conv(self[0], x, want_stats=self[1].training)
-        mid = F.bn_combine([Term(z1, self[1], stats=st1)], relu=True)
-        z2, st = run_conv(self[3], mid, want_stats=self[4].training)
-        return Term(z2, self[4], stats=st)
+        x, _ = _dropped(self.drop, x)
+        z1, st1 = run_conv(self.dw, x, want_stats=self.norm1.training)
+        mid = F.bn_combine([Term(z1, self.norm1, stats=st1)], relu=True)
+        mid, _ = _dropped(self.drop2, mid)
+        z2, st = run_conv(self.pw, mid, want_stats=self.norm2.training)
+        return Term(z2, self.norm2, stats=st)
 
 
 class AdapterBlock(nn.Module):

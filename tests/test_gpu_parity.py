@@ -986,6 +986,69 @@ def test_derived_random_genotypes_vs_oracle(seed):
     assert not bad, 'gradients off: ' + ', '.join('%s %.2e (oracle noise %.2e)' % (k, errs[k], noise[k]) for k in bad[:6])
 
 
+def _channel_mask_dropout2d(x, p=0.5, training=True, inplace=False):
+    """A deterministic stand-in for torch.nn.functional.dropout2d, the same on the CPU (oracle) and on the device: whole
+    (image, channel) planes are dropped by a fixed rule of (n, c, height), the rest scaled by 1 / (1 - p)."""
+    if not training or p == 0:
+        return x
+    n, c = x.shape[:2]
+    idx = torch.arange(n, device=x.device).view(n, 1) * 7 + torch.arange(c, device=x.device).view(1, c) * 3 + x.shape[2]
+    keep = (idx % 4 != 0).to(x.dtype) / (1.0 - p)
+    return x * keep.view(n, c, 1, 1)
+
+
+@pytest.mark.parametrize('seed', [21, 22])
+def test_derived_dropout_vs_oracle(seed, monkeypatch):
+    """SenasModel(dropout_prob > 0) (models/senas_model.py:80,110-111,133-134 -> utils/operations.py:121-122): a Dropout2d
+    in front of every convolution of the candidate ops.  With one deterministic mask on both sides, training-mode logits,
+    loss and gradients must match the oracle (placement of the dropouts, the shifted child indices / state_dict keys);
+    in eval mode the network with dropout equals the one without."""
+    from oracle import senas_ref as R
+    from senas_amd.genotype import Genotype
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    monkeypatch.setattr(torch.nn.functional, 'dropout2d', _channel_mask_dropout2d)
+    rng = np.random.RandomState(seed)
+    down, up = _random_genotype(rng, 3)
+    if seed == 21:      # every weighted candidate at least once
+        down[0], down[1], up[1], up[2] = ('dep_sep_conv_5', down[0][1]), ('se_conv_3', down[1][1]), ('dil_2_conv_5', up[1][1]), ('dep_sep_conv_3', up[2][1])
+    geno = Genotype(down=down, down_concat=range(2, 5), up=up, up_concat=range(2, 5), gamma=[1, 1, 1])
+    net = SenasModel(2, 1, c=8, depth=4, dropout_prob=0.25, genotype=geno)
+    _randomize(net, seed)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert any(k.endswith('_ops.0.1.weight') for k in sd), 'the convolution behind a Dropout2d is child 1'
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    gio.share_stem(sd)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 1, 32, 32, generator=gen)
+    y = torch.randint(0, 2, (2, 32, 32), generator=gen)
+    ref = R.derived_forward(sd, x, R.Genotype(*geno), depth=4, dropout_prob=0.25)[-1]
+    ref_loss = R.dice_ce_loss(ref, y)
+    ref_loss.backward()
+    plain = R.derived_forward({k: v.detach() for k, v in sd.items()}, x, R.Genotype(*geno), depth=4, dropout_prob=0.25, training=False)[-1]
+    net = net.to(dev()).train()
+    out = net(x.to(dev()))
+    loss = SegmentationLosses('dice_ce')(out, y.to(dev()))
+    loss.backward()
+    close(out[-1], ref.detach().numpy(), 'logits with dropout', rel=1e-3)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    got = grads_of(net)
+    checked = 0
+    for k in ('stem0.0.weight', 'head_block.0.segmentation_head.1.weight'):
+        if k in got and sd[k].grad is not None:
+            close(torch.from_numpy(got[k]), sd[k].grad.numpy(), 'grad ' + k, rel=2e-2)
+            checked += 1
+    assert checked >= 1
+    # the mask really bites (training differs from eval), and in eval mode the dropouts are the identity
+    assert float((plain - ref.detach()).abs().max()) > 1e-3
+    net.eval()
+    with torch.no_grad():
+        ev = net(x.to(dev()))[-1]
+    close(ev, plain.numpy(), 'eval logits (dropout is the identity)', rel=1e-3)
+
+
 # ---------------------------------------------------------------------------------------------- inference pass (8f-4)
 @pytest.mark.parametrize('folded', [False, True])
 @pytest.mark.parametrize('graphed', [False, True])

@@ -243,3 +243,36 @@ def test_packers_do_not_revalidate_each_other():
     step.close()
     ev.packer.uninstall()
     assert F.SINK is None
+
+
+@pytest.mark.gpu
+def test_train_step_with_dropout_replays_fresh_masks():
+    """SenasModel(dropout_prob > 0) under the HIP-graph train step: the captured Dropout2d draws a NEW mask at every replay
+    (torch's graph-safe Philox offset), so two replays on the same batch with a zero learning rate give different losses,
+    and eval mode stays deterministic."""
+    import torch
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.step import TrainStep
+    from senas_amd.utils import weights_init
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    net = SenasModel(2, 1, c=8, depth=3, dropout_prob=0.3, genotype=senas_node_4).to(dev)
+    net.apply(weights_init)
+    net.train()
+    x = torch.randn(2, 1, 32, 32, device=dev)
+    y = torch.randint(0, 2, (2, 32, 32), device=dev)
+    opt = torch.optim.SGD(net.parameters(), lr=0.0, momentum=0.0)
+    step = TrainStep(net, SegmentationLosses('dice_ce'), opt, x, y, use_graph=True)
+    try:
+        assert step.graphed
+        losses = [float(step()) for _ in range(4)]
+    finally:
+        step.close()
+    assert all(l == l and abs(l) < 1e3 for l in losses)
+    assert len({round(l, 6) for l in losses}) > 1, 'every replay used the same dropout mask: %r' % (losses,)
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x)[-1], net(x)[-1]
+    assert torch.equal(a, b)

@@ -354,3 +354,18 @@ def test_shipped_config_matches_the_reference_values():
     assert _parse_genotype(str(senas_node_4)) == senas_node_4
     with pytest.raises(ValueError):
         _parse_genotype('__import__("os").system("true")')
+
+
+def test_dropout_keeps_the_reference_child_indices():
+    """utils/operations.py:118-130: with dp > 0 a Dropout2d is child 0 of the op's Sequential and the convolution child 1
+    (DepSepConv: 0 1 2 3 | 4 5 6) -- the state_dict keys of SenasModel(dropout_prob > 0) shift accordingly."""
+    from senas_amd.operations import ConvBn, ConvBnSe, DepSepConv
+    import torch.nn as nn
+    a, b, c = ConvBn(8, 8, 3, dropout=0.1), ConvBnSe(8, 8, 3, dropout=0.1), DepSepConv(8, 8, 3, dropout=0.1)
+    assert isinstance(a[0], nn.Dropout2d) and a.conv is a[1] and a.norm is a[2]
+    assert isinstance(b[0], nn.Dropout2d) and b.conv is b[1] and b.norm is b[2] and b.se is b[3]
+    assert [type(m).__name__ for m in c] == ['Dropout2d', 'Conv2d', 'BatchNorm2d', 'ReLU', 'Dropout2d', 'Conv2d', 'BatchNorm2d']
+    assert c.dw is c[1] and c.norm1 is c[2] and c.pw is c[5] and c.norm2 is c[6]
+    plain = DepSepConv(8, 8, 3)
+    assert plain.dw is plain[0] and plain.norm1 is plain[1] and plain.pw is plain[3] and plain.norm2 is plain[4] and plain.drop is None
+    assert sorted(k for k in a.state_dict() if k.endswith('weight')) == ['1.weight', '2.weight']

@@ -360,6 +360,88 @@ __global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom ga,
     else dwconv_x4_body<KSB, S>(gb, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
 }
 
+// ConvTranspose2d(k, stride 2, padding k / 2, output_padding 1), depthwise: the UP candidates' dep_sep_conv_3 / _5
+// (utils/operations.py:58-60,107-115).  One thread = the 2 x 2 output quad of one input-grid position, 4 channels: output
+// (2 qy + py, 2 qx + px) takes the taps with ky = (py + pad) mod 2 (mod 2) from input row qy + (py + pad - ky) / 2, so the quad
+// reads a 3 x 3 (5x5) or 2 x 2 (3x3) neighbourhood ONCE and every weight once -- the one-output-per-thread gather walked
+// all k*k taps per output and threw three quarters of them away on the parity test.
+template <int KS>
+__device__ __forceinline__ void dwconv_t2_quad_body(const GatherGeom& g, const float* __restrict__ in, const float* __restrict__ w,
+                                                    float* __restrict__ out, double* __restrict__ stats, long total, int P) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [tap][C]
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    constexpr int LO = KS == 3 ? 0 : -1;                            // first neighbourhood row / column relative to (qy, qx)
+    const int C = g.cout;
+    for (int i = threadIdx.x; i < TAPS * C; i += 256) {
+        const int t = i / C, cc = i - t * C;
+        wl[i] = w[cc * TAPS + t];
+    }
+    __syncthreads();
+    Stats4 acc_st;
+    stats_init4(acc_st);
+    const bool uniform = P > 0;
+    const int chunks = uniform ? P : 1;
+    const int cv = C >> 2;
+    int n_blk = 0, c_thr = 0;
+    for (int kk = 0; kk < chunks; ++kk) {
+        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        const bool active = idx < total;
+        if (!active) idx = total - 1;
+        const int c = (int)(idx % cv) * 4;
+        long r = idx / cv;
+        const int qx = (int)(r % g.win);
+        r /= g.win;
+        const int qy = (int)(r % g.hin), n = (int)(r / g.hin);
+        n_blk = n; c_thr = c;
+        float4 v[2 - LO][2 - LO];
+#pragma unroll
+        for (int dy = LO; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = LO; dx <= 1; ++dx) {
+                const int iy = qy + dy, ix = qx + dx;
+                const bool ok = iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+                v[dy - LO][dx - LO] = ok ? *reinterpret_cast<const float4*>(in + ((size_t)(n * g.hin + iy) * g.win + ix) * C + c)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    if (((py + PAD - ky) & 1) != 0) continue;        // (compile-time)
+                    const int dy = (py + PAD - ky) / 2;              // -1, 0, 1 (exact: the numerator is even)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        if (((px + PAD - kx) & 1) != 0) continue;
+                        const int dx = (px + PAD - kx) / 2;
+                        const float4 a = v[dy - LO][dx - LO];
+                        const float4 wt = *reinterpret_cast<const float4*>(wl + (ky * KS + kx) * C + c);
+                        acc[0] = fmaf(a.x, wt.x, acc[0]); acc[1] = fmaf(a.y, wt.y, acc[1]);
+                        acc[2] = fmaf(a.z, wt.z, acc[2]); acc[3] = fmaf(a.w, wt.w, acc[3]);
+                    }
+                }
+                if (active) stv<4>(out + (((size_t)n * g.hout + 2 * qy + py) * g.wout + 2 * qx + px) * C + c, acc);
+                stats_accumulate4(acc_st, stats, uniform, n, C, c, acc, active);
+            }
+    }
+    stats_flush4(acc_st, stats, uniform, n_blk, C, c_thr);
+}
+
+template <int KSA, int KSB>
+__global__ __launch_bounds__(256) void dwconv_multi_fwd_t2_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
+                                                                  long total, int P) {
+    const int p = blockIdx.y;
+    if (KSA == KSB || p < ka) dwconv_t2_quad_body<KSA>(ga, in, tab.w[p], tab.out[p], tab.stats[p], total, P);
+    else dwconv_t2_quad_body<KSB>(gb, in, tab.w[p], tab.out[p], tab.stats[p], total, P);
+}
+
+static bool dw_t2_quad_ok(const GatherGeom& gg, int transposed) {
+    return transposed && gg.stride == 2 && gg.dil == 1 && gg.kh == gg.kw && (gg.kh == 3 || gg.kh == 5) && gg.pad == gg.kh / 2 &&
+           gg.cout % 4 == 0 && gg.cin == gg.cout && gg.hout == 2 * gg.hin && gg.wout == 2 * gg.win;
+}
+
 // data gradient of the same: dx = sum over problems of the (transposed / plain) gather of dy_p with w_p, one pass
 template <bool TG>
 __global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom ga, GatherGeom gb, int ka, DwTab tab, int k, float* __restrict__ out,
@@ -1226,6 +1308,17 @@ extern "C" int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const se
         else { if (g->stride == 1) SENAS_X4(5, 5, 1); else SENAS_X4(5, 5, 2); }
 #undef SENAS_X4
         return launch_status("dwconv_pair_fwd (x4)");
+    }
+    if (dw_t2_quad_ok(gga, g->transposed) && dw_t2_quad_ok(ggb, g->transposed)) {         // stride-2 transposed: one 2 x 2 output quad per thread
+        const long per_imgq = (long)g->hi * g->wi * (g->co / 4), totalq = per_imgq * g->n;
+        const int Pq = want ? stats_chunks_per_block(per_imgq, g->co, totalq) : 0;
+        dim3 gridq((unsigned)((totalq + 256L * (Pq > 0 ? Pq : 1) - 1) / (256L * (Pq > 0 ? Pq : 1))), k);
+#define SENAS_T2(KA_, KB_) hipLaunchKernelGGL((dwconv_multi_fwd_t2_kernel<KA_, KB_>), gridq, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, totalq, Pq)
+        if (kb > 0) SENAS_T2(3, 5);
+        else if (g->kh == 3) SENAS_T2(3, 3);
+        else SENAS_T2(5, 5);
+#undef SENAS_T2
+        return launch_status("dwconv_pair_fwd (transposed quads)");
     }
     const long per_img = (long)g->ho * g->wo * (g->co / 4);
     const long total = per_img * g->n;

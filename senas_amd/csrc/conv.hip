@@ -1263,7 +1263,12 @@ bool dw_pair_ok(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, in
 long dw_multi_wgrad_blocks(const senas_conv_geom* g, int* chunk) {
     const long total = (long)g->n * (g->transposed ? (long)g->hi * g->wi : (long)g->ho * g->wo);
     const long lanes = 256 / (g->ci / 4);
-    long nblk = (total + 2 * lanes - 1) / (2 * lanes);
+    // every block ends in a fold of taps x 4 partial sums per thread (DPP + LDS) that costs several times the MACs of one
+    // pixel: give a thread 16 or 8 pixels where the map is big enough to still fill the chip with 256 blocks per problem, 2 otherwise
+    const long fine = (total + 2 * lanes - 1) / (2 * lanes);
+    long nblk = (total + 16 * lanes - 1) / (16 * lanes);
+    if (nblk < 256) nblk = (total + 8 * lanes - 1) / (8 * lanes);
+    if (nblk < 256) nblk = fine < 256 ? fine : 256;
     if (nblk > 2048) nblk = 2048;
     *chunk = (int)((total + nblk - 1) / nblk);
     return (total + *chunk - 1) / *chunk;

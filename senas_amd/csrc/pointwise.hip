@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(const float4* __restric
                                                          const float4* __restrict__ x2, const float* __restrict__ g,
                                                          float4* __restrict__ dx1, float4* __restrict__ dx2,
                                                          double* __restrict__ dg, long n4) {
-    __shared__ double red[2][256];
+    __shared__ double red[2][4];
     const float a = g[0], b = g[1];
     double s1 = 0.0, s2 = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -297,14 +297,14 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(const float4* __restric
         s1 += (double)d.x * u.x + (double)d.y * u.y + (double)d.z * u.z + (double)d.w * u.w;
         s2 += (double)d.x * v.x + (double)d.y * v.y + (double)d.z * v.z + (double)d.w * v.w;
     }
-    red[0][threadIdx.x] = s1;
-    red[1][threadIdx.x] = s2;
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dg, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(dg + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
-    if (threadIdx.x == 0) { atomicAdd(dg, red[0][0]); atomicAdd(dg + 1, red[1][0]); }
 }
 
 }  // namespace senas
@@ -327,7 +327,7 @@ extern "C" int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1,
                   "blend2_bwd: tensors must be 16-byte aligned");
     const long n4 = numel / 4;
     long blocks = (n4 + 255) / 256;
-    if (blocks > 512) blocks = 512;                                    // every block ends in two fp64 atomics
+    if (blocks > 128) blocks = 128;                                    // every block ends in two fp64 atomics on the SAME pair: 512 blocks spent 15 of their 19 us queueing there
     hipLaunchKernelGGL(blend2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float4*>(x1), reinterpret_cast<const float4*>(x2), g, reinterpret_cast<float4*>(dx1),
                        reinterpret_cast<float4*>(dx2), dg, n4);

@@ -192,7 +192,7 @@ int senas_bn_finalize(int n, int64_t hw, int c, const double* stats, const float
  * k pointers, k <= SENAS_MAX_DWMULTI.  g describes ONE of the convolutions (groups == ci == co).  Returns
  * SENAS_EUNSUPPORTED (nothing launched) off the fast path (channels not a power-of-two multiple of 4, taps not 3x3 / 5x5);
  * ws: senas_dwconv_multi_ws_bytes(g, k) bytes of scratch (per-block partial sums, overwritten).                       */
-#define SENAS_MAX_DWMULTI 8
+#define SENAS_MAX_DWMULTI 12
 int senas_dwconv_multi_fwd(const senas_conv_geom* g, int k, const float* x, const float* const* w, float* const* y,
                            double* const* stats, void* stream);
 int senas_dwconv_multi_bwd_data(const senas_conv_geom* g, int k, const float* const* dy, const float* const* w, float* dx,
@@ -212,6 +212,14 @@ int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const senas_conv_ge
                           const float* const* w, float* const* y, double* const* stats, void* stream);
 int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* const* dy,
                                const float* const* w, float* dx, void* stream);
+/* ... and with one input PER PROBLEM (xs: HOST array of ka + kb device pointers; NULL: all read x): the candidates of BOTH
+ * input states of a search cell (search/cell.py:81-93: the edges from s0 and from s1 have one geometry) share the forward
+ * and the weight-gradient launch; the data gradient stays one launch per input (senas_dwconv_pair_bwd_data on its problems). */
+int senas_dwconv_pair_fwd_xs(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                             const float* const* xs, const float* const* w, float* const* y, double* const* stats, void* stream);
+int senas_dwconv_pair_bwd_weight_xs(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                    const float* const* xs, const float* const* dy, float* const* dw, void* ws,
+                                    senas_sum_item* defer, void* stream);
 int64_t senas_dwconv_pair_ws_bytes(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb);
 int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
                                  const float* const* dy, float* const* dw, void* ws, senas_sum_item* defer, void* stream);

@@ -52,7 +52,7 @@ class SumItem(C.Structure):
 MAX_SUMS = 64
 MAX_DSTAIL = 12
 MAX_BNRELU = 8
-MAX_DWMULTI = 8
+MAX_DWMULTI = 12
 MAX_PWMULTI = 8
 UNSUPPORTED = -3
 
@@ -106,6 +106,8 @@ SIGNATURES = {
     'senas_dwconv_multi_bwd_weight': (_I, [_G, _I, _P, _PP, _PP, _P, _P]),
     'senas_dwconv_multi_bwd_weight_deferred': (_I, [_G, _I, _P, _PP, _PP, _P, C.POINTER(SumItem), _P]),
     'senas_dwconv_pair_fwd': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _PP, _P]),
+    'senas_dwconv_pair_fwd_xs': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _PP, _PP, _P]),
+    'senas_dwconv_pair_bwd_weight_xs': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _PP, _P, C.POINTER(SumItem), _P]),
     'senas_dwconv_pair_bwd_data': (_I, [_G, _I, _G, _I, _PP, _PP, _P, _P]),
     'senas_dwconv_pair_ws_bytes': (C.c_int64, [_G, _I, _G, _I]),
     'senas_dwconv_pair_bwd_weight': (_I, [_G, _I, _G, _I, _P, _PP, _PP, _P, C.POINTER(SumItem), _P]),

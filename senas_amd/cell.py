@@ -247,7 +247,7 @@ class Cell(nn.Module):
         terms = {}                                  # flat edge index -> [Term per candidate]
         states = []
 
-        held = []                                   # DepSepConv candidates of the FIRST input state whose tails wait for the second's
+        held = []                                   # DepSepConv candidates of the FIRST input state: they wait for the second's
 
         def add_state(h):
             # everything that reads this state runs now; every reader (and the output concat) gets its own alias of
@@ -263,25 +263,36 @@ class Cell(nn.Module):
                 taken += a
                 stages = getattr(job, 'stages', None)
                 if stages is not None and self.pair_tails and nin == 2 and j < 2:
-                    # the two input states' DepSepConv candidates have one shape: their depthwise halves run per state,
-                    # their fused tails (and the two backward passes of those) as ONE launch over both states' candidates
+                    # the two input states' DepSepConv candidates have one shape: their depthwise halves run as ONE
+                    # forward and one weight-gradient launch over both states (functional.dwconv_multi2), their fused tails
+                    # (and the two backward passes of those) as ONE launch over both states' candidates
                     stage1, items = stages
-                    zs, sts = stage1(xs)
                     if j == 0:
-                        held.append((items, zs, sts))
+                        held.append((items, stage1, xs))
                         continue
-                    if held and len(held[0][0]) + len(items) <= F.MAX_DSTAIL and held[0][1][0].shape == zs[0].shape:
-                        i0, z0, s0 = held.pop(0)
-                        out = self._depsep_tail(i0 + items, z0 + zs, s0 + sts)
+                    if not held:
+                        out = self._depsep_tail(items, *stage1(xs))
                     else:
-                        out = self._depsep_tail(items, zs, sts)
+                        i0, stage1_0, xs0 = held.pop(0)
+                        both = None
+                        if len(xs0) == 1 and len(xs) == 1 and xs0[0].shape == xs[0].shape:      # (NORM / DOWN cells: one geometry)
+                            both = F.dwconv_multi2(xs0[0], [m[0] for _, _, m in i0], xs[0], [m[0] for _, _, m in items],
+                                                   items[0][2][1].training)
+                        if both is not None:
+                            (z0, s0), (z1, s1) = [[list(col) for col in zip(*side)] for side in both]
+                        else:
+                            (z0, s0), (z1, s1) = stage1_0(xs0), stage1(xs)
+                        if len(i0) + len(items) <= F.MAX_DSTAIL and z0[0].shape == z1[0].shape:
+                            out = self._depsep_tail(i0 + items, z0 + z1, s0 + s1)
+                        else:
+                            out = self._depsep_tail(i0, z0, s0) + self._depsep_tail(items, z1, s1)
                 else:
                     out = job(xs)
                 for e, p, t in out:
                     terms.setdefault(e, {})[p] = t
             if j == 1:
-                for items, zs, sts in held:               # (no partner: on their own)
-                    for e, p, t in self._depsep_tail(items, zs, sts):
+                for items, stage1, xs0 in held:           # (no partner: on their own)
+                    for e, p, t in self._depsep_tail(items, *stage1(xs0)):
                         terms.setdefault(e, {})[p] = t
                 del held[:]
             states.append(aliases[-1] if j >= nin else None)

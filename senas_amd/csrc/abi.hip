@@ -14,5 +14,5 @@ void set_error_msg(const char* what) {
 }  // namespace senas
 
 extern "C" const char* senas_last_error(void) { return senas::g_err; }
-extern "C" int senas_abi_version(void) { return 21; }
+extern "C" int senas_abi_version(void) { return 22; }
 

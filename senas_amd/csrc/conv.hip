@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(GatherGeom g, const float* 
 // k depthwise convolutions of ONE input with k weight sets (the same-named DepSepConv candidates of the edges leaving
 // a search-cell state): blockIdx.y = problem
 struct DwTab {
-    const float* a[SENAS_MAX_DWMULTI];      // per-problem operand (forward: unused; weight gradient: the per-problem side)
+    const float* a[SENAS_MAX_DWMULTI];      // per-problem operand (forward: the problem's own input or NULL; data gradient: dy_p)
     const float* w[SENAS_MAX_DWMULTI];
     float* out[SENAS_MAX_DWMULTI];
     double* stats[SENAS_MAX_DWMULTI];
@@ -349,15 +349,16 @@ template <bool TG>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                long total, int P) {
     const int p = blockIdx.y;
-    dwconv_body<TG, 4, false>(p < ka ? ga : gb, in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
+    dwconv_body<TG, 4, false>(p < ka ? ga : gb, tab.a[p] ? tab.a[p] : in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
 }
 
 template <int KSA, int KSB, int S>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                   long total, int P) {
     const int p = blockIdx.y;
-    if (KSA == KSB || p < ka) dwconv_x4_body<KSA, S>(ga, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
-    else dwconv_x4_body<KSB, S>(gb, in, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
+    const float* src = tab.a[p] ? tab.a[p] : in;          // a problem may bring its own input (the two input states of a search cell)
+    if (KSA == KSB || p < ka) dwconv_x4_body<KSA, S>(ga, src, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
+    else dwconv_x4_body<KSB, S>(gb, src, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
 }
 
 // ConvTranspose2d(k, stride 2, padding k / 2, output_padding 1), depthwise: the UP candidates' dep_sep_conv_3 / _5
@@ -433,8 +434,9 @@ template <int KSA, int KSB>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_t2_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                   long total, int P) {
     const int p = blockIdx.y;
-    if (KSA == KSB || p < ka) dwconv_t2_quad_body<KSA>(ga, in, tab.w[p], tab.out[p], tab.stats[p], total, P);
-    else dwconv_t2_quad_body<KSB>(gb, in, tab.w[p], tab.out[p], tab.stats[p], total, P);
+    const float* src = tab.a[p] ? tab.a[p] : in;
+    if (KSA == KSB || p < ka) dwconv_t2_quad_body<KSA>(ga, src, tab.w[p], tab.out[p], tab.stats[p], total, P);
+    else dwconv_t2_quad_body<KSB>(gb, src, tab.w[p], tab.out[p], tab.stats[p], total, P);
 }
 
 static bool dw_t2_quad_ok(const GatherGeom& gg, int transposed) {
@@ -1247,7 +1249,7 @@ bool dw_geom_ok(const senas_conv_geom* g) {
     return (size_t)4 * (c4 <= 16 ? 4 : 64 / c4) * c4 * taps * 16 <= 64 * 1024;
 }
 
-bool dw_pair_ok(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb) {
+bool dw_pair_ok(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, bool all_weights_in_lds = true) {
     if (ka < 1 || kb < 0 || ka + kb > SENAS_MAX_DWMULTI || !dw_geom_ok(ga)) return false;
     size_t wbytes = (size_t)ka * ga->kh * ga->kw * ga->ci * sizeof(float);
     if (kb > 0) {
@@ -1257,7 +1259,7 @@ bool dw_pair_ok(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, in
         if (!(ga->kh == 3 && gb->kh == 5 && ga->dil == 1 && gb->dil == 1)) return false;     // the one mix there is: 3x3 then 5x5
         wbytes += (size_t)kb * gb->kh * gb->kw * gb->ci * sizeof(float);
     }
-    return wbytes <= 60 * 1024;
+    return !all_weights_in_lds || wbytes <= 60 * 1024;     // (only the data gradient keeps every problem's weights in LDS)
 }
 
 long dw_multi_wgrad_blocks(const senas_conv_geom* g, int* chunk) {
@@ -1286,18 +1288,20 @@ senas::WgradGeom wgrad_geom(const senas_conv_geom* g) {
 }
 }  // namespace
 
-extern "C" int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
-                                     const float* const* w, float* const* y, double* const* stats, void* stream) {
+extern "C" int senas_dwconv_pair_fwd_xs(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                        const float* const* xs, const float* const* w, float* const* y, double* const* stats,
+                                        void* stream) {
     using namespace senas;
-    if (!dw_pair_ok(ga, ka, gb, kb)) return SENAS_EUNSUPPORTED;
-    SENAS_REQUIRE(x && w && y, "dwconv_pair_fwd: null pointer");
+    if (!dw_pair_ok(ga, ka, gb, kb, xs == nullptr)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE((x || xs) && w && y, "dwconv_pair_fwd: null pointer");
     const int k = ka + kb;
     const senas_conv_geom* g = ga;
     const GatherGeom gga = fwd_geom(ga), ggb = kb > 0 ? fwd_geom(gb) : gga;
     DwTab tab{};
     bool want = stats != nullptr;
     for (int p = 0; p < k; ++p) {
-        SENAS_REQUIRE(w[p] && y[p], "dwconv_pair_fwd: null pointer");
+        SENAS_REQUIRE(w[p] && y[p] && (xs == nullptr || xs[p]), "dwconv_pair_fwd: null pointer");
+        tab.a[p] = xs != nullptr ? xs[p] : nullptr;
         tab.w[p] = w[p]; tab.out[p] = y[p]; tab.stats[p] = want ? stats[p] : nullptr;
         want = want && tab.stats[p] != nullptr;
     }
@@ -1332,6 +1336,11 @@ extern "C" int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const se
     if (g->transposed) hipLaunchKernelGGL((dwconv_multi_fwd_kernel<true>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, total, P);
     else hipLaunchKernelGGL((dwconv_multi_fwd_kernel<false>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, x, tab, total, P);
     return launch_status("dwconv_pair_fwd");
+}
+
+extern "C" int senas_dwconv_pair_fwd(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                     const float* const* w, float* const* y, double* const* stats, void* stream) {
+    return senas_dwconv_pair_fwd_xs(ga, ka, gb, kb, x, nullptr, w, y, stats, stream);
 }
 
 extern "C" int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* const* dy,
@@ -1375,17 +1384,18 @@ extern "C" int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, con
 }
 
 extern "C" int64_t senas_dwconv_pair_ws_bytes(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb) {
-    if (!dw_pair_ok(ga, ka, gb, kb)) return 0;
+    if (!dw_pair_ok(ga, ka, gb, kb, ka + kb <= 8)) return 0;             // (more than 8 problems: the per-problem-input forms only)
     int chunk;
     const int64_t nblk = dw_multi_wgrad_blocks(ga, &chunk);
     return nblk * ga->ci * ((int64_t)ka * ga->kh * ga->kw + (kb > 0 ? (int64_t)kb * gb->kh * gb->kw : 0)) * sizeof(float) + 256;
 }
 
-extern "C" int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
-                                            const float* const* dy, float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
+extern "C" int senas_dwconv_pair_bwd_weight_xs(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                               const float* const* xs, const float* const* dy, float* const* dw, void* ws,
+                                               senas_sum_item* defer, void* stream) {
     using namespace senas;
-    if (!dw_pair_ok(ga, ka, gb, kb)) return SENAS_EUNSUPPORTED;
-    SENAS_REQUIRE(x && dy && dw && ws, "dwconv_pair_bwd_weight: null pointer");
+    if (!dw_pair_ok(ga, ka, gb, kb, xs == nullptr)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE((x || xs) && dy && dw && ws, "dwconv_pair_bwd_weight: null pointer");
     const int k = ka + kb, c4 = ga->ci / 4;
     WgradGeom wga = wgrad_geom(ga), wgb = kb > 0 ? wgrad_geom(gb) : wga;
     int chunk;
@@ -1396,9 +1406,10 @@ extern "C" int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, c
     float* part = reinterpret_cast<float*>(ws);
     for (int p = 0; p < k; ++p) {
         const senas_conv_geom* g = p < ka ? ga : gb;
-        SENAS_REQUIRE(dy[p] && dw[p], "dwconv_pair_bwd_weight: null pointer");
-        tab.I[p] = g->transposed ? dy[p] : x;              // fine-grid operand
-        tab.G[p] = g->transposed ? x : dy[p];              // coarse-grid operand
+        SENAS_REQUIRE(dy[p] && dw[p] && (xs == nullptr || xs[p]), "dwconv_pair_bwd_weight: null pointer");
+        const float* xp = xs != nullptr ? xs[p] : x;       // a problem may bring its own input
+        tab.I[p] = g->transposed ? dy[p] : xp;             // fine-grid operand
+        tab.G[p] = g->transposed ? xp : dy[p];             // coarse-grid operand
         tab.part[p] = part;
         tab.dw[p] = dw[p];
         n_elem[p] = g->ci * g->kh * g->kw;
@@ -1416,6 +1427,11 @@ extern "C" int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, c
         else hipLaunchKernelGGL(dwconv_wgrad_sum_kernel, dim3((n_elem[p] + 3) / 4), dim3(256), 0, st, tab.part[p], tab.dw[p], n_elem[p], (int)nblk);
     }
     return launch_status("dwconv_pair_bwd_weight");
+}
+
+extern "C" int senas_dwconv_pair_bwd_weight(const senas_conv_geom* ga, int ka, const senas_conv_geom* gb, int kb, const float* x,
+                                            const float* const* dy, float* const* dw, void* ws, senas_sum_item* defer, void* stream) {
+    return senas_dwconv_pair_bwd_weight_xs(ga, ka, gb, kb, x, nullptr, dy, dw, ws, defer, stream);
 }
 
 // the single-geometry forms (include/senas_hip.h)

@@ -668,6 +668,78 @@ class _DwMulti(torch.autograd.Function):
         return (dx, None, None, None, None, None) + tuple(dws)
 
 
+class _DwMulti2(torch.autograd.Function):
+    """The same for problems that read one of TWO inputs (senas_dwconv_pair_fwd_xs): the DepSepConv candidates of both input
+    states of a search cell.  src[p] in {0, 1} names problem p's input (kernel order: the ka 3x3 problems, then the kb 5x5
+    ones).  One launch forward, one for all weight gradients; the data gradients stay one launch per input."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, ga, ka, gb, kb, src, want_stats, *ws):
+        k = ka + kb
+        xs = [nhwc(x0), nhwc(x1)]
+        ws = [_dev(w).contiguous() for w in ws]
+        g = ga
+        ys = [new_nhwc(g.n, g.co, g.ho, g.wo, xs[0]) for _ in range(k)]
+        stats = [new_stats(g.n, g.co, xs[0]) for _ in range(k)] if want_stats else []
+        xp = (C.c_void_p * k)(*[xs[src[p]].data_ptr() for p in range(k)])
+        wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
+        yp = (C.c_void_p * k)(*[y.data_ptr() for y in ys])
+        sp = (C.c_void_p * k)(*[s.data_ptr() for s in stats]) if want_stats else None
+        _lib.check(_lib.lib().senas_dwconv_pair_fwd_xs(C.byref(ga), ka, C.byref(gb) if kb else None, kb, None, xp, wp, yp, sp, _stream()),
+                   'senas_dwconv_pair_fwd_xs')
+        ctx.geoms, ctx.k, ctx.src = (ga, ka, gb, kb), k, tuple(src)
+        ctx.save_for_backward(xs[0], xs[1], *ws)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*stats)
+        return tuple(ys) + tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (ga, ka, gb, kb), k, src, L = ctx.geoms, ctx.k, ctx.src, _lib.lib()
+        g = ga
+        xs, ws = ctx.saved_tensors[:2], ctx.saved_tensors[2:]
+        dys = list(grads[:k])
+        if all(d is None for d in dys):
+            return (None,) * (8 + k)
+        dev_ = xs[0].device
+        dys = [nhwc(d) if d is not None else torch.zeros((g.n, g.co, g.ho, g.wo), device=dev_).contiguous(memory_format=CL) for d in dys]
+        dxs = [None, None]
+        for i in range(2):
+            if not ctx.needs_input_grad[i]:
+                continue
+            pa = [p for p in range(ka) if src[p] == i]
+            pb = [p for p in range(ka, k) if src[p] == i]
+            if not pa and not pb:
+                continue
+            ps = pa + pb
+            dyp = (C.c_void_p * len(ps))(*[dys[p].data_ptr() for p in ps])
+            wp = (C.c_void_p * len(ps))(*[ws[p].data_ptr() for p in ps])
+            dx = torch.empty_like(xs[i], memory_format=CL)
+            if pa:
+                rc = L.senas_dwconv_pair_bwd_data(C.byref(ga), len(pa), C.byref(gb) if pb else None, len(pb), dyp, wp, dx.data_ptr(), _stream())
+            else:
+                rc = L.senas_dwconv_pair_bwd_data(C.byref(gb), len(pb), None, 0, dyp, wp, dx.data_ptr(), _stream())
+            _lib.check(rc, 'senas_dwconv_pair_bwd_data')
+            dxs[i] = dx
+        dws = [None] * k
+        if any(ctx.needs_input_grad[8:]):
+            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
+            gbp = C.byref(gb) if kb else None
+            scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=dev_, dtype=torch.uint8)
+            xp = (C.c_void_p * k)(*[xs[src[p]].data_ptr() for p in range(k)])
+            dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
+            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
+            items = (_lib.SumItem * k)() if DEFER is not None else None
+            _lib.check(L.senas_dwconv_pair_bwd_weight_xs(C.byref(ga), ka, gbp, kb, None, xp, dyp, dwp, scratch.data_ptr(), items, _stream()),
+                       'senas_dwconv_pair_bwd_weight_xs')
+            if items is not None:
+                for t in range(k):
+                    one = _lib.SumItem()
+                    C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
+                    DEFER.append((one, scratch))
+        return (dxs[0], dxs[1], None, None, None, None, None, None) + tuple(dws)
+
+
 def _dw_geom(x, c0):
     tr = isinstance(c0, torch.nn.ConvTranspose2d)
     n, ci, hi, wi = x.shape
@@ -707,6 +779,37 @@ def dwconv_multi(x, convs, want_stats):
     for pos, i in enumerate(order):
         res[i] = (out[pos], out[k + pos] if want_stats else None)
     return res
+
+
+def dwconv_multi2(x0, convs0, x1, convs1, want_stats):
+    """dwconv_multi for the candidates of TWO tensors of one shape (the input states of a search cell) in ONE forward and one
+    weight-gradient launch: ([(z, stats)] for convs0, [(z, stats)] for convs1), or None off that path."""
+    convs = list(convs0) + list(convs1)
+    k = len(convs)
+    if not (convs0 and convs1) or k > _lib.MAX_DWMULTI or x0.shape != x1.shape:
+        return None
+    sizes = sorted(set(c.kernel_size[0] for c in convs))
+    if len(sizes) > 2 or (len(sizes) == 2 and sizes != [3, 5]):
+        return None
+    c0 = convs[0]
+    for c in convs:
+        if c.groups != c.in_channels or c.in_channels != c.out_channels or c.in_channels != x0.shape[1]:
+            return None
+        if (type(c), c.stride, c.dilation, c.groups) != (type(c0), c0.stride, c0.dilation, c0.groups) or c.padding[0] != c.kernel_size[0] // 2:
+            return None
+    order = sorted(range(k), key=lambda i: (convs[i].kernel_size[0], i))         # 3x3 problems first, each input's together
+    ka = sum(1 for c in convs if c.kernel_size[0] == sizes[0])
+    kb = k - ka
+    ga = _dw_geom(x0, convs[order[0]])
+    gb = _dw_geom(x0, convs[order[-1]]) if kb else None
+    if _lib.lib().senas_dwconv_pair_ws_bytes(C.byref(ga), ka, C.byref(gb) if kb else None, kb) == 0:
+        return None
+    src = tuple(0 if i < len(convs0) else 1 for i in order)
+    out = _DwMulti2.apply(x0, x1, ga, ka, gb, kb, src, bool(want_stats), *[convs[i].weight for i in order])
+    res = [None] * k
+    for pos, i in enumerate(order):
+        res[i] = (out[pos], out[k + pos] if want_stats else None)
+    return res[:len(convs0)], res[len(convs0):]
 
 
 class _PwMulti(torch.autograd.Function):

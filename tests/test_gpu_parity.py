@@ -1423,6 +1423,51 @@ def test_dwconv_multi_vs_single(case):
     close(xd.grad, x64.grad.numpy(), 'dx (sum over the problems)', rel=2e-4)
 
 
+@pytest.mark.parametrize('case', [(3, 2, 32, 16, 16, 1, False), (3, 4, 8, 12, 20, 1, False), (2, 2, 16, 8, 8, 2, False), (3, 2, 32, 8, 12, 2, True),
+                                  (2, 3, 32, 8, 8, 1, False)])
+def test_dwconv_multi2_vs_two_single_input_launches(case):
+    """functional.dwconv_multi2 (the DepSepConv candidates of BOTH input states of a search cell in one forward and one
+    weight-gradient launch, senas_dwconv_pair_fwd_xs / _bwd_weight_xs): outputs, statistics, both input gradients and all
+    weight gradients equal to functional.dwconv_multi run once per input (edges, n, c, h, w, stride, transposed; each
+    edge brings a 3x3 and a 5x5 problem)."""
+    from senas_amd import functional as F
+    edges, n, c, h, w, stride, tr = case
+    torch.manual_seed(sum(case[:6]))
+
+    def convs():
+        out = []
+        for _ in range(edges):
+            for ks in (3, 5):
+                if tr:
+                    m = torch.nn.ConvTranspose2d(c, c, ks, stride=stride, padding=ks // 2, output_padding=stride - 1, groups=c, bias=False)
+                else:
+                    m = torch.nn.Conv2d(c, c, ks, stride=stride, padding=ks // 2, groups=c, bias=False)
+                out.append(m.to(dev()))
+        return out
+    ca, cb = convs(), convs()
+    xa = torch.randn(n, c, h, w, device=dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = torch.randn(n, c, h, w, device=dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ref_a, ref_b = F.dwconv_multi(xa, ca, True), F.dwconv_multi(xb, cb, True)
+    assert ref_a is not None and ref_b is not None
+    wts = [torch.randn_like(z) for z, _ in ref_a + ref_b]
+    sum((z * t).sum() for (z, _), t in zip(ref_a + ref_b, wts)).backward()
+    want = [xa.grad.clone(), xb.grad.clone()] + [m.weight.grad.clone() for m in ca + cb]
+    want_out = [(z.detach().clone(), st.clone()) for z, st in ref_a + ref_b]
+    xa.grad = xb.grad = None
+    for m in ca + cb:
+        m.weight.grad = None
+    both = F.dwconv_multi2(xa, ca, xb, cb, True)
+    assert both is not None, 'off the paired path'
+    got = both[0] + both[1]
+    for (z, st), (wz, wst) in zip(got, want_out):
+        close(z, wz.cpu().numpy(), 'output', rel=1e-6)
+        assert torch.allclose(st, wst, rtol=1e-10, atol=1e-9), 'statistics differ'         # (fp64 atomics: the order may differ)
+    sum((z * t).sum() for (z, _), t in zip(got, wts)).backward()
+    have = [xa.grad, xb.grad] + [m.weight.grad for m in ca + cb]
+    for i, (a, b) in enumerate(zip(have, want)):
+        close(a, b.cpu().numpy(), 'gradient %d' % i, rel=2e-6)
+
+
 def copy_module64(m):
     import copy
     return copy.deepcopy(m).double()

@@ -903,7 +903,12 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     hipStream_t st = as_stream(stream);
     if (d.nterms <= kFuseTerms && fused_fwd_lds(d) <= 48 * 1024) {          // one launch: prologue + stream
         const int V = (d.c % 4 == 0) ? 4 : 1;
-        dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+        // every block repeats the preparation (statistics -> coefficients, ~3 us): at most 1024 blocks in all, a few
+        // elements per thread, instead of 4096 one-element blocks
+        unsigned gx = node_grid(d.hw * (d.c / V), d.n);
+        const unsigned fat = (unsigned)(1024 / (d.n > 0 ? d.n : 1));
+        if (gx > fat && fat >= 1) gx = fat;
+        dim3 grid(gx, d.n);
         if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s);
         else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s);
         return launch_status("node_fwd (fused)");

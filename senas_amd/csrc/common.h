@@ -264,6 +264,7 @@ bool t2_lds_ok(const GatherGeom& g);
 int launch_t2_lds(const GatherGeom& g, const float* in, const float* wp, float* out, double* stats, hipStream_t st);
 // conv_c8.hip (the 8-channel inner-edge convolutions of the search cell on 16 x 16 x 4 fp32 MFMA tiles)
 bool c8_mfma_ok(const GatherGeom& g);
+int c8_mfma_tiles_per_wave(const GatherGeom& g);
 int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, double* stats,
                    hipStream_t st);
 bool c8_mfma_wgrad_ok(const WgradGeom& g);

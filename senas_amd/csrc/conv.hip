@@ -1202,7 +1202,11 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         snprintf(b, 48, "conv_stem_mfma_kernel<%d, %d>", gg.kh, gg.cin);
         return b;
     }
-    if (!tr && c8_mfma_ok(gg)) return gg.cin == 8 ? "conv_c8_mfma_kernel<8>" : "conv_c8_mfma_kernel<16>";     // (callers without a ReLU on load)
+    if (!tr && c8_mfma_ok(gg)) {                                                                                 // (callers without a ReLU on load)
+        static thread_local char c8name[48];
+        snprintf(c8name, sizeof c8name, "conv_c8_mfma_kernel<%d, %d>", gg.cin == 8 ? 8 : 16, c8_mfma_tiles_per_wave(gg));
+        return c8name;
+    }
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && thin_n_ok(gg) && (gg.cout <= 4 || tr || !lds_gather_ok(gg))) {
         static char buf[8][48];

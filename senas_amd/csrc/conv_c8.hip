@@ -28,11 +28,14 @@ __device__ __forceinline__ float c8_weight(const float* __restrict__ src, int d1
 
 constexpr int TH = 8, TW = 32;
 
-template <int CIN>
+// NT: 16-pixel MFMA tiles per wave -- 4 (tile 8 x 32, wave w owns rows 2w, 2w + 1) or, on maps that would leave most CUs
+// without a block, 2 (tile 4 x 32, wave w owns row w: twice the blocks, half the serial MFMA chain of a wave)
+template <int CIN, int NT>
 __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                            int d1, int swap, int flip, float* __restrict__ out,
                                                            double* __restrict__ stats) {
     constexpr int PS = CIN + 4, CG = CIN / 4, KS = 5, TAPS = 25, NA = TAPS * CG;
+    constexpr int TH = 2 * NT, RW = NT / 2;                         // tile rows, rows per wave   (shadows the 8-row default)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lp = lane & 15, lk = lane >> 4;                      // pixel within a tile / k within a K-step (= channel quad of D)
@@ -68,13 +71,13 @@ __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const f
     }
     __syncthreads();
 
-    // ---- 4 tiles per wave: tile j = row 2 * wave + (j >> 1), columns 16 * (j & 1) ..
-    f32x4 acc[4];
+    // ---- NT tiles per wave: tile j = row RW * wave + (j >> 1), columns 16 * (j & 1) ..
+    f32x4 acc[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int base[4];
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int base[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) base[j] = ((2 * wave + (j >> 1)) * WW + 16 * (j & 1) + lp) * PS + lk;
+    for (int j = 0; j < NT; ++j) base[j] = ((RW * wave + (j >> 1)) * WW + 16 * (j & 1) + lp) * PS + lk;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const f
             for (int cg = 0; cg < CG; ++cg) {
                 const float a = areg[(ky * KS + kx) * CG + cg];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     const float b = win[base[j] + toff + 4 * cg];      // B[k = lk][col = pixel lp]
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
                 }
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const f
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     const bool ch_ok = 4 * lk < cout;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int oy = oy0 + 2 * wave + (j >> 1), ox = ox0 + 16 * (j & 1) + lp;
+    for (int j = 0; j < NT; ++j) {
+        const int oy = oy0 + RW * wave + (j >> 1), ox = ox0 + 16 * (j & 1) + lp;
         if (ch_ok && oy < g.hout && ox < g.wout) {
             float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
             stv<4>(out + (((size_t)n * g.hout + oy) * g.wout + ox) * cout + 4 * lk, v);
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const f
 }
 
 template <int CIN>
-size_t c8_lds_bytes(const GatherGeom& g) {
-    const size_t window = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * (CIN + 4) * sizeof(float);
+size_t c8_lds_bytes(const GatherGeom& g, int th = TH) {
+    const size_t window = (size_t)(th + 2 * g.pad) * (TW + 2 * g.pad) * (CIN + 4) * sizeof(float);
     const size_t weights = (size_t)25 * CIN * 16 * sizeof(float);
     return window > weights ? window : weights;
 }
@@ -141,22 +144,35 @@ bool c8_mfma_ok(const GatherGeom& g) {
     return g.n >= 1 && g.n <= 65535 && (long)g.n * g.hout * g.wout * 16 < 0x7fffffffL;
 }
 
+// 16-pixel MFMA tiles per wave of the launch: 4 (8 x 32 tiles), or 2 (4 x 32) when that leaves CUs with fewer than two blocks
+int c8_mfma_tiles_per_wave(const GatherGeom& g) {
+    const long blocks8 = (long)((g.wout + TW - 1) / TW) * ((g.hout + TH - 1) / TH) * g.n;
+    return blocks8 < (g.cin == 16 ? 512 : 256) && g.hout > 4 ? 2 : 4;       // (16 input channels: twice the chain per tile)
+}
+
 // w: torch layout viewed as [tap][a = input channel][b = output channel] through (d1, swap) as in conv_thin.hip
 int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, double* stats,
                    hipStream_t st) {
-    dim3 grid((g.wout + TW - 1) / TW, (g.hout + TH - 1) / TH, g.n);
+    // fewer than one 8 x 32 tile per CU: 4 x 32 tiles (the launch is as long as one wave's serial chain of 25 x c_in / 4 MFMAs
+    // per 16-pixel tile -- half the tiles per wave, half the chain)
+    const int th = 2 * c8_mfma_tiles_per_wave(g);
+    dim3 grid((g.wout + TW - 1) / TW, (g.hout + th - 1) / th, g.n);
     if (g.cin == 8) {
-        hipLaunchKernelGGL((conv_c8_mfma_kernel<8>), grid, dim3(256), c8_lds_bytes<8>(g), st, g, in, w, d1, swap, flip, out, stats);
+        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 2>), grid, dim3(256), c8_lds_bytes<8>(g, 4), st, g, in, w, d1, swap, flip, out, stats);
+        else hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 4>), grid, dim3(256), c8_lds_bytes<8>(g), st, g, in, w, d1, swap, flip, out, stats);
     } else {
-        const size_t bytes = c8_lds_bytes<16>(g);
+        const size_t bytes = c8_lds_bytes<16>(g, th);
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 2>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) { set_error("conv_c8_mfma: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_c8_mfma_kernel<16>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
+        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
+        else hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
     }
     return launch_status("conv_c8_mfma");
 }

@@ -114,7 +114,6 @@ class GradAllReducer(object):
         if not self.cuda or any(not g.is_contiguous() or g.dtype != torch.float32 for _, g in have):
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
             return
-        import ctypes as C
         from . import _lib
         from . import functional as F
         from .packing import _CopyItem

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Which torch (aten) ops still launch kernels inside one eager search step driven by SearchStep (everything that is not
 a libsenas_hip launch): op name, input shapes, count.   python tools/glue_ops.py [derived]"""
-import collections
 import os
 import sys
 

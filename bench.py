@@ -47,6 +47,11 @@ def parse_args(argv=None):
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)')
     ap.add_argument('--one-device', action='store_true',
                     help='rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)')
+    ap.add_argument('--rank-timeout', type=float, default=540.0,
+                    help='N > 1: seconds the parent waits for the ranks before it kills them and exits non-zero')
+    ap.add_argument('--pg-timeout', type=float, default=120.0, help='N > 1: torch.distributed rendezvous / collective timeout, seconds')
+    ap.add_argument('--cpu-uncapped', action='store_true',
+                    help='also time the CPU baseline with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3, literally)')
     return ap.parse_args(argv)
 
 
@@ -67,7 +72,33 @@ def spawn_ranks(args):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log('starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
-    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    # watchdog: a wedged RCCL bootstrap must not eat the caller's time limit and leave no line.  The ranks run in their own
+    # process group (a fresh child -- this process never touched a GPU and never re-execs); on a timeout the whole group
+    # is killed and the exit code is non-zero.
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=args.rank_timeout)
+    except subprocess.TimeoutExpired:
+        log('the %d ranks did not finish within %.1f s: killing process group %d' % (args.gpus, args.rank_timeout, proc.pid))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            stdout, _ = proc.communicate(timeout=10)
+        except (subprocess.TimeoutExpired, ValueError):
+            stdout = b''
+        sys.stderr.write((stdout or b'').decode(errors='replace')[-4000:])
+        sys.stderr.write('\nbench: timed out after %.1f s waiting for %d ranks (rank logs above, if any)\n' % (args.rank_timeout, args.gpus))
+        sys.exit(5)
+    done = subprocess.CompletedProcess(cmd, proc.returncode, stdout)
     line = None
     for raw in done.stdout.decode().splitlines():
         if raw.startswith('{') and '"metric"' in raw:
@@ -257,10 +288,12 @@ def main():
             log('HSA_ENABLE_IPC_MODE_LEGACY is not exported; setting it to 0 (dmabuf IPC) for RCCL')
             os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
         torch.cuda.set_device(dev_index)
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=args.pg_timeout)       # a rank that never shows up fails the others, not hangs them
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index), timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=pg_timeout)
     dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
 
@@ -378,6 +411,14 @@ def main():
             out['search_step']['cpu_baseline'] = dict(common, value=round(v, 3),
                                                       sample='same search step (arch pass + Adam, weight pass + clip + SGD) on 4+4 images '
                                                              '1x256x256, best of 2 after 1 warm-up; train images per second')
+        if args.cpu_uncapped:
+            # BASELINE.md section 3 literally: torch.set_num_threads(os.cpu_count()) -- on the GPU box that is the whole
+            # 256-CPU host, of which this job owns a 16-CPU share, so the figure is reported beside the capped one, once
+            torch.set_num_threads(os.cpu_count() or threads)
+            v = cpu_baseline_train(args.batch, args.size, reps=2)
+            out['cpu_baseline']['uncapped'] = {'value': round(v, 3), 'threads': torch.get_num_threads(),
+                                               'note': 'torch.set_num_threads(os.cpu_count()); cores this process may run on: %d'
+                                                       % len(os.sched_getaffinity(0))}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

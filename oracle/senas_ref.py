@@ -405,6 +405,17 @@ def dice_ce_loss(logits, target, smooth=1e-5):
     return F.cross_entropy(logits, target.long()) + soft_dice_loss(logits, target, smooth)
 
 
+def multi_dice_ce_loss(outputs, target, depth, weight_factors=None, smooth=1e-5):
+    """MultiSegmentationLosses('dice_ce', depth, weight_factors) -- utils/loss/loss.py:30-43: the weighted sum of the
+    per-output losses (zip stops at the shorter of factors / outputs) divided by the NUMBER OF OUTPUTS."""
+    factors = [1] * depth if weight_factors is None else list(weight_factors)
+    assert len(factors) == depth
+    total = 0
+    for wf, logits in zip(factors, outputs):
+        total = total + wf * dice_ce_loss(logits, target, smooth)
+    return total / len(outputs)
+
+
 def hard_counts(logits, label):
     """confusion_matrix -- utils/metrics.py:145-162: per-class (1..C-1) hard TP/FP/FN over the batch."""
     seg = F.softmax(logits, 1).argmax(1)

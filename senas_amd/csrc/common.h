@@ -10,6 +10,9 @@ namespace senas {
 void set_error(const char* what, hipError_t e);
 void set_error_msg(const char* what);
 
+// Raise a kernel's dynamic-LDS limit above 64 KiB, once per (kernel, device) -- abi.hip
+int raise_lds_limit(const void* kernel, int bytes, const char* what);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Every launcher ends with this: report (not swallow) launch failures.

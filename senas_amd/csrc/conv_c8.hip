@@ -162,15 +162,8 @@ int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1,
         else hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 4>), grid, dim3(256), c8_lds_bytes<8>(g), st, g, in, w, d1, swap, flip, out, stats);
     } else {
         const size_t bytes = c8_lds_bytes<16>(g, th);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 2>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e != hipSuccess) { set_error("conv_c8_mfma: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
-            attr_set = true;
-        }
+        const void* fn = th == 4 ? reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 2>) : reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 4>);
+        if (int rc = raise_lds_limit(fn, 96 * 1024, "conv_c8_mfma: raising the dynamic LDS limit")) return rc;
         if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
         else hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
     }

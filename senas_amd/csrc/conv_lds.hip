@@ -440,13 +440,9 @@ static int launch_lds_variant(const GatherGeom& g, const float* in, const float*
                               const float* mask, double* stats, hipStream_t st, const Epi& epi = Epi{}) {
     constexpr int TH = RW * MT * (32 / TWL);
     const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW, S);
-    static bool attr_set = false;
-    if (bytes > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { set_error("conv_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
-        attr_set = true;
-    }
+    if (bytes > 64 * 1024)
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>), 150 * 1024,
+                                     "conv_lds: raising the dynamic LDS limit")) return rc;
     dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
     hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
                        mask, stats, epi);

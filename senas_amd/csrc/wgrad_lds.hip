@@ -380,13 +380,8 @@ static int launch_one(const WgradGeom& g, const float* X, const float* G, float*
     size_t bytes = wgrad_lds_bytes(g, th, TWL);
     const size_t fold = (size_t)4 * REM * 4096;                // epilogue: 4 storing waves x REM accumulators x 4 KiB
     if (fold > bytes) bytes = fold;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { set_error("wgrad_lds: raising the dynamic LDS limit", e); return SENAS_ELAUNCH; }
-        attr_set = true;
-    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), 150 * 1024,
+                                 "wgrad_lds: raising the dynamic LDS limit")) return rc;
     const int rows = th * (32 / TWL);
     const int tiles_x = (g.wg + TWL - 1) / TWL, tiles_y = (g.hg + rows - 1) / rows;
     hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,

@@ -163,10 +163,11 @@ SINK = None
 DEFER = None
 
 
-def flush_deferred():
-    """Run the deferred weight-gradient sums (senas_wgrad_sum_batched, up to 64 per launch) and release their partials."""
+def flush_deferred(reopen=False):
+    """Run the deferred weight-gradient sums (senas_wgrad_sum_batched, up to 64 per launch) and release their partials.
+    ``reopen``: keep the deferral window open afterwards (a flush in the middle of a backward pass)."""
     global DEFER
-    items, DEFER = DEFER, None
+    items, DEFER = DEFER, ([] if (reopen and DEFER is not None) else None)
     if not items:
         return
     L = _lib.lib()
@@ -183,8 +184,19 @@ def wgrad_dest(w):
         v = SINK.dest(w)
         if v is not None:
             return v, None
+        if DEFER and SINK.pending(w):
+            # a further gradient of a parameter whose first one still has its sum deferred (a module applied twice, e.g.
+            # the shared head under deep supervision): that sum OVERWRITES the view, so it must run before autograd
+            # accumulates this one into the view
+            flush_deferred(reopen=True)
     t = torch.empty_like(w)
     return t, t
+
+
+def may_defer(*autograd_grads):
+    """A two-stage weight gradient may leave its sum to flush_deferred() only when every destination is a view of the
+    flat gradient buffer (autograd is handed None): a fresh tensor goes to autograd at once and must be complete."""
+    return DEFER is not None and all(g is None for g in autograd_grads)
 
 
 def _span(kind, g, x, w, y):
@@ -260,7 +272,7 @@ class _Conv2d(torch.autograd.Function):
             # scratch where it writes per-block partials
             wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
             with _span('conv_wgrad', g, x, w, dy):
-                if DEFER is not None:
+                if may_defer(dw):
                     item = _lib.SumItem()
                     _lib.check(L.senas_conv2d_bwd_weight_deferred(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
                                                                   wsw.data_ptr(), int(zero.value), C.byref(item), _stream()),
@@ -657,7 +669,7 @@ class _DwMulti(torch.autograd.Function):
             dwt, dws = zip(*[wgrad_dest(w) for w in ws])
             scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=x.device, dtype=torch.uint8)
             dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            items = (_lib.SumItem * k)() if DEFER is not None else None
+            items = (_lib.SumItem * k)() if may_defer(*dws) else None
             _lib.check(L.senas_dwconv_pair_bwd_weight(C.byref(ga), ka, gbp, kb, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
                        'senas_dwconv_pair_bwd_weight')
             if items is not None:
@@ -729,7 +741,7 @@ class _DwMulti2(torch.autograd.Function):
             xp = (C.c_void_p * k)(*[xs[src[p]].data_ptr() for p in range(k)])
             dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
             dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            items = (_lib.SumItem * k)() if DEFER is not None else None
+            items = (_lib.SumItem * k)() if may_defer(*dws) else None
             _lib.check(L.senas_dwconv_pair_bwd_weight_xs(C.byref(ga), ka, gbp, kb, None, xp, dyp, dwp, scratch.data_ptr(), items, _stream()),
                        'senas_dwconv_pair_bwd_weight_xs')
             if items is not None:

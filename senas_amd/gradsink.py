@@ -124,6 +124,10 @@ class GradSink(object):
             return sw.grad_buf
         return None
 
+    def pending(self, w):
+        """Was ``w`` (a registered parameter or stacked buffer) already handed its in-place destination in this pass?"""
+        return w.data_ptr() in self.written
+
     def finish(self):
         """After backward: fold the deferred weight-gradient sums (a few launches for all convolutions of the pass), then
         add the slices of the stacked weight gradients written in this pass to their parameters' views (one launch; the

@@ -80,3 +80,25 @@ class SegmentationLosses(nn.Module):
 
     def forward(self, outputs, target):
         return self.loss(outputs[-1], target)
+
+
+class MultiSegmentationLosses(nn.Module):
+    """Deep-supervision loss (reference: utils/loss/loss.py:30-43, chosen at experiments/search_arc.py:107 and
+    train_model.py:111 when ``deep_supervision: True``): ``sum_i w_i * loss([outputs[i]], target) / len(outputs)`` over the
+    list a model built with ``supervision=True`` returns.  Every addend is the fused dice_ce kernel pair; the weighted
+    sum is host arithmetic on 0-d tensors (``depth`` of them)."""
+
+    def __init__(self, name, depth, weight_factors=None):
+        super().__init__()
+        self.loss = SegmentationLosses(name)
+        factors = [1] * depth if weight_factors is None else list(weight_factors)
+        if len(factors) != depth:
+            raise ValueError('MultiSegmentationLosses: %d weight factors for depth %d' % (len(factors), depth))
+        self.weight_factors = factors
+
+    def forward(self, outputs, target):
+        total = None
+        for factor, logits in zip(self.weight_factors, outputs):      # (zip: outputs beyond ``depth`` are ignored, as there)
+            term = self.loss([logits], target) * factor
+            total = term if total is None else total + term
+        return total / len(outputs)

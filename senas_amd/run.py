@@ -104,7 +104,7 @@ def search(argv=None):
     """search_arc.py: two optimizers, ``Architecture.step`` on a validation batch from ``alpha_begin`` on, weight step on a
     training batch, cosine schedule per epoch, genotype after every epoch."""
     from . import checkpoint
-    from .loss import SegmentationLosses
+    from .loss import MultiSegmentationLosses, SegmentationLosses
     from .models import DATASET_SHAPES
     from .parallel import broadcast_parameters
     from .senas_search import NAS
@@ -115,14 +115,14 @@ def search(argv=None):
     rank, world, dev = _dist_setup()
     torch.manual_seed(cfg.get('seed', 0))
     nclass, in_ch = DATASET_SHAPES[str(cfg['data']['dataset']).lower()]
-    if blk.get('deep_supervision'):
-        raise NotImplementedError('deep_supervision needs MultiSegmentationLosses (not on the SENAS hot path)')
+    supervision = bool(blk.get('deep_supervision'))
     model = NAS(in_ch, blk['init_channels'], nclass, blk['depth'], meta_node_num=blk['meta_node_num'],
-                use_sharing=blk['sharing_normal'], double_down_channel=blk['double_down_channel'], supervision=False,
+                use_sharing=blk['sharing_normal'], double_down_channel=blk['double_down_channel'], supervision=supervision,
                 device=dev).to(dev).train()
     if world > 1:
         broadcast_parameters(model)
-    crit = SegmentationLosses(blk['loss']['name'])
+    # search_arc.py:107
+    crit = MultiSegmentationLosses(blk['loss']['name'], blk['depth']) if supervision else SegmentationLosses(blk['loss']['name'])
     opt_w = _optimizer(model.parameters(), blk['model_optimizer'])
     opt_a = _optimizer(model.arch_parameters(), blk['arch_optimizer'])
     epochs = args.epochs if args.epochs is not None else blk['epoch']
@@ -150,7 +150,7 @@ def search(argv=None):
                 except StopIteration:
                     vit = iter(valid)
                     xv, yv = next(vit)
-            losses.append(step(x, y, xv, yv))
+            losses.append(step(x, y, xv, yv).clone())        # (a graphed step returns ONE static buffer: copy it)
         sched.step()
         mean = float(torch.stack(losses).mean()) if losses else float('nan')
         geno = model.genotype()
@@ -170,7 +170,7 @@ def train(argv=None):
     schedule per epoch."""
     from . import checkpoint, geno_searched
     from .genotype import Genotype  # noqa: F401  (the namespace ``--genotype`` text is evaluated in)
-    from .loss import SegmentationLosses
+    from .loss import MultiSegmentationLosses, SegmentationLosses
     from .models import DATASET_SHAPES, get_segmentation_model
     from .parallel import broadcast_parameters
     from .step import TrainStep
@@ -185,15 +185,15 @@ def train(argv=None):
         geno = _parse_genotype(args.genotype)
     else:
         geno = getattr(geno_searched, blk['geno_type'])
-    if blk.get('deep_supervision'):
-        raise NotImplementedError('deep_supervision needs MultiSegmentationLosses (not on the SENAS hot path)')
+    supervision = bool(blk.get('deep_supervision'))
     model = get_segmentation_model(cfg['model']['arch'], dataset=cfg['data']['dataset'], c=blk['init_channels'], depth=blk['depth'],
-                                   supervision=False, genotype=geno, double_down_channel=blk['double_down_channel'])
+                                   supervision=supervision, genotype=geno, double_down_channel=blk['double_down_channel'])
     model.apply(weights_init)
     model = model.to(dev).train()
     if world > 1:
         broadcast_parameters(model)
-    crit = SegmentationLosses(blk['loss']['name'])
+    # train_model.py:111
+    crit = MultiSegmentationLosses(blk['loss']['name'], blk['depth']) if supervision else SegmentationLosses(blk['loss']['name'])
     opt = _optimizer(model.parameters(), blk['model_optimizer'])
     sched = None
     if (blk.get('lr_schedule') or {}).get('name') == 'cos':
@@ -214,7 +214,7 @@ def train(argv=None):
                 break
             x_buf.copy_(x, non_blocking=True)
             y_buf.copy_(y, non_blocking=True)
-            losses.append(step())
+            losses.append(step().clone())
         if sched is not None:
             sched.step()
         mean = float(torch.stack(losses).mean()) if losses else float('nan')

@@ -189,8 +189,11 @@ class GraphedForwardBackward(object):
             return
         rest = r.sink.span(e.last + 1, r.last)
         dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=r.group)
-        self._work.wait()
-        self._work = None
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        else:                                      # the early all-reduce was not launched (collectives off during the pass)
+            dist.all_reduce(e.sink.span(e.first, e.last), op=dist.ReduceOp.SUM, group=e.group)
         r.sink.span(r.first, r.last).mul_(1.0 / r.world)
 
 

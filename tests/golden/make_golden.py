@@ -628,11 +628,70 @@ def gen_loss_metric(Loss, Metric):
     print('loss_metric: %d cases' % len(cases))
 
 
+def gen_round3(S, M, GS):
+    """Deep supervision (``deep_supervision: True``): utils/loss/loss.py:30-43 MultiSegmentationLosses over the list a
+    ``supervision=True`` net returns -- the shared head is applied once per output, so its weights receive several
+    gradients per pass.  nets3.npz: whole nets under that loss; multi_loss.npz: the loss alone, with weight factors."""
+    from utils.loss.loss import MultiSegmentationLosses
+    gen = torch.Generator().manual_seed(33)
+    out, index = {}, []
+    ones = [1] * 6
+    for tag, kw, shape, ncls in (('nas.c8.msup', dict(input_c=1, c=8, num_classes=2, depth=4, meta_node_num=3, supervision=True),
+                                  (2, 1, 64, 64), 2),):
+        torch.manual_seed(7)
+        net = S.NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+        out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        _net_case(net, x, tgt, MultiSegmentationLosses('dice_ce', kw['depth']), tag, out, arch_full=True)
+        index.append(tag)
+    for tag, geno, kw, shape in (
+            ('derived.node2.c8.msup', GS.senas_node_2._replace(gamma=ones), dict(nclass=2, in_channels=1, c=8, depth=4, supervision=True),
+             (2, 1, 64, 64)),
+            ('derived.node4.c32.msup', GS.senas_node_4._replace(gamma=ones), dict(nclass=3, in_channels=1, c=32, depth=3, supervision=True),
+             (2, 1, 32, 32))):
+        net = M.SenasModel(genotype=geno, **kw)
+        _rand_init(net, gen)
+        net.train()
+        x = torch.randn(*shape, generator=gen)
+        tgt = torch.randint(0, kw['nclass'], (shape[0],) + shape[2:], generator=gen)
+        out[tag + '/kw'] = np.array(json.dumps(kw))
+        out[tag + '/genotype'] = np.array(_geno_json(geno))
+        _net_case(net, x, tgt, MultiSegmentationLosses('dice_ce', kw['depth']), tag, out, arch_full=False)
+        index.append(tag)
+    out['index'] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, 'nets3.npz'), **out)
+    print('nets3: %d cases' % len(index))
+    out, cases = {}, []
+    for tag, shape, ncls, depth, factors in (('ml.3x2c', (2, 2, 16, 16), 2, 3, None), ('ml.4x3c.w', (2, 3, 12, 20), 3, 4, [0.5, 1.0, 2.0, 4.0]),
+                                             ('ml.2of5', (1, 2, 8, 8), 2, 5, None)):
+        nout = 2 if tag == 'ml.2of5' else depth                   # fewer outputs than ``depth``: zip() stops, the divisor is len(outputs)
+        logits = [(2.0 * torch.randn(*shape, generator=gen)).requires_grad_(True) for _ in range(nout)]
+        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+        crit = MultiSegmentationLosses('dice_ce', depth, factors)
+        loss = crit(logits, tgt)
+        loss.backward()
+        out[tag + '/target'], out[tag + '/loss'] = _np(tgt), _np(loss)
+        out[tag + '/meta'] = np.array(json.dumps({'depth': depth, 'factors': factors, 'outputs': nout}))
+        for i, l in enumerate(logits):
+            out[tag + '/logits%d' % i], out[tag + '/dlogits%d' % i] = _np(l), _np(l.grad)
+        cases.append(tag)
+    out['index'] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, 'multi_loss.npz'), **out)
+    print('multi_loss: %d cases' % len(cases))
+
+
 def main():
     torch.set_num_threads(4)
     S, C, O, G, M, GS, Loss, Metric = _import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'round2':          # only the round-2 files (the others stay byte-identical)
         gen_nets2(S, M, GS, Loss)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'round3':
+        gen_round3(S, M, GS)
         return
     gen_prims(O)
     gen_blocks(O)
@@ -643,6 +702,7 @@ def main():
     gen_search_step(S, Loss)
     gen_genoparse(S, G)
     gen_loss_metric(Loss, Metric)
+    gen_round3(S, M, GS)
     with open(os.path.join(OUT, 'PROVENANCE.json'), 'w') as f:
         json.dump({'generator': 'tests/golden/make_golden.py', 'reference': 'RayburnChen/senas @ /root/reference',
                    'torch': torch.__version__, 'numpy': np.__version__, 'device': 'cpu', 'dtype': 'float32'}, f, indent=1)

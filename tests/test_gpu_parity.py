@@ -179,7 +179,7 @@ def _build_net(z, tag):
     return load_into(net, gio.unpack(z, tag + '/sd0/')).train(), kw
 
 
-NET_CASES = [(f, t) for f in ('nets', 'nets2') for t in gio.index(f)]
+NET_CASES = [(f, t) for f in ('nets', 'nets2', 'nets3') for t in gio.index(f)]
 
 
 @pytest.mark.parametrize('fixture,tag', NET_CASES)
@@ -187,7 +187,7 @@ def test_whole_net(fixture, tag):
     """nets: round-1 cases; nets2: the reference's default flags -- NAS(use_sharing=True, double_down_channel=True)
     (search/senas_search.py:118,148,26,45) and SenasModel(double_down_channel=True) (models/senas_model.py:80)."""
     from senas_amd.genotype import Genotype
-    from senas_amd.loss import SegmentationLosses
+    from senas_amd.loss import MultiSegmentationLosses, SegmentationLosses
     z = gio.load(fixture)
     net, kw = _build_net(z, tag)
     if tag.startswith('nas'):
@@ -197,7 +197,10 @@ def test_whole_net(fixture, tag):
     outs = net(x)
     for i, o in enumerate(outs):
         close(o, z[tag + '/logits%d' % i], '%s logits%d' % (tag, i), rel=1e-3)
-    loss = SegmentationLosses('dice_ce')(outs, tgt)
+    # nets3 (tags ending in msup): deep supervision under MultiSegmentationLosses -- the shared head receives one gradient
+    # per output (utils/loss/loss.py:30-43, search/senas_search.py:104-107)
+    crit = MultiSegmentationLosses('dice_ce', kw['depth']) if tag.endswith('msup') else SegmentationLosses('dice_ce')
+    loss = crit(outs, tgt)
     assert abs(float(loss) - float(z[tag + '/loss'])) <= 1e-4 * abs(float(z[tag + '/loss']))
     loss.backward()
     got = grads_of(net)
@@ -220,6 +223,11 @@ def test_whole_net(fixture, tag):
     # rest passes on the strength of the reference's fp32-vs-fp64 spread -- bounded in number (the c = 32 fixtures of
     # test_full_width_net_every_gradient have no escape at all)
     print('%s: %d of %d full gradients used the conditioning escape: %s' % (tag, len(escaped), len(full64), escaped[:4]))
+    worst_full = max((float(np.abs(got[k] - e64).max()) / max(float(np.abs(e64).max()), 1e-3 * top), k) for k, e64 in full64.items())
+    margins = {'full_gradients': len(full64), 'used_conditioning_escape': len(escaped), 'escape_allowed': max(2, len(full64) // 4),
+               'worst_full_gradient_vs_fp64': worst_full[0], 'worst_full_gradient': worst_full[1],
+               'escaped': [{'tensor': k, 'gpu_vs_fp64': a, 'reference_fp32_vs_fp64': b, 'gpu_vs_reference_fp32': c} for k, a, b, c in escaped],
+               'bound': 'max(2e-4, 10 x |ref32 - ref64|) of the tensor scale per tensor; escape = beyond 1e-3 of fp64 AND beyond 2e-4 of the reference fp32 run'}
     assert len(escaped) <= max(2, len(full64) // 4), escaped
     d32, d64 = gio.digest(z, tag + '/grad/'), gio.digest(z, tag + '/grad64/')
     assert set(d32) == set(got)
@@ -234,6 +242,10 @@ def test_whole_net(fixture, tag):
             outliers.append((gpu_err, ref_err, k))
     # batch-norm scale gradients are cancellation residues (sum(ds*z) - mean*sum(ds)); a few of the
     # tensors amplify summation-order noise past the tight bound -- at most 2% may, none past 2e-2
+    margins.update({'gradient_norms': len(d64), 'norm_outliers': len(outliers), 'norm_outliers_allowed': max(2, len(d64) // 50),
+                    'worst_norm_outliers': [{'tensor': k, 'gpu': a, 'reference_fp32': b} for a, b, k in sorted(outliers)[-3:]]})
+    from conftest import record_margin
+    record_margin('test_whole_net[%s-%s]' % (fixture, tag), **margins)
     assert len(outliers) <= max(2, len(d64) // 50), '%s: %d gradient norms off: %s' % (tag, len(outliers), sorted(outliers)[-5:])
     gio.check_digest(gio.digest(z, tag + '/bn1/'), {k: v.cpu().numpy() for k, v in net.state_dict().items()},
                      rtol=1e-3, atol_scale=1e-4, what=tag + ' bn')
@@ -276,6 +288,11 @@ def test_full_width_net_every_gradient(tag):
     worst = max(errs, key=errs.get)
     print('%s: %d gradients, worst %s %.2e (reference spread there %.2e); %d beyond 1e-3, %d tensors have a reference spread above 2.5e-4'
           % (tag, len(errs), worst, errs[worst], spread[worst], len(loose), sum(1 for v in spread.values() if v > 2.5e-4)))
+    from conftest import record_margin
+    record_margin('test_full_width_net_every_gradient[%s]' % tag, gradients=len(errs), worst_tensor=worst, worst_vs_fp64=errs[worst],
+                  reference_spread_at_worst=float(spread[worst]), beyond_1e3=len(loose), beyond_1e3_allowed=max(3, len(errs) // 8),
+                  beyond_1e3_detail=[{'tensor': k, 'gpu_vs_fp64': errs[k], 'reference_spread': float(spread[k])} for k in loose],
+                  bound='max(1e-3, 4 x the reference\'s own spread under 1e-6 perturbations) per tensor')
     for k, v in errs.items():
         assert v <= max(1e-3, 4 * spread[k]), (k, v, spread[k])
     assert len(loose) <= max(3, len(errs) // 8), loose
@@ -644,6 +661,24 @@ def test_fused_clip_sgd_matches_torch(cfg):
             if p.grad is not None:
                 close(q.grad, p.grad.cpu().numpy(), 'clipped grad %d step %d' % (k, step), rel=2e-6)
     assert set(opt_g.state_dict()['state'].keys()) == set(opt_r.state_dict()['state'].keys())
+
+
+@pytest.mark.parametrize('tag', gio.index('multi_loss'))
+def test_multi_loss_kernels(tag):
+    """MultiSegmentationLosses (utils/loss/loss.py:30-43) over senas_dice_ce_fwd/_bwd against the reference's own value
+    and per-output gradients (weight factors; fewer outputs than ``depth``)."""
+    from senas_amd.loss import MultiSegmentationLosses
+    z = gio.load('multi_loss')
+    meta = json.loads(str(z[tag + '/meta']))
+    logits = [torch.from_numpy(z[tag + '/logits%d' % i]).to(dev()).requires_grad_(True) for i in range(meta['outputs'])]
+    tgt = torch.from_numpy(z[tag + '/target']).to(dev())
+    loss = MultiSegmentationLosses('dice_ce', meta['depth'], meta['factors'])(logits, tgt)
+    np.testing.assert_allclose(loss.item(), float(z[tag + '/loss']), rtol=3e-6)
+    loss.backward()
+    for i, l in enumerate(logits):
+        np.testing.assert_allclose(l.grad.cpu().numpy(), z[tag + '/dlogits%d' % i], rtol=3e-5, atol=3e-9)
+    with pytest.raises(ValueError):
+        MultiSegmentationLosses('dice_ce', 3, [1.0, 2.0])
 
 
 @pytest.mark.parametrize('tag', gio.index('loss_metric'))

@@ -28,12 +28,18 @@ def _nets(kind):
         return SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4).to(dev()).train()
     if kind == 'derived_sup':
         return SenasModel(2, 1, c=8, depth=3, genotype=senas_node_4._replace(gamma=[1] * 6), supervision=True).to(dev()).train()
+    if kind == 'derived_sup_c32':
+        # c = 32: the head's (and every cell's) weight gradients run on the two-stage kernels whose sums are DEFERRED
+        return SenasModel(2, 1, c=32, depth=3, genotype=senas_node_4._replace(gamma=[1] * 6), supervision=True).to(dev()).train()
+    if kind == 'supernet_sup_c32':
+        return NAS(1, 32, 2, 3, meta_node_num=3, use_sharing=False, double_down_channel=False, supervision=True, device=dev()).to(dev()).train()
     sup = kind == 'supernet_sup'
     return NAS(1, 8, 2, 3 if sup else 4, meta_node_num=3, use_sharing=(kind == 'supernet_share'), double_down_channel=False,
                supervision=sup, device=dev()).to(dev()).train()
 
 
-@pytest.mark.parametrize('kind', ['derived', 'derived_sup', 'supernet', 'supernet_share', 'supernet_sup'])
+@pytest.mark.parametrize('kind', ['derived', 'derived_sup', 'derived_sup_c32', 'supernet', 'supernet_share', 'supernet_sup',
+                                  'supernet_sup_c32'])
 def test_grad_sink_matches_autograd(kind):
     """With a GradSink installed the backward kernels write parameter gradients into views of one flat buffer and hand
     autograd nothing; modules applied more than once per pass (the shared head under deep supervision) and stacked
@@ -41,13 +47,24 @@ def test_grad_sink_matches_autograd(kind):
     same values up to the summation order of atomics and of gradients that arrive more than once."""
     from senas_amd import functional as F
     from senas_amd.gradsink import GradSink
-    from senas_amd.loss import SegmentationLosses
+    from senas_amd.loss import MultiSegmentationLosses, SegmentationLosses
     from senas_amd.step import _model_stacks
     net = _nets(kind)
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(2, 1, 64, 64, generator=gen).to(dev())
     y = torch.randint(0, 2, (2, 64, 64), generator=gen).to(dev())
-    crit = SegmentationLosses('dice_ce')
+    # *_sup: the criterion sums over ALL supervised outputs, so the shared head really receives one gradient per output
+    # (SegmentationLosses looks at outputs[-1] only and would leave the other applications without a gradient)
+    crit = MultiSegmentationLosses('dice_ce', 3) if '_sup' in kind else SegmentationLosses('dice_ce')
+    if '_sup' in kind:
+        calls = []
+        heads = [m for m in net.modules() if type(m).__name__ == 'Head']
+        hooks = [m.register_forward_hook(lambda mod, a, b: calls.append(1)) for m in heads]
+        with torch.no_grad():
+            net(x)
+        for h in hooks:
+            h.remove()
+        assert len(heads) == 1 and len(calls) > 1, 'the head of %s is applied %d times: the case does not cover accumulation' % (kind, len(calls))
     assert F.SINK is None
     crit(net(x), y).backward()
     want = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
@@ -104,6 +121,36 @@ def test_two_rank_step_drivers_rccl(kind, tmp_path):
     r = _two_ranks(kind, 'nccl', False, tmp_path)
     assert r['two_graph_backward'] and r['replicas_identical'] and r['moved'], r
     assert max(r['grad_vs_oracle_mean']) <= 1e-3, r
+
+
+def test_bench_spawns_two_ranks():
+    """``bench.py --gpus 2`` without a torch.distributed environment starts the ranks itself (watchdog, process-group
+    timeout): rehearsed over gloo with both ranks on cuda:0 -- the RCCL twin needs two devices and runs on the first
+    multi-GPU lease (what it replaces: nn.DataParallel, experiments/train_model.py:135-137)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--one-device', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+           '--search-steps', '2', '--no-cpu-baseline', '--rank-timeout', '600']
+    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert done.returncode == 0, done.stderr.decode()[-3000:]
+    lines = [l for l in done.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, done.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['allreduce_overlapped_with_backward'] and out['config']['global_batch'] == 16
+    assert out['search_step']['n_gpus'] == 2 and out['value'] > 0 and out['search_step']['value'] > 0
+
+
+def test_bench_watchdog_kills_wedged_ranks(tmp_path):
+    """The parent of an N-rank run gives up after --rank-timeout, kills the ranks' process group and exits non-zero (5):
+    a wedged bootstrap must not eat the driver's limit.  (No GPU work: the ranks are stopped while they start up.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--one-device', '--backend', 'gloo', '--rank-timeout', '0.5']
+    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert done.returncode == 5, (done.returncode, done.stderr.decode()[-1000:])
+    assert b'timed out' in done.stderr
 
 
 def test_yaml_entry_points(tmp_path):

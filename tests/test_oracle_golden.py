@@ -123,7 +123,7 @@ def test_cell(tag):
 
 
 # ------------------------------------------------------------------ whole nets
-NET_CASES = [(f, t) for f in ('nets', 'nets2') for t in gio.index(f)]
+NET_CASES = [(f, t) for f in ('nets', 'nets2', 'nets3') for t in gio.index(f)]
 
 
 def _run_net(z, tag):
@@ -145,12 +145,13 @@ def _run_net(z, tag):
 
 @pytest.mark.parametrize('fixture,tag', NET_CASES)
 def test_whole_net(fixture, tag):
-    """nets: round-1 cases; nets2: the reference's default flags (use_sharing / double_down_channel)."""
+    """nets: round-1 cases; nets2: the reference's default flags (use_sharing / double_down_channel); nets3: deep supervision
+    under MultiSegmentationLosses (tags ending in ``msup``)."""
     z = gio.load(fixture)
     sd, x, tgt, outs, kw = _run_net(z, tag)
     for i, o in enumerate(outs):
         _close(o.detach(), z[tag + '/logits%d' % i], '%s logits%d' % (tag, i), rtol=2e-4, atol=2e-5)
-    loss = R.dice_ce_loss(outs[-1], tgt)
+    loss = R.multi_dice_ce_loss(outs, tgt, kw['depth']) if tag.endswith('msup') else R.dice_ce_loss(outs[-1], tgt)
     _close(loss.detach(), z[tag + '/loss'], tag + ' loss', rtol=1e-5, atol=1e-6)
     loss.backward()
     got = gio.alias_shared_stem(_grads_of(sd), 'net.' if tag.startswith('nas') else '')
@@ -269,3 +270,17 @@ def test_loss_and_metric(tag):
     assert abs(pix - exp[0]) < 2e-3
     assert R.miou_from_counts(*cnt) == pytest.approx(exp[1], abs=1e-3)
     assert R.dice_from_counts(*cnt) == pytest.approx(exp[2], abs=1e-3)
+
+
+@pytest.mark.parametrize('tag', gio.index('multi_loss'))
+def test_multi_loss(tag):
+    """MultiSegmentationLosses (utils/loss/loss.py:30-43): value and the gradient of every output."""
+    z = gio.load('multi_loss')
+    meta = json.loads(str(z[tag + '/meta']))
+    logits = [torch.from_numpy(z[tag + '/logits%d' % i]).requires_grad_(True) for i in range(meta['outputs'])]
+    tgt = torch.from_numpy(z[tag + '/target'])
+    loss = R.multi_dice_ce_loss(logits, tgt, meta['depth'], meta['factors'])
+    _close(loss.detach(), z[tag + '/loss'], tag + ' loss', rtol=1e-6)
+    loss.backward()
+    for i, l in enumerate(logits):
+        _close(l.grad, z[tag + '/dlogits%d' % i], '%s dlogits%d' % (tag, i), rtol=1e-5, atol=1e-9)

@@ -92,6 +92,29 @@ int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d
                              int64_t* elems);
 /* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
 int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
+/* ---- the same convolutions on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -------------------------
+ * Stride-1 "same" nn.Conv2d 3x3 / 5x5 with c_in a multiple of 16 (32 for terms == 1) and c_out a multiple of 32 on maps at
+ * least 32 wide and 8 high -- the dense candidates and pre/post-process convolutions of the derived cell
+ * (utils/operations.py:89-95,118-130,206-218; models/senas_model.py:11-16) -- forward and data gradient.  `terms` selects the
+ * operand form; both operands are split the same way, the activations while they are staged in LDS, the weights once per
+ * step in the packed image:
+ *     1  "bf16"   : operands rounded to bf16 (round to nearest even)
+ *     3  "bf16x3" : x = hi + lo, products hi*hi + hi*lo + lo*hi               (per-product error ~2^-17 |x||w|)
+ *     6  "bf16x6" : x = hi + mid + lo (exact), 6 products, lo*lo-order terms dropped (<= 2^-25 |x||w|: below fp32 rounding)
+ * Everything else is as in senas_conv2d_fwd / _bwd_data (fp32 NHWC tensors in HBM, stats, in_relu, ws).  Shapes off this
+ * path return SENAS_EUNSUPPORTED and launch nothing (the caller then uses the fp32 entry points).  packed_lp: the image
+ * described by senas_conv2d_pack_layout_lp (elems in 4-byte units), refreshed with senas_pack_batched_lp -- items as for
+ * senas_pack_batched with the `swap` value that the layout call returns (it carries `terms`); NULL: repacked into ws.   */
+int senas_conv2d_fwd_lp(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu, double* stats,
+                        void* ws, const void* packed_lp, int terms, void* stream);
+int senas_conv2d_bwd_data_lp(const senas_conv_geom* g, const float* dy, const float* w, float* dx, int in_relu, const float* x,
+                             void* ws, const void* packed_lp, int terms, void* stream);
+int senas_conv2d_pack_layout_lp(const senas_conv_geom* g, int direction, int terms, int32_t* d0, int32_t* d1, int32_t* swap,
+                                int64_t* elems);
+int senas_pack_batched_lp(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
+/* kernel symbol of the lp forward (which = 0) / data gradient (1) / weight gradient (2); "" when the geometry is off the path */
+const char* senas_conv2d_kernel_name_lp(const senas_conv_geom* g, int which, int terms);
+
 /* Stacked weights of the search cell (see senas_unstack_fwd): item i copies rows x row_len floats from src rows that
  * are src_stride floats apart into dst rows that are dst_stride floats apart -- every per-edge weight of the model into
  * its slice of a stacked buffer in ONE launch, and (the other way round) every slice of the stacked weight gradients
@@ -130,6 +153,14 @@ typedef struct senas_sum_item {
 int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
                                      float* dw, void* ws, int ws_is_zero, senas_sum_item* defer, void* stream);
 int senas_wgrad_sum_batched(const senas_sum_item* items, int n, void* stream);
+
+/* Weight gradient of the same convolutions on the bf16 pipe (both operands split while they are staged in LDS; fragments
+ * by transposing LDS reads).  *bytes == 0: the geometry is off the path (use senas_conv2d_bwd_weight).  ws: *bytes of
+ * scratch for the per-block partial images (need not be zeroed); defer as in senas_conv2d_bwd_weight_deferred (NULL:
+ * the sum runs at once).  dw (torch layout) is OVERWRITTEN.                                                              */
+int senas_conv2d_bwd_weight_ws_lp(const senas_conv_geom* g, int terms, int64_t* bytes);
+int senas_conv2d_bwd_weight_lp(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw, void* ws,
+                               int terms, senas_sum_item* defer, void* stream);
 
 /* ---- pooling / resampling --------------------------------------------------------------------
  * nn.AvgPool2d(3, stride, 1, count_include_pad=False)  (operations.py:62,150)

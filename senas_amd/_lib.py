@@ -131,6 +131,13 @@ SIGNATURES = {
     'senas_sgd_clip_step': (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
+    'senas_conv2d_fwd_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    'senas_conv2d_bwd_data_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    'senas_conv2d_bwd_weight_ws_lp': (_I, [_G, _I, C.POINTER(C.c_int64)]),
+    'senas_conv2d_bwd_weight_lp': (_I, [_G, _P, _I, _P, _P, _P, _I, C.POINTER(SumItem), _P]),
+    'senas_conv2d_pack_layout_lp': (_I, [_G, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    'senas_pack_batched_lp': (_I, [_P, _I, _L, _P]),
+    'senas_conv2d_kernel_name_lp': (C.c_char_p, [_G, _I, _I]),
     'senas_conv2d_kernel_name': (C.c_char_p, [_G, _I]),
     'senas_last_error': (C.c_char_p, []),
     'senas_abi_version': (_I, []),

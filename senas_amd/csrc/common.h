@@ -250,6 +250,24 @@ template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
                       const float* mask, double* stats, hipStream_t st);
 
+// conv_bf.hip (the same convolutions on the bf16 matrix pipe: operands split into 1, 2 or 3 bf16 planes, fp32 accumulation;
+// terms = 1 plain bf16, 3 "bf16x3", 6 "bf16x6")
+bool bf_gather_ok(const GatherGeom& g, int terms);
+template <bool TG>
+int launch_bf_gather(const GatherGeom& g, int terms, const float* in, const void* wimg, float* out, int in_relu, const float* mask,
+                     double* stats, hipStream_t st);
+void bf_gather_name(const GatherGeom& g, int terms, bool tg, char* buf, int len);
+int64_t bf_image_bytes(int A, int B, int taps, int terms);
+void launch_bf_pack(const float* w, void* img, int d0, int d1, int taps, int swap, int terms, hipStream_t st);
+int launch_bf_pack_batched(const void* items_dev, int n, int64_t max_elems, hipStream_t st);
+
+// wgrad_bf.hip (the weight gradient of the same convolutions on the bf16 pipe; partial images as wgrad_lds.hip)
+bool bf_wgrad_ok(const WgradGeom& g, int terms);
+int64_t bf_wgrad_ws_bytes(const WgradGeom& g, int terms);
+int launch_bf_wgrad(const WgradGeom& g, int terms, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                    hipStream_t st);
+void bf_wgrad_name(const WgradGeom& g, int terms, char* buf, int len);
+
 // conv_stem.hip (stem forward: 1..4 input channels, (tap, channel) on the K axis of the fp32 MFMA)
 bool stem_mfma_ok(const GatherGeom& g);
 int launch_stem_mfma(const GatherGeom& g, const float* in, const float* w, float* out, int in_relu, double* stats, hipStream_t st);

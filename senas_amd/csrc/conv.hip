@@ -787,7 +787,8 @@ extern "C" int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g) {
     // repacked weights: [n-tile][tap][reduction channels][32] for the MFMA kernels (either direction)
     const int64_t big = g->ci > g->co ? g->ci : g->co, small = g->ci > g->co ? g->co : g->ci;
     const int64_t cols = ((small + 31) / 32) * 32 > ((big + 31) / 32) * 32 ? ((small + 31) / 32) * 32 : ((big + 31) / 32) * 32;
-    return (int64_t)g->kh * g->kw * big * cols * sizeof(float) + 256;
+    // (x 3/2: the three-plane bf16 image of the split-operand convolutions, conv_bf.hip, is 6 bytes per weight)
+    return (int64_t)g->kh * g->kw * big * cols * 6 + 256;
 }
 
 // Workspace of the weight gradient: which path it takes decides the size and whether it must arrive zero-filled.
@@ -985,6 +986,109 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 1);
     if (!g->transposed) return launch_direct<true>(gg, dy, wp, dx, 0, mask, nullptr, st);
     return launch_direct<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
+}
+
+// ---- split-operand / bf16 forms of the stride-1 "same" dense convolution (conv_bf.hip)
+static inline bool lp_terms_ok(int terms) { return terms == 1 || terms == 3 || terms == 6; }
+
+extern "C" int senas_conv2d_pack_layout_lp(const senas_conv_geom* g, int direction, int terms, int32_t* d0, int32_t* d1, int32_t* swap,
+                                           int64_t* elems) {
+    SENAS_REQUIRE(g && d0 && d1 && swap && elems && (direction == 0 || direction == 1) && lp_terms_ok(terms), "conv2d_pack_layout_lp: bad argument");
+    *d0 = g->transposed ? g->ci : g->co;
+    *d1 = g->transposed ? g->co : g->ci;
+    const int reduce_is_d1 = g->transposed ? (direction == 1) : (direction == 0);
+    const int A = reduce_is_d1 ? *d1 : *d0, B = reduce_is_d1 ? *d0 : *d1;
+    *swap = reduce_is_d1 | (terms << 8);
+    // only shapes conv_bf serves: a Conv2d (the data gradient of a transposed one is a strided gather), 3x3 / 5x5, full tiles
+    const bool ok = g->groups == 1 && !g->transposed && g->kh == g->kw && (g->kh == 3 || g->kh == 5) && A % (terms == 1 ? 32 : 16) == 0 && B % 32 == 0;
+    *elems = ok ? bf_image_bytes(A, B, g->kh * g->kw, terms) / 4 : 0;
+    return SENAS_OK;
+}
+
+extern "C" int senas_pack_batched_lp(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream) {
+    SENAS_REQUIRE(items_dev && n > 0 && max_elems > 0, "pack_batched_lp: bad argument");
+    return launch_bf_pack_batched(items_dev, n, max_elems, as_stream(stream));
+}
+
+extern "C" int senas_conv2d_fwd_lp(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu, double* stats,
+                                   void* ws, const void* packed_lp, int terms, void* stream) {
+    SENAS_REQUIRE(geom_ok(g) && lp_terms_ok(terms), "conv2d_fwd_lp: inconsistent geometry");
+    SENAS_REQUIRE(x && w && y, "conv2d_fwd_lp: null pointer");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!bf_gather_ok(gg, terms)) return SENAS_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const void* img = packed_lp;
+    if (img == nullptr) {
+        SENAS_REQUIRE(ws, "conv2d_fwd_lp: null workspace");
+        launch_bf_pack(w, ws, g->co, g->ci, g->kh * g->kw, 1, terms, st);
+        img = ws;
+    }
+    return launch_bf_gather<false>(gg, terms, x, img, y, in_relu, nullptr, stats, st);
+}
+
+extern "C" int senas_conv2d_bwd_data_lp(const senas_conv_geom* g, const float* dy, const float* w, float* dx, int in_relu, const float* x,
+                                        void* ws, const void* packed_lp, int terms, void* stream) {
+    SENAS_REQUIRE(geom_ok(g) && lp_terms_ok(terms), "conv2d_bwd_data_lp: inconsistent geometry");
+    SENAS_REQUIRE(dy && w && dx, "conv2d_bwd_data_lp: null pointer");
+    SENAS_REQUIRE(!in_relu || x, "conv2d_bwd_data_lp: in_relu needs x");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!bf_gather_ok(gg, terms)) return SENAS_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const void* img = packed_lp;
+    if (img == nullptr) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_data_lp: null workspace");
+        launch_bf_pack(w, ws, g->co, g->ci, g->kh * g->kw, 0, terms, st);
+        img = ws;
+    }
+    return launch_bf_gather<true>(gg, terms, dy, img, dx, 0, in_relu ? x : nullptr, nullptr, st);
+}
+
+extern "C" int senas_conv2d_bwd_weight_ws_lp(const senas_conv_geom* g, int terms, int64_t* bytes) {
+    SENAS_REQUIRE(geom_ok(g) && bytes && lp_terms_ok(terms), "conv2d_bwd_weight_ws_lp: bad argument");
+    *bytes = 0;
+    if (g->groups != 1 || g->transposed) return SENAS_OK;
+    const WgradGeom wg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (bf_wgrad_ok(wg, terms)) *bytes = bf_wgrad_ws_bytes(wg, terms) + 256;
+    return SENAS_OK;
+}
+
+extern "C" int senas_conv2d_bwd_weight_lp(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw, void* ws,
+                                          int terms, senas_sum_item* defer, void* stream) {
+    if (defer != nullptr) defer->kind = 0;
+    SENAS_REQUIRE(geom_ok(g) && lp_terms_ok(terms), "conv2d_bwd_weight_lp: inconsistent geometry");
+    SENAS_REQUIRE(x && dy && dw, "conv2d_bwd_weight_lp: null pointer");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    const WgradGeom wg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (!bf_wgrad_ok(wg, terms)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(ws, "conv2d_bwd_weight_lp: null workspace");
+    senas_sum_item item;
+    const int rc = launch_bf_wgrad(wg, terms, x, dy, reinterpret_cast<float*>(ws), dw, in_relu, &item, as_stream(stream));
+    if (rc != SENAS_OK) return rc;
+    if (defer != nullptr) { *defer = item; return SENAS_OK; }
+    return senas_wgrad_sum_batched(&item, 1, stream);
+}
+
+extern "C" const char* senas_conv2d_kernel_name_lp(const senas_conv_geom* g, int which, int terms) {
+    if (!geom_ok(g) || which < 0 || which > 2 || !lp_terms_ok(terms) || g->groups != 1 || g->transposed) return "";
+    if (which == 2) {
+        const WgradGeom wg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        if (!bf_wgrad_ok(wg, terms)) return "";
+        static char wbuf[8][48];
+        static int wslot = 0;
+        char* b = wbuf[wslot++ & 7];
+        bf_wgrad_name(wg, terms, b, 48);
+        return b;
+    }
+    GatherGeom gg = which == 0 ? GatherGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil}
+                               : GatherGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!bf_gather_ok(gg, terms)) return "";
+    static char buf[8][48];
+    static int slot = 0;
+    char* b = buf[slot++ & 7];
+    bf_gather_name(gg, terms, which == 1, b, 48);
+    return b;
 }
 
 // One launch for the second stage of up to SENAS_MAX_SUMS two-stage weight gradients: block b belongs to the item whose

@@ -154,6 +154,33 @@ def _packed(w, direction):
     return ent.img.data_ptr()
 
 
+# Arithmetic of the dense stride-1 convolutions that have a bf16-matrix-pipe form (csrc/conv_bf.hip): 0 = fp32 MFMA (bit-for-bit
+# fp32 FMA chains, the default), else the number of bf16 products per fp32 product: 1 "bf16" (operands rounded to bf16),
+# 3 "bf16x3", 6 "bf16x6" (operands split into 2 / 3 bf16 planes; fp32 accumulation throughout).  Tensors in HBM stay fp32.
+MATH_TERMS = 0
+MATH_NAMES = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+
+
+def set_math(name):
+    """Select the arithmetic of the dense convolutions: 'f32' | 'bf16x6' | 'bf16x3' | 'bf16'.  Returns the previous name.
+    Step drivers / packers built before the call keep the images of the mode they were built in: set it first."""
+    global MATH_TERMS
+    if name not in MATH_NAMES:
+        raise SenasHipError('unknown math mode %r (one of %s)' % (name, sorted(MATH_NAMES)))
+    prev = math_name()
+    MATH_TERMS = MATH_NAMES[name]
+    return prev
+
+
+def math_name():
+    return next(k for k, v in MATH_NAMES.items() if v == MATH_TERMS)
+
+
+def _packed_lp(w, direction):
+    """The cached bf16 image of ``w`` for the current math mode (directions 2 + direction in the packer's table)."""
+    return _packed(w, (MATH_TERMS, direction))
+
+
 # senas_amd.gradsink.GradSink of the running step driver, or None: parameter gradients go through autograd
 SINK = None
 
@@ -204,7 +231,10 @@ def _span(kind, g, x, w, y):
         return _NOSPAN
     macs = (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
     which = {'conv_fwd': 0, 'conv_dgrad': 1, 'conv_wgrad': 2}[kind]
-    name = _lib.lib().senas_conv2d_kernel_name(C.byref(g), which).decode()      # the symbol rocprofv3 reports
+    name = b''
+    if MATH_TERMS:
+        name = _lib.lib().senas_conv2d_kernel_name_lp(C.byref(g), which, MATH_TERMS)
+    name = (name or _lib.lib().senas_conv2d_kernel_name(C.byref(g), which)).decode()      # the symbol rocprofv3 reports
     tag = (kind,) + tuple(getattr(g, f) for f, _ in g._fields_)
     return TIMER.span(name, 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()), tag)
 
@@ -241,8 +271,14 @@ class _Conv2d(torch.autograd.Function):
         stats = new_stats(n, co, x) if want_stats else None
         ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
         with _span('conv_fwd', g, x, w, y):
-            _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
-                                          ws.data_ptr(), _packed(w, 0), _stream()), 'senas_conv2d_fwd')
+            rc = _lib.UNSUPPORTED
+            if MATH_TERMS:
+                rc = L.senas_conv2d_fwd_lp(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
+                                           ws.data_ptr(), _packed_lp(w, 0), MATH_TERMS, _stream())
+            if rc == _lib.UNSUPPORTED:                      # (off the bf16 path: the fp32 kernels)
+                rc = L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
+                                        ws.data_ptr(), _packed(w, 0), _stream())
+            _lib.check(rc, 'senas_conv2d_fwd')
         ctx.save_for_backward(x, w)
         ctx.g, ctx.in_relu = g, int(in_relu)
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
@@ -262,11 +298,29 @@ class _Conv2d(torch.autograd.Function):
             dx = torch.empty_like(x, memory_format=CL)
             ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
             with _span('conv_dgrad', g, x, w, dy):
-                _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
-                                                   x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
+                rc = _lib.UNSUPPORTED
+                if MATH_TERMS:
+                    rc = L.senas_conv2d_bwd_data_lp(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
+                                                    x.data_ptr(), ws.data_ptr(), _packed_lp(w, 1), MATH_TERMS, _stream())
+                if rc == _lib.UNSUPPORTED:
+                    rc = L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
+                                                 x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream())
+                _lib.check(rc, 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
             dwt, dw = wgrad_dest(w)
             nbytes, zero = C.c_int64(), C.c_int32()
+            if MATH_TERMS:                                  # the bf16-pipe form, where the geometry has one
+                _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), MATH_TERMS, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
+            if MATH_TERMS and nbytes.value:
+                wsw = torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
+                with _span('conv_wgrad', g, x, w, dy):
+                    item = _lib.SumItem() if may_defer(dw) else None
+                    _lib.check(L.senas_conv2d_bwd_weight_lp(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(), wsw.data_ptr(),
+                                                            MATH_TERMS, C.byref(item) if item is not None else None, _stream()),
+                               'senas_conv2d_bwd_weight_lp')
+                    if item is not None and item.kind:
+                        DEFER.append((item, wsw))
+                return dx, dw, None, None, None, None, None, None, None, None
             _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
             # pre-zeroed arena slice where the path accumulates with atomics (no memset launch per conv); plain
             # scratch where it writes per-block partials
@@ -1136,6 +1190,7 @@ class StackedWeight(object):
         self.managed = False
         self.packer = None                     # the WeightPacker that keeps the buffer filled while ``managed``
         self.filled = None                     # the parameters' version counters when a packer last filled the buffer
+        self.eager_fill = None                 # (version counters, WEIGHT_GEN) of the last unmanaged fill by tensor()
 
     def __deepcopy__(self, memo):
         # a copied model gets an unmanaged stack over ITS parameters, not a copy of the packer / gradient buffers behind this one
@@ -1159,6 +1214,7 @@ class StackedWeight(object):
             # zero-filled: the padding parts (zero weights that bring a stack of three to a full 32-channel tile) stay zero
             self.buf = torch.zeros(shape, device=p0.device, dtype=p0.dtype)
             self.managed = False
+            self.eager_fill = None
         return self.buf
 
     def slices(self):
@@ -1171,9 +1227,15 @@ class StackedWeight(object):
     def tensor(self):
         buf = self.buffer()
         if not self.current():
-            with torch.no_grad():
-                for dst, p in zip(self.slices(), self.params):
-                    dst.copy_(p)
+            # unmanaged: refill -- but only when a parameter moved since the last fill.  A module applied more than once per
+            # pass (the shared head under deep supervision) must not rewrite the buffer between its applications: the
+            # earlier application's convolution saved a view of it for its backward pass
+            stamp = (tuple((p._version, p.data_ptr()) for p in self.params), WEIGHT_GEN)
+            if self.eager_fill != stamp:
+                with torch.no_grad():
+                    for dst, p in zip(self.slices(), self.params):
+                        dst.copy_(p)
+                self.eager_fill = stamp
         return _StackFn.apply(buf, self.dim, *self.params)
 
 

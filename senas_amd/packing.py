@@ -47,7 +47,7 @@ class WeightPacker(object):
         L = _lib.lib()
         self.gen = -1                # functional.WEIGHT_GEN at the last refresh: the images count only in that generation
         self.entries = []            # (weight parameter, direction, image tensor)
-        items = []
+        items, lp_items = [], []
         seen = set()
         # stacked weight buffers of the search cells (cell.py): filled by refresh(), then packed like any other weight
         self.stacks = [sw for m in model.modules() if hasattr(m, 'stacked_weights') for sw in m.stacked_weights()]
@@ -85,6 +85,21 @@ class WeightPacker(object):
                 self.entries.append((w, direction, img))
                 items.append(_Item(w.data_ptr(), img.data_ptr(), d0.value, d1.value, w.shape[2] * w.shape[3], swap.value,
                                    elems.value))
+                # the bf16 image of the same weight for the math mode this packer is built in (csrc/conv_bf.hip)
+                terms = F.MATH_TERMS
+                if terms:
+                    _lib.check(L.senas_conv2d_pack_layout_lp(C.byref(g), direction, terms, C.byref(d0), C.byref(d1), C.byref(swap),
+                                                             C.byref(elems)), 'senas_conv2d_pack_layout_lp')
+                    if elems.value:
+                        img = torch.empty(elems.value, device=w.device, dtype=torch.float32)
+                        self.entries.append((w, (terms, direction), img))
+                        lp_items.append(_Item(w.data_ptr(), img.data_ptr(), d0.value, d1.value, w.shape[2] * w.shape[3], swap.value,
+                                              elems.value))
+        self.n_lp = len(lp_items)
+        self.max_lp = max((it.elems for it in lp_items), default=0)
+        if self.n_lp:
+            raw = bytes((_Item * self.n_lp)(*lp_items))
+            self.table_lp = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.entries[0][0].device)
         self.n = len(items)
         self.max_elems = max((it.elems for it in items), default=0)
         if self.n:
@@ -101,6 +116,9 @@ class WeightPacker(object):
         if self.n:
             _lib.check(_lib.lib().senas_pack_batched(self.table.data_ptr(), self.n, self.max_elems, F._stream()),
                        'senas_pack_batched')
+        if self.n_lp:
+            _lib.check(_lib.lib().senas_pack_batched_lp(self.table_lp.data_ptr(), self.n_lp, self.max_lp, F._stream()),
+                       'senas_pack_batched_lp')
         self.mark_refreshed()
 
     def mark_refreshed(self):

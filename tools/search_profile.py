@@ -14,8 +14,12 @@ import bench  # noqa: E402
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    print(bench.bench_search(torch.device('cuda:0'), steps, 0, 1), flush=True)
+    """search_profile.py [steps] [--eager]: --eager runs the two passes launch by launch instead of replaying the captured
+    graphs (rocprofv3 --pmc crashed inside the tool on the replayed search graphs, ~2 800 nodes each, in round 3; the
+    per-launch counters of the same kernels on the same tensors do not depend on how they were launched)."""
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    steps = int(args[0]) if args else 2
+    print(bench.bench_search(torch.device('cuda:0'), steps, 0, 1, use_graph='--eager' not in sys.argv), flush=True)
 
 
 if __name__ == '__main__':

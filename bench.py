@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument('--rank-timeout', type=float, default=540.0,
                     help='N > 1: seconds the parent waits for the ranks before it kills them and exits non-zero')
     ap.add_argument('--pg-timeout', type=float, default=120.0, help='N > 1: torch.distributed rendezvous / collective timeout, seconds')
+    ap.add_argument('--lp-steps', type=int, default=60,
+                    help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16; 0 = skip them)')
     ap.add_argument('--cpu-uncapped', action='store_true',
                     help='also time the CPU baseline with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3, literally)')
     return ap.parse_args(argv)
@@ -229,6 +231,111 @@ def cpu_baseline_search(batch, size, reps=2):
     return batch / min(times)
 
 
+BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def lp_accuracy(dev):
+    """Max error of every math mode against the CPU oracle on one small derived net (c = 32, depth 2, 2x1x64x64; fp32 oracle,
+    fp64 for the gradients would not change the picture): logits / worst parameter-gradient L2.  Rank 0, N = 1 only."""
+    import torch
+    from oracle import senas_ref as R            # checker only
+    from senas_amd import functional as F
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.utils import weights_init
+    torch.manual_seed(11)
+    net = SenasModel(2, 1, c=32, depth=2, genotype=senas_node_4)
+    net.apply(weights_init)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 1, 64, 64, generator=g)
+    y = torch.randint(0, 2, (2, 64, 64), generator=g)
+    sd, params = _oracle_leaves(net)
+    sd = {k: (v.double().detach().requires_grad_(v.requires_grad) if v.is_floating_point() else v) for k, v in sd.items()}
+    a, b = 'blocks.0.0.', 'stem1.'
+    for k in list(sd):
+        if k.startswith(a):
+            sd[k] = sd[b + k[len(a):]]
+    ref = R.derived_forward(sd, x.double(), R.Genotype(*senas_node_4), depth=2)[-1]
+    R.dice_ce_loss(ref, y).backward()
+    net = net.to(dev).train()
+    buffers = {k: v.detach().clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
+    out = {}
+    prev = F.math_name()
+    for mode in ('f32', 'bf16x6', 'bf16x3', 'bf16'):
+        F.set_math(mode)
+        net.load_state_dict(buffers, strict=False)
+        net.zero_grad(set_to_none=True)
+        o = net(x.to(dev))[-1]
+        SegmentationLosses('dice_ce')([o], y.to(dev)).backward()
+        e_out = float((o.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        worst = 0.0
+        for k, p in net.named_parameters():
+            e = sd[k].grad
+            if e is None or float(e.norm()) < 1e-9:
+                continue
+            worst = max(worst, float((p.grad.detach().cpu().double() - e).norm() / e.norm()))
+        out[mode] = {'logits_max_rel_err_vs_oracle_fp64': e_out, 'worst_gradient_l2_rel_err_vs_oracle_fp64': worst}
+    F.set_math(prev)
+    net.zero_grad(set_to_none=True)
+    return out
+
+
+def bench_train_mode(mode, args, dev, rank, world, ref_ms):
+    """A labelled block: the SAME derived train step with the dense stride-1 convolutions on the bf16 matrix pipe
+    (senas_amd.functional.set_math): bf16x6 / bf16x3 split operands or plain bf16 operands, fp32 accumulation, fp32 tensors
+    in HBM.  Never the headline: `value` stays the fp32-exact step."""
+    import torch
+    from senas_amd import functional as F
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.parallel import broadcast_parameters
+    from senas_amd.step import TrainStep
+    prev = F.set_math(mode)
+    try:
+        net = build_derived(dev)
+        if world > 1:
+            broadcast_parameters(net)
+        crit = SegmentationLosses('dice_ce')
+        opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)
+        x, y = synthetic(args.batch, 1, 2, args.size, 1 + rank, dev)
+        step = TrainStep(net, crit, opt, x, y, world_size=world, grad_clip=5.0, use_graph=not args.no_graph)
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        elapsed, loss = timed(step, args.lp_steps, world, dev)
+        ms = 1e3 * elapsed / args.lp_steps
+        # per-kernel HIP events of the dense convolutions in this mode (two eager passes)
+        step.fb._collectives = False
+        F.TIMER = F.KernelTimer()
+        for _ in range(2):
+            step.fb._eager()
+        timer, F.TIMER = F.TIMER, None
+        step.fb._collectives = True
+        agg = timer.summary(F.KernelTimer.empty_pair_ms())
+        step.close()
+        terms = F.MATH_NAMES[mode]
+        top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:18]
+        for name, a in top:
+            log('  [%s] %-44s %4d launches %8.3f ms/step  %7.2f TFLOP/s (fp32-equivalent)' % (mode, name, a['launches'] // 2, a['ms'] / 2,
+                                                                                             a['flops'] / (a['ms'] * 1e-3) / 1e12))
+        name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        peak = BF16_PEAK_TFLOPS / terms                         # fp32-equivalent FLOP/s the pipe can deliver with `terms` MFMAs per product
+        res = {'math': mode, 'dtype': {'bf16': 'bf16 operands (RNE), f32 accumulate, f32 storage',
+                                       'bf16x3': 'f32 split into 2 bf16 planes, 3 MFMA products, f32 accumulate, f32 storage',
+                                       'bf16x6': 'f32 split into 3 bf16 planes, 6 MFMA products, f32 accumulate, f32 storage'}[mode],
+               'value': round(args.batch * world * args.lp_steps / elapsed, 3), 'unit': 'images/s', 'ms_per_step': round(ms, 3),
+               'steps': args.lp_steps, 'speedup_vs_f32_step': round(ref_ms / ms, 3), 'loss': float(loss.detach()),
+               'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / 2, 2),
+               'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
+                            'frac': round(tf / peak, 4), 'traffic': None, 'launches': a['launches'],
+                            'avg_launch_ms': round(a['ms'] / a['launches'], 4),
+                            'peak_convention': '2.5 PFLOP/s dense bf16 MFMA / %d MFMA products per fp32 product' % terms}}
+        return res
+    finally:
+        F.set_math(prev)
+
+
 def timed(step, steps, world, dev):
     """EXACTLY ``steps`` calls bracketed by barrier + synchronize on both sides; MAX over ranks."""
     import torch
@@ -391,6 +498,17 @@ def main():
     log('train step: %.2f ms/step, %.2f images/s' % (ms_per_step, value))
     step.close()
     del step, net, opt
+
+    if args.lp_steps > 0:
+        for mode in ('bf16x6', 'bf16x3', 'bf16'):
+            out['train_step_' + mode] = bench_train_mode(mode, args, dev, rank, world, ms_per_step)
+            if rank == 0:
+                log('train step [%s]: %.2f ms/step, %.2f images/s' % (mode, out['train_step_' + mode]['ms_per_step'], out['train_step_' + mode]['value']))
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            acc = lp_accuracy(dev)
+            out['accuracy_vs_oracle'] = acc
+            for mode in ('bf16x6', 'bf16x3', 'bf16'):
+                out['train_step_' + mode]['max_error_vs_oracle'] = acc[mode]
 
     if args.search_steps > 0:
         out['search_step'] = bench_search(dev, args.search_steps, rank, world, use_graph=not args.no_graph)

@@ -27,6 +27,7 @@
 // Epilogue: lane = output channel, so a store instruction writes two full 128-byte rows; per-image channel statistics
 // (fp64) stay in registers across the tiles of an image and leave as one atomic pair per channel and wave.
 #include "common.h"
+#include <stdlib.h>
 
 namespace senas {
 
@@ -73,6 +74,7 @@ struct BfArgs {
     double* stats;
     int in_relu;
     int tiles_x, tiles_y, ntiles, cot;      // ntiles = cot * n * tiles_y * tiles_x
+    int probe;                              // tuning probe (SENAS_BF_PROBE): bit 0 no staging, bit 1 no taps, bit 2 no epilogue
 };
 
 }  // namespace
@@ -83,6 +85,14 @@ template <> struct Prod<1> { static constexpr int N = 1; static constexpr int a[
 template <> struct Prod<2> { static constexpr int N = 3; static constexpr int a[3] = {1, 0, 0}; static constexpr int b[3] = {0, 1, 0}; };
 template <> struct Prod<3> { static constexpr int N = 6; static constexpr int a[6] = {1, 2, 0, 1, 0, 0}; static constexpr int b[6] = {1, 0, 2, 0, 1, 0}; };
 
+// largest halo an instantiation serves: 3x3 kernels up to dilation 2, 5x5 up to dilation 3
+constexpr int bf_max_halo(int ksz) { return ksz == 3 ? 2 : 6; }
+// staging sweeps of the producers' 256 threads over the largest window: (4 MT + 2 halo) x (32 + 2 halo) pixels, 256 / Q per sweep
+constexpr int bf_pieces(int mt, int ns, int ksz) {
+    const int halo = bf_max_halo(ksz), xl = ns == 1 ? 32 : 64;
+    return ((4 * mt + 2 * halo) * (32 + 2 * halo) + xl - 1) / xl;
+}
+
 template <bool TG, int MT, int NS, int KSZ>
 __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
     constexpr int CP = NS == 1 ? 32 : 16;           // channels per pass
@@ -92,7 +102,9 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
     constexpr int P16 = NS == 3 ? 7 : 5;            // pixel stride in 16-byte units
     constexpr int TAPS = KSZ * KSZ;
     constexpr int TH = 4 * MT;
-    constexpr int RING = 3;
+    constexpr int PF = bf_pieces(MT, NS, KSZ);      // staging sweeps: the largest window of this instantiation
+    constexpr int RING = NS == 1 ? 8 : (NS == 2 ? 6 : 5);   // weight fragments RING - 1 taps ahead of the MFMAs that use them
+    constexpr int AHEAD = RING - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const GatherGeom& g = a.g;
     const int tid = threadIdx.x & 255;
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
     const int halo = g.pad;
     const int tile_w = 32 + 2 * halo, tile_h = TH + 2 * halo;
     const int wpix = tile_w * tile_h;
-    const int wbytes = wpix * P16 * 16;
+    const int wbytes = PF * XL * P16 * 16;          // (padding slots behind the window take the stores of idle pieces)
     const int npass = g.cin / CP;
 
     // this block's tiles: XCD x (blocks b with b % 8 == x share an L2) owns a contiguous eighth of the tile list, and a block
@@ -131,52 +143,95 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
 
     if (producer) {
         // ------------------------------------------------------------------------------------------------ producers
-        constexpr int PF = Q == 4 ? 14 : 28;            // pieces per thread: covers an (8 + 12) x (32 + 12) window
+        // Rules this section follows (each one measured on this kernel):
+        //  - NO control flow between the loads of an item, nor between its LDS stores: across a branch the compiler waits for
+        //    every outstanding load (vmcnt(0)), which serialises them.  Pieces beyond the window load element 0 and are
+        //    stored into the padding slots behind the window (the buffers hold PF * XL pixels); pieces outside the image
+        //    are zeroed by a select.
+        //  - the loads of item j + 2 are issued right after item j + 1 has been converted and stored, one whole phase before
+        //    they are needed: the HBM / L2 round trip is never on the critical path of a phase.
+        //  - the window position (ty, tx) of every piece is item-independent: packed once into one register per piece;
+        //    offsets are 32-bit (the launcher checks that the tensor has fewer than 2^31 elements).
         const int sq = tid % Q, spl = tid / Q;
-        const int ty0 = spl / tile_w, tx0 = spl - ty0 * tile_w;
-        const int dty = XL / tile_w, dtx = XL - dty * tile_w;
-        for (int j = 0; j < items; ++j) {
+        int pos[PF];
+        {
+            int ty = spl / tile_w, tx = spl - ty * tile_w;
+            const int dty = XL / tile_w, dtx = XL - dty * tile_w;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                pos[k] = (k * XL + spl < wpix) ? ((ty << 16) | tx) : -1;       // -1: a padding slot
+                ty += dty; tx += dtx;
+                if (tx >= tile_w) { tx -= tile_w; ++ty; }
+            }
+        }
+        const int rowc = g.win * g.cin;
+        const float lo_clamp = a.in_relu ? 0.f : -__builtin_huge_valf();       // max(v, lo): the ReLU on load, or nothing
+        auto issue = [&](int j, float4 (&pf)[PF], unsigned& ok) {
             int n, cot, oy0, ox0;
             decode(t0 + j / npass, n, cot, oy0, ox0);
-            const int pass = j % npass;
-            const float* src = a.in + (size_t)n * g.hin * g.win * g.cin + pass * CP + sq * 4;
-            unsigned char* buf = lds_raw + (size_t)(j & 1) * wbytes;
-            float4 pf[PF];
-            int ty = ty0, tx = tx0;
-            // straight-line loads (out-of-window / out-of-image pieces read element 0 and are zeroed below): a branch per
-            // load makes the compiler wait for earlier loads between them
+            const float* src = a.in + (size_t)n * g.hin * g.win * g.cin + (j % npass) * CP + sq * 4;
+            const int by = oy0 - halo, bx = ox0 - halo;
+            ok = 0;                                     // bit k: piece k of the item lies inside the image
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
-                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
-                const bool inb = k * XL + spl < wpix && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
-                pf[k] = *reinterpret_cast<const float4*>(src + (inb ? ((size_t)iy * g.win + ix) * g.cin : 0));
-                ty += dty; tx += dtx;
-                if (tx >= tile_w) { tx -= tile_w; ++ty; }
+                const int iy = by + (pos[k] >> 16), ix = bx + (pos[k] & 0xffff);
+                const bool inb = pos[k] >= 0 && (unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win;
+                ok |= inb ? (1u << k) : 0u;
+                const int off = (iy * rowc + ix * g.cin) & -(int)inb;          // (arithmetic, not a select: no branch)
+                pf[k] = *reinterpret_cast<const float4*>(src + off);
             }
-            ty = ty0; tx = tx0;
+        };
+        auto commit = [&](int j, const float4 (&pf)[PF], unsigned ok) {
+            unsigned char* buf = lds_raw + (size_t)(j & 1) * wbytes + spl * (P16 * 16) + sq * 8;
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
-                const int iy = oy0 - halo + ty, ix = ox0 - halo + tx;
-                const bool live = k * XL + spl < wpix;
-                const bool inb = live && iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
                 float4 v = pf[k];
-                if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool inb = (ok >> k) & 1u;
+                v.x = inb ? fmaxf(v.x, lo_clamp) : 0.f; v.y = inb ? fmaxf(v.y, lo_clamp) : 0.f;
+                v.z = inb ? fmaxf(v.z, lo_clamp) : 0.f; v.w = inb ? fmaxf(v.w, lo_clamp) : 0.f;
                 uint2 pl[NS];
                 split4<NS>(v, pl);
-                if (live) {
-                    unsigned char* px = buf + (size_t)(k * XL + spl) * (P16 * 16);
-                    if (NS == 1) {
-                        *reinterpret_cast<uint2*>(px + sq * 8) = pl[0];
-                    } else {
 #pragma unroll
-                        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(px + p * 32 + sq * 8) = pl[p];
-                    }
-                }
-                ty += dty; tx += dtx;
-                if (tx >= tile_w) { tx -= tile_w; ++ty; }
+                for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(buf + k * (XL * P16 * 16) + p * 32) = pl[p];
             }
-            __syncthreads();
+        };
+        if (a.probe & 1) {
+            for (int j = 0; j < items; ++j) __syncthreads();
+            return;
+        }
+        if constexpr (NS == 1) {
+            // one register set (28 pieces of 16 bytes): the loads of item j + 1 fly while the consumers work on item j - 1
+            float4 pf[PF];
+            unsigned ok;
+            issue(0, pf, ok);
+            commit(0, pf, ok);
+            if (items > 1) issue(1, pf, ok);
+            __syncthreads();                            // item 0 is staged
+            for (int j = 1; j < items; ++j) {           // the consumers work on item j - 1
+                commit(j, pf, ok);
+                if (j + 1 < items) issue(j + 1, pf, ok);
+                __syncthreads();
+            }
+        } else {
+            // two register sets: an item's loads are issued TWO phases before they are stored -- on the small maps a phase
+            // (75 .. 150 MFMAs) is shorter than an HBM round trip under load
+            float4 pa[PF], pb[PF];
+            unsigned oka, okb = 0;
+            issue(0, pa, oka);
+            if (items > 1) issue(1, pb, okb);
+            commit(0, pa, oka);
+            if (items > 2) issue(2, pa, oka);
+            __syncthreads();                            // item 0 is staged
+            for (int j = 1; j < items; j += 2) {
+                commit(j, pb, okb);
+                if (j + 2 < items) issue(j + 2, pb, okb);
+                __syncthreads();
+                if (j + 1 < items) {
+                    commit(j + 1, pa, oka);
+                    if (j + 3 < items) issue(j + 3, pa, oka);
+                    __syncthreads();
+                }
+            }
         }
         return;
     }
@@ -199,11 +254,11 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
         }
         s_sum = q_sum = 0.0;
     };
-    {   // weight fragments of the first two taps of the first item
+    {   // weight fragments of the first AHEAD taps of the first item
         int n, cot, oy0, ox0;
         decode(t0, n, cot, oy0, ox0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < AHEAD; ++i)
 #pragma unroll
             for (int f = 0; f < U2; ++f) bq[i][f] = wptr(cot, 0, i < TAPS ? i : 0)[f * 64];
     }
@@ -240,16 +295,17 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
 #pragma unroll
                 for (int f = 0; f < U2; ++f) aq[0][m][f] = lds4[lbase + m * lrow + toff + f * 2];
         }
+        if (!(a.probe & 2))
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            // weight fragments two taps ahead (the ring holds taps t, t + 1, t + 2), LDS fragments one tap ahead; the
+            // weight fragments AHEAD taps ahead (the ring holds taps t .. t + AHEAD), LDS fragments one tap ahead; the
             // scheduling barriers keep the requests IN FRONT of this tap's MFMAs (left alone, the compiler sinks the loads
             // to their first use and every tap waits out a full L2 round trip)
             {
-                const int tn = t + 2;
+                const int tn = t + AHEAD;
                 const uint4* wp = tn < TAPS ? wptr(cot, pass, tn) : wptr(cot2, pass2, tn - TAPS);
 #pragma unroll
-                for (int f = 0; f < U2; ++f) bq[(t + 2) % RING][f] = wp[f * 64];
+                for (int f = 0; f < U2; ++f) bq[(t + AHEAD) % RING][f] = wp[f * 64];
             }
             if (t + 1 < TAPS) {
                 const int toff = tap_off(t + 1);
@@ -272,15 +328,19 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the ring's two look-ahead slots become taps 0 and 1 of the next item
+        // the ring's look-ahead slots become taps 0 .. AHEAD - 1 of the next item
         {
-            uint4 n0[U2], n1[U2];
+            uint4 nx[AHEAD][U2];
 #pragma unroll
-            for (int f = 0; f < U2; ++f) { n0[f] = bq[TAPS % RING][f]; n1[f] = bq[(TAPS + 1) % RING][f]; }
+            for (int i = 0; i < AHEAD; ++i)
 #pragma unroll
-            for (int f = 0; f < U2; ++f) { bq[0][f] = n0[f]; bq[1][f] = n1[f]; }
+                for (int f = 0; f < U2; ++f) nx[i][f] = bq[(TAPS + i) % RING][f];
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+                for (int f = 0; f < U2; ++f) bq[i][f] = nx[i][f];
         }
-        if (pass == npass - 1) {
+        if (pass == npass - 1 && !(a.probe & 4)) {
             // ---- epilogue: lane = output channel co, register v = pixel (row MT*wave + m, column acc_row(v, h))
             if (a.stats != nullptr && (n != stat_n || cot != stat_cot)) {
                 flush_stats();
@@ -305,9 +365,12 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
                     }
 #pragma unroll
                     for (int v = 0; v < 16; ++v) outp[row + (size_t)acc_row(v, h) * g.cout] = acc[m][v];
-                    if (a.stats != nullptr) {
+                    if (a.stats != nullptr) {               // 16 values in fp32, then into the fp64 running sums
+                        float s16 = 0.f, q16 = 0.f;
 #pragma unroll
-                        for (int v = 0; v < 16; ++v) { s_sum += acc[m][v]; q_sum += (double)acc[m][v] * acc[m][v]; }
+                        for (int v = 0; v < 16; ++v) { s16 += acc[m][v]; q16 = fmaf(acc[m][v], acc[m][v], q16); }
+                        s_sum += (double)s16;
+                        q_sum += (double)q16;
                     }
                 } else {
 #pragma unroll
@@ -336,15 +399,16 @@ bool bf_gather_ok(const GatherGeom& g, int terms) {
     if (g.stride != 1 || g.kh != g.kw || (g.kh != 3 && g.kh != 5)) return false;
     if (g.pad != g.dil * (g.kh / 2) || g.hout != g.hin || g.wout != g.win) return false;
     if (g.cin % (terms == 1 ? 32 : 16) != 0 || g.cout % 32 != 0) return false;
-    if (g.wout < 32 || g.hout < 8 || g.pad > 6) return false;
+    if (g.wout < 32 || g.hout < 8 || g.pad > bf_max_halo(g.kh)) return false;
     return (long)g.n * g.hin * g.win * g.cin < 0x7fffffffL && (long)g.n * g.hout * g.wout * g.cout < 0x7fffffffL;
 }
 
-// rows per wave: 2 (8 x 32 tiles) while that still gives every CU four tiles, else 1; bf16x6 windows only fit with 1
+// rows per wave: 2 (8 x 32 tiles) while that still gives every CU two tiles, else 1; bf16x6 windows only fit with 1
 static int bf_mt(const GatherGeom& g, int terms) {
     if (terms == 6) return 1;
     const long tiles8 = (long)((g.wout + 31) / 32) * ((g.hout + 7) / 8) * g.n * (g.cout / 32);
-    return tiles8 >= 1024 ? 2 : 1;
+    static const int thr = getenv("SENAS_BF_MT2_TILES") ? atoi(getenv("SENAS_BF_MT2_TILES")) : 512;       // (tuning override; measured: 8-row tiles from 2 tiles per CU on)
+    return tiles8 >= thr ? 2 : 1;
 }
 
 template <bool TG, int MT, int NS, int KSZ>
@@ -357,7 +421,10 @@ static int launch_bf(const GatherGeom& g, const float* in, const void* wimg, flo
     a.tiles_y = (g.hout + TH - 1) / TH;
     a.cot = g.cout / 32;
     a.ntiles = a.cot * g.n * a.tiles_y * a.tiles_x;
-    const size_t wbytes = (size_t)(32 + 2 * g.pad) * (TH + 2 * g.pad) * P16 * 16;
+    static const int probe = getenv("SENAS_BF_PROBE") ? atoi(getenv("SENAS_BF_PROBE")) : 0;
+    a.probe = probe;
+    constexpr int XL = NS == 1 ? 32 : 64;
+    const size_t wbytes = (size_t)bf_pieces(MT, NS, KSZ) * XL * P16 * 16;
     const size_t bytes = 2 * wbytes;
     if (bytes > 160 * 1024) { set_error_msg("conv_bf: window does not fit in LDS"); return SENAS_EUNSUPPORTED; }
     if (bytes > 64 * 1024)

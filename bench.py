@@ -376,6 +376,22 @@ def pmc_traffic(name):
     return None, None
 
 
+def search_traffic():
+    """HBM bytes per search step from the committed rocprofv3 --pmc passes over tools/search_profile.py (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950; tools/pmc_traffic.py --all --steps N), with the time of the
+    three heaviest kernel families from the committed steady-state table.  Returns (bytes or None, source, families)."""
+    for fname in ('r3_pmc_traffic_search.json',):
+        path = os.path.join(ROOT, 'profiles', fname)
+        try:
+            pmc = json.load(open(path))
+            fam = list(pmc.get('families', {}).items())[:3]
+            return int(pmc['hbm_bytes_per_step']), 'profiles/%s (rocprofv3 --pmc passes of tools/search_profile.py --eager, %d steps; not measured in this run)' \
+                % (fname, pmc['steps']), {k: v for k, v in fam}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None, None
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -584,12 +600,15 @@ def bench_search(dev, steps, rank, world, use_graph=True):
     # forward + data gradients, no weight gradients -- and is charged 2/3 of that
     gbytes = 4 * SUPERNET_GB_PER_IMG * (1.0 + 2.0 / 3.0)
     achieved = gbytes / dt
+    traffic, traffic_source, top_families = search_traffic()
     res = {'workload': 'BASELINE configs[%d]: NAS supernet c=32 depth=5 nodes=3, arch step (4 val) + weight step (4 train) per GPU, 1x256x256'
                        % (2 if world == 1 else 3),
            'value': round(4 * world / dt, 3), 'unit': 'train images/s', 'n_gpus': world, 'train_images_per_sec': round(4 * world / dt, 3),
            'ms_per_step': round(dt * 1e3, 2), 'steps': steps, 'timed_region_s': round(elapsed, 3), 'hip_graph': bool(search.graphed),
            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+                        'traffic_gbs_at_this_step_time': round(traffic / dt / 1e9, 1) if traffic else None,
+                        'top_families_by_traffic': top_families,
                         'algorithmic_gb_per_step': round(gbytes, 2),
                         'convention': '4 img x 5.690 GB (weight pass, fwd+bwd) + 4 img x 2/3 x 5.690 GB (architecture pass: '
                                       'weights frozen, forward + data gradients only); whole step, not one kernel -- the step is '

@@ -202,6 +202,34 @@ int senas_blend2_fwd(int64_t numel, const float* x1, const float* x2, const floa
 int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1, const float* x2, const float* g, float* dx1,
                      float* dx2, double* dg, void* stream);
 
+/* ---- the architecture tensors of the supernet, one launch per direction --------------------------------------------------
+ * NAS.forward (search/senas_search.py:246-260): row softmax of alphas_dn / alphas_up / alphas_dn_nm / alphas_up_nm ([k][ops]),
+ * softmax of betas_dn / betas_up over the node windows [i : 2i + 2] (the reference's overlapping slices, :254-257), row
+ * softmax of gamma ([grows][2]); and what every MixedOp / Cell of a kind then multiplies in (search/cell.py:33-36,100-106):
+ *     M[kind][e][o] = beta_soft[kind][e] * alpha_soft[kind, NORM edge ? the *_nm table : the dn / up table][e][o]
+ * kind 0 = down cell (NORM edges: input state >= 2), kind 1 = up cell (NORM edges: every input state but 1); edges in the
+ * order node 0 (states 0, 1), node 1 (states 0..2), ...  k = sum over nodes of (2 + i).
+ * Backward: dM[kind] / dG are the tables the cell nodes (senas_node_bwd, dmix_accumulate) and the blends (senas_blend2_bwd)
+ * ADDED their gradients into; the seven parameter gradients are OVERWRITTEN.  d_alpha[3] == NULL: alphas_up_nm IS alphas_dn_nm
+ * (NAS(use_sharing=True), senas_search.py:148-150) and d_alpha[2] receives both contributions.                          */
+typedef struct senas_arch_mix {
+    const float* alpha[4];      /* dn, up, dn_nm, up_nm */
+    const float* beta[2];       /* dn, up */
+    const float* gamma;
+    float* s_alpha[4];
+    float* s_beta[2];
+    float* s_gamma;
+    float* M[2];
+    const float* dM[2];
+    const double* dG;
+    float* d_alpha[4];
+    float* d_beta[2];
+    float* d_gamma;
+    int32_t k, ops, nodes, grows;
+} senas_arch_mix;
+int senas_arch_mix_fwd(const senas_arch_mix* a, void* stream);
+int senas_arch_mix_bwd(const senas_arch_mix* a, void* stream);
+
 /* ---- batch-norm statistics --------------------------------------------------------------------
  * Per-image per-channel sum / sum-of-squares of x [n][hw][c] ADDED into stats double[n][c][2].   */
 int senas_chan_stats(int n, int64_t hw, int c, const float* x, double* stats, void* stream);
@@ -410,10 +438,12 @@ typedef struct senas_node_desc {
  *          zeroes) -- the statistics the BatchNorm2d of an 'identity' candidate reading this node needs
  *   y2 (optional): y is ALSO written as a channel slice of a wider NHWC tensor (y2_pixel_stride floats between pixels) --
  *          the node's place in the concatenation the cell's post-process convolution reads (models/senas_model.py:64),
- *          instead of a torch.cat copy; y may then be NULL (a node that nothing but the concatenation reads)            */
+ *          instead of a torch.cat copy; y may then be NULL (a node that nothing but the concatenation reads);
+ *          y2_zero_pad zero channels are written behind the slice (search/cell.py:110: the 24-channel concatenation of a
+ *          search cell is padded to a full 32-channel tile for the post-process convolution)                              */
 int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                    float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1, uint8_t* mask8,
-                   double* out_stats, float* y2, int64_t y2_pixel_stride, void* stream);
+                   double* out_stats, float* y2, int64_t y2_pixel_stride, int y2_zero_pad, void* stream);
 /* Backward of the above.  p1: double[n][c], p2: double[nterms][n][c], both ZEROED by the caller.
  *   dgamma[t], dbeta[t]: float[c] destinations, one pair per term (host arrays of device pointers);
  *   dmix: float[nterms] or NULL, overwritten -- or, with dmix_accumulate != 0, added to: the cells of one kind share

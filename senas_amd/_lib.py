@@ -43,6 +43,14 @@ class DsTailItem(C.Structure):
                 ('dbeta1', C.c_void_p), ('dw', C.c_void_p), ('dw_acc', C.c_void_p)]
 
 
+class ArchMix(C.Structure):
+    """senas_arch_mix (include/senas_hip.h)."""
+    _fields_ = [('alpha', C.c_void_p * 4), ('beta', C.c_void_p * 2), ('gamma', C.c_void_p), ('s_alpha', C.c_void_p * 4),
+                ('s_beta', C.c_void_p * 2), ('s_gamma', C.c_void_p), ('M', C.c_void_p * 2), ('dM', C.c_void_p * 2), ('dG', C.c_void_p),
+                ('d_alpha', C.c_void_p * 4), ('d_beta', C.c_void_p * 2), ('d_gamma', C.c_void_p),
+                ('k', C.c_int32), ('ops', C.c_int32), ('nodes', C.c_int32), ('grows', C.c_int32)]
+
+
 class SumItem(C.Structure):
     """senas_sum_item (include/senas_hip.h)."""
     _fields_ = [('part', C.c_void_p), ('dw', C.c_void_p), ('kind', C.c_int32), ('A', C.c_int32), ('B', C.c_int32), ('taps', C.c_int32),
@@ -129,7 +137,7 @@ SIGNATURES = {
     'senas_dice_ce_bwd': (_I, [_L, _I, _P, _P, _P, _P, _P, _P]),
     'senas_seg_metric_update': (_I, [_I, _L, _I, _P, _P, _F, _P, _P, _P, _P]),
     'senas_sgd_clip_step': (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
-    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_fwd_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     'senas_conv2d_bwd_data_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
@@ -138,6 +146,8 @@ SIGNATURES = {
     'senas_conv2d_pack_layout_lp': (_I, [_G, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'senas_pack_batched_lp': (_I, [_P, _I, _L, _P]),
     'senas_conv2d_kernel_name_lp': (C.c_char_p, [_G, _I, _I]),
+    'senas_arch_mix_fwd': (_I, [C.POINTER(ArchMix), _P]),
+    'senas_arch_mix_bwd': (_I, [C.POINTER(ArchMix), _P]),
     'senas_conv2d_kernel_name': (C.c_char_p, [_G, _I]),
     'senas_last_error': (C.c_char_p, []),
     'senas_abi_version': (_I, []),

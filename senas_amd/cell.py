@@ -300,35 +300,56 @@ class Cell(nn.Module):
         add_state(self.preprocess0(in0))
         add_state(self.preprocess1(in1))
         offset = 0
+        # the node outputs go straight into the (zero-padded) buffer the post-process convolution reads: every node writes its
+        # channel slice from its own kernel, the last one also the zero channels behind it (node.bn_combine cat=...) -- no
+        # torch.cat launch, and a last node that nothing else reads is stored nowhere else
+        catbuf, c_cat = None, 0
         for i in range(nodes):
             node_terms = []
             for j in range(nin + i):
                 by_pos = terms.pop(offset + j)
                 node_terms += [by_pos[p] for p in sorted(by_pos)]
             offset += nin + i
+            cat = None
+            ref = next((t.z for t in node_terms if t.z is not None), None)
+            if ref is not None and self._post_padded(ref.shape[1] * nodes) and (catbuf is not None or i == 0):
+                n, c, h, w = ref.shape
+                if catbuf is None:
+                    catbuf, c_cat = F.new_nhwc(n, 32, h, w, ref), c
+                last = i == nodes - 1
+                cat = (catbuf, i * c, not last, 32 - nodes * c if last else 0)
+            elif catbuf is not None:
+                raise F.SenasHipError('search cell: a node without tensor terms behind a concatenation buffer')
             # a node that feeds later nodes is read by their 'identity' candidates, whose BatchNorm2d needs its channel sums
-            add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True, out_stats=self.training and i < nodes - 1))
-        return self._post(states[nin:nin + nodes])
+            add_state(F.bn_combine(node_terms, mix=mixes[i], relu=True, out_stats=self.training and i < nodes - 1, cat=cat))
+        return self._post(states[nin:nin + nodes], catbuf, c_cat)
 
-    def _post(self, outs):
+    def _post_padded(self, c_in):
+        """Does the post-process convolution run on a zero-padded 32-channel concatenation?  (Three 8-channel nodes make 24
+        input channels, which fall off the LDS convolution / weight-gradient kernels.)"""
+        return self.stacked and c_in % 16 != 0 and c_in <= 32 and c_in % 4 == 0
+
+    def _post(self, outs, catbuf=None, c_cat=0):
         """post_process on the concatenated node outputs.  Three 8-channel nodes make 24 input channels, which fall off
-        the LDS convolution / weight-gradient kernels (16-channel passes, 32-row tiles): pad the concatenation with 8 zero
-        channels and the weight with 8 zero input planes (a persistent padded buffer, functional.StackedWeight) -- same
-        result, 32 -> 32 kernels."""
+        the LDS convolution / weight-gradient kernels (16-channel passes, 32-row tiles): the concatenation carries 8 zero
+        channels and the weight 8 zero input planes (a persistent padded buffer, functional.StackedWeight) -- same
+        result, 32 -> 32 kernels.  ``catbuf``: the padded concatenation the nodes have already written (Cell.forward)."""
         post = self.post_process
         c_in = sum(o.shape[1] for o in outs)
-        if not self.stacked or c_in % 16 == 0 or c_in > 32 or c_in % 4 != 0:
+        if not self._post_padded(c_in):
             return post(torch.cat(outs, dim=1))
         stacks = self.__dict__.setdefault('_stacks', {})
         key = ('post', id(post.conv))
         if key not in stacks:
             stacks[key] = F.StackedWeight([post.conv.weight], 1, pad_to=32)
-        o0 = outs[0]
-        zkey = ('zeros', o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3], str(o0.device))
-        if zkey not in stacks:                           # a constant: made once, only ever read
-            stacks[zkey] = torch.zeros((o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3]), device=o0.device).contiguous(memory_format=torch.channels_last)
-        zeros = stacks[zkey]
-        x = torch.cat(list(outs) + [zeros], dim=1)
+        if catbuf is not None:
+            x = F.cat_slices(catbuf, c_cat, outs)
+        else:
+            o0 = outs[0]
+            zkey = ('zeros', o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3], str(o0.device))
+            if zkey not in stacks:                           # a constant: made once, only ever read
+                stacks[zkey] = torch.zeros((o0.shape[0], 32 - c_in, o0.shape[2], o0.shape[3]), device=o0.device).contiguous(memory_format=torch.channels_last)
+            x = torch.cat(list(outs) + [stacks[zkey]], dim=1)
         conv = post.conv
         z, st = F.conv2d(x, stacks[key].tensor(), stride=1, pad=conv.padding[0], dil=1, want_stats=post.norm.training)
         return F.bn_combine([F.Term(z, post.norm, stats=st)])

@@ -172,7 +172,9 @@ template <int V>
 __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n, const ZTable& z, const float* lds,
                                                const float* bias, const float* __restrict__ residual, int relu,
                                                float* __restrict__ y, uint8_t* __restrict__ mask8, double* __restrict__ out_stats,
-                                               float* __restrict__ y2, int y2s) {
+                                               float* __restrict__ y2, int y2s, int y2pad = 0) {
+    // y2pad: zero channels written behind the slice (the padding that brings a 24-channel concatenation to a full 32-channel
+    // tile, search cell post-process: the thread that owns a pixel's last channel group writes them)
     // y2 (optional): the same values again as a channel slice of a wider NHWC tensor (pixel stride y2s floats) -- the node's
     // place in the concatenation the cell's post-process convolution reads (models/senas_model.py:64), so that no
     // torch.cat launch copies it there; y itself may then be NULL (a node nothing else reads)
@@ -210,7 +212,15 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
         if (y != nullptr) stv<V>(y + off, acc);
-        if (y2 != nullptr) stv<V>(y2 + pixel * y2s + ch, acc);
+        if (y2 != nullptr) {
+            stv<V>(y2 + pixel * y2s + ch, acc);
+            if (y2pad > 0 && ch + V == c) {
+                float zero[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) zero[j] = 0.f;
+                for (int q = 0; q < y2pad; q += V) stv<V>(y2 + pixel * y2s + c + q, zero);
+            }
+        }
         if constexpr (V == 4) {
             ch_thr = ch;
             stats_accumulate4(ost, out_stats, true, n, c, ch, acc, true);
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
                                                                const float* __restrict__ coef, const float* __restrict__ shiftc,
                                                                const float* __restrict__ residual, int relu,
                                                                float* __restrict__ y, uint8_t* __restrict__ mask8,
-                                                               double* __restrict__ out_stats, float* __restrict__ y2, int y2s) {
+                                                               double* __restrict__ out_stats, float* __restrict__ y2, int y2s, int y2pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
     const int n = blockIdx.y;
     float* bias = lds + nterms * c;
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
         bias[ch] = b;
     }
     __syncthreads();
-    combine_stream<V>(hw, c, nterms, n, z, lds, bias, residual, relu, y, mask8, out_stats, y2, y2s);
+    combine_stream<V>(hw, c, nterms, n, z, lds, bias, residual, relu, y, mask8, out_stats, y2, y2s, y2pad);
 }
 
 // ------------------------------------------------------------------------------------------ forward, fused
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
                                                              float* __restrict__ y, uint8_t* __restrict__ mask8,
                                                              float* __restrict__ coefs, float* __restrict__ gate,
                                                              float* __restrict__ se_m, float* __restrict__ se_a1,
-                                                             double* __restrict__ out_stats, float* __restrict__ y2, int y2s) {
+                                                             double* __restrict__ out_stats, float* __restrict__ y2, int y2s, int y2pad) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int n = blockIdx.y, nimg = d.n, c = d.c, T = d.nterms;
     const bool first = blockIdx.x == 0, writer0 = first && n == 0;
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
     }
     if (owner) bias[ch] = bsum;
     __syncthreads();
-    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8, out_stats, y2, y2s);
+    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8, out_stats, y2, y2s, y2pad);
 }
 
 static size_t fused_fwd_lds(const NodeDesc& d) {
@@ -880,7 +890,7 @@ static bool fill_ztable(const NodeDesc& d, const float* const* z, const int32_t*
 
 extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z, const int32_t* z_pixel_stride, const float* residual, float* y,
                               float* coefs, float* gate, float* coef, float* shiftc, float* se_m, float* se_a1,
-                              uint8_t* mask8, double* out_stats, float* y2, int64_t y2_pixel_stride, void* stream) {
+                              uint8_t* mask8, double* out_stats, float* y2, int64_t y2_pixel_stride, int y2_zero_pad, void* stream) {
     NodeDesc d;
     SENAS_REQUIRE(fill_desc(desc, d), "node_fwd: bad descriptor");
     SENAS_REQUIRE(z && (y || y2) && coefs && gate && coef && shiftc, "node_fwd: null pointer");
@@ -888,6 +898,9 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
                                     (desc->c % 4 != 0 || (y2_pixel_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(y2) & 15) == 0))),
                   "node_fwd: the second destination must keep 16-byte alignment and a pixel stride >= c");
     const int y2s = (int)y2_pixel_stride;
+    const int y2pad = y2 != nullptr ? y2_zero_pad : 0;
+    SENAS_REQUIRE(y2pad >= 0 && (y2pad == 0 || (desc->c % 4 == 0 && y2pad % 4 == 0 && desc->c + y2pad <= y2s)),
+                  "node_fwd: the zero padding behind the second destination must be whole 16-byte pieces inside the pixel");
     ZTable zt{};
     SENAS_REQUIRE(fill_ztable(d, z, z_pixel_stride, zt), "node_fwd: a strided term must keep 16-byte alignment and stride >= c");
     bool any_se = false;
@@ -909,8 +922,8 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
         const unsigned fat = (unsigned)(1024 / (d.n > 0 ? d.n : 1));
         if (gx > fat && fat >= 1) gx = fat;
         dim3 grid(gx, d.n);
-        if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s);
-        else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s);
+        if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s, y2pad);
+        else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s, y2pad);
         return launch_status("node_fwd (fused)");
     }
     const size_t lds1 = prepare_fwd_lds(d);
@@ -919,8 +932,8 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     const int V = (d.c % 4 == 0) ? 4 : 1;
     dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
     const size_t lds2 = ((size_t)d.nterms * d.c + d.c) * sizeof(float);
-    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr, out_stats, y2, y2s);
-    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr, (double*)nullptr, y2, y2s);
+    if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr, out_stats, y2, y2s, y2pad);
+    else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr, (double*)nullptr, y2, y2s, y2pad);
     return launch_status("node_fwd");
 }
 

@@ -602,6 +602,97 @@ class _EdgeMix(torch.autograd.Function):
         return torch.where(is_norm, dW, zero), torch.where(is_norm, zero, dW), (g * W).sum(1), None, None
 
 
+class _ArchMix(torch.autograd.Function):
+    """softmax(alpha) x 4, the windowed softmax(beta) x 2, softmax(gamma) and the two per-kind mixing matrices in ONE launch
+    (senas_arch_mix_fwd); backward: from the accumulation tables the nodes / blends added into, straight to the seven
+    parameter gradients in one more (senas_arch_mix_bwd).  Outputs: M_dn, M_up, softmax(gamma) (differentiable: they tie the
+    consumers to this node) and the six softmax tables (bookkeeping only)."""
+
+    @staticmethod
+    def forward(ctx, nodes, dM_dn, dM_up, dG, a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma):
+        params = [_dev(t).contiguous() for t in (a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma)]
+        k, ops = params[0].shape
+        dev_ = params[0].device
+        new = lambda *shape: torch.empty(shape, device=dev_, dtype=torch.float32)
+        soft = [new(k, ops) for _ in range(4)] + [new(k), new(k), new(*gamma.shape)]
+        M = [new(k, ops), new(k, ops)]
+        a = _lib.ArchMix()
+        for i in range(4):
+            a.alpha[i], a.s_alpha[i] = params[i].data_ptr(), soft[i].data_ptr()
+        for i in range(2):
+            a.beta[i], a.s_beta[i], a.M[i] = params[4 + i].data_ptr(), soft[4 + i].data_ptr(), M[i].data_ptr()
+        a.gamma, a.s_gamma = params[6].data_ptr(), soft[6].data_ptr()
+        a.k, a.ops, a.nodes, a.grows = k, ops, nodes, gamma.shape[0]
+        _lib.check(_lib.lib().senas_arch_mix_fwd(C.byref(a), _stream()), 'senas_arch_mix_fwd')
+        ctx.save_for_backward(dM_dn, dM_up, dG, *params, *soft, *M)
+        ctx.nodes = nodes
+        ctx.shared_nm = a_up_nm.data_ptr() == a_dn_nm.data_ptr()
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*soft[:6])
+        return (M[0], M[1], soft[6]) + tuple(soft[:6])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        dM_dn, dM_up, dG = saved[:3]
+        params, soft, M = saved[3:10], saved[10:17], saved[17:19]
+        if any(g is not None for g in grads[:3]):
+            raise SenasHipError('arch_mix: gradients reach the mixing tables through autograd; they are accumulated in place')
+        k, ops = params[0].shape
+        dests, outs = [], []
+        for i, p in enumerate(params):
+            if i == 3 and ctx.shared_nm:                 # alphas_up_nm IS alphas_dn_nm: its gradient rides in that one's
+                dests.append(None)
+                outs.append(None)
+                continue
+            d, g = wgrad_dest(p)
+            dests.append(d)
+            outs.append(g if p.numel() else None)        # (an empty gamma -- depth 2 -- has no gradient, as in the reference)
+        a = _lib.ArchMix()
+        for i in range(4):
+            a.alpha[i], a.s_alpha[i] = params[i].data_ptr(), soft[i].data_ptr()
+            a.d_alpha[i] = dests[i].data_ptr() if dests[i] is not None else None
+        for i in range(2):
+            a.beta[i], a.s_beta[i], a.M[i] = params[4 + i].data_ptr(), soft[4 + i].data_ptr(), M[i].data_ptr()
+            a.d_beta[i] = dests[4 + i].data_ptr()
+        a.dM[0], a.dM[1], a.dG = dM_dn.data_ptr(), dM_up.data_ptr(), dG.data_ptr()
+        a.gamma, a.s_gamma, a.d_gamma = params[6].data_ptr(), soft[6].data_ptr(), dests[6].data_ptr()
+        a.k, a.ops, a.nodes, a.grows = k, ops, ctx.nodes, params[6].shape[0]
+        _lib.check(_lib.lib().senas_arch_mix_bwd(C.byref(a), _stream()), 'senas_arch_mix_bwd')
+        return (None, None, None, None) + tuple(outs)
+
+
+class ArchTables(object):
+    """What NAS.forward hands the network in place of ~20 softmax / select / multiply / concatenate launches: the softmax
+    tables (the positional arguments of SenasSearch.forward), with the mixing matrices of both cell kinds parked on the beta
+    tables (Cell._node_mixes looks there) and the blend table on the gamma one (SenasSearch: functional.GammaRows)."""
+
+    def __init__(self, nodes, a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma):
+        k, ops = a_dn.shape
+        dev_ = a_dn.device
+        dM = [zeros32(k * ops, dev_).view(k, ops) for _ in range(2)]
+        dG = zeros64(tuple(gamma.shape), dev_)
+        out = _ArchMix.apply(nodes, dM[0], dM[1], dG, a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma)
+        M_dn, M_up, s_gamma = out[:3]
+        self.s_dn, self.s_up, self.s_dn_nm, self.s_up_nm, self.bs_dn, self.bs_up = out[3:]
+        self.s_gamma = s_gamma
+        rows = GammaRows.__new__(GammaRows)
+        rows.table, rows.acc = s_gamma, dG
+        s_gamma._senas_rows = rows
+        for kind, (M, bs, w_norm, w_chg) in enumerate(((M_dn, self.bs_dn, self.s_dn_nm, self.s_dn), (M_up, self.bs_up, self.s_up_nm, self.s_up))):
+            kinds, mixes, offset = [], [], 0
+            for i in range(nodes):
+                cnt = 2 + i
+                kinds += [(j >= 2) if kind == 0 else (j != 1) for j in range(cnt)]
+                mixes.append(SharedMix(M, offset * ops, cnt * ops, dM[kind]))
+                offset += cnt
+            bs._senas_mix = {(id(w_norm), id(w_chg), tuple(kinds)): mixes}
+
+    def args(self):
+        """(alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma) as SenasSearch.forward takes them."""
+        return self.s_dn_nm, self.s_up_nm, self.s_dn, self.s_up, self.bs_dn, self.bs_up, self.s_gamma
+
+
 class SharedMix(object):
     """Rows [off, off + rows) of an _EdgeMix matrix as the mixing weights of one node: ``M`` (for autograd ordering and
     the kernel's read), the flat offset / length of the node's weights in it, and the accumulation buffer ``dM``."""

@@ -12,6 +12,43 @@ import torch.nn as nn
 from .operations import ConvBn, Stem1
 
 
+class FanPlan(object):
+    """Readers of the tensors a macro-grid forward pass produces.  A tensor with several consumers (a cell output that
+    is a skip input of later cells, the in1 of the next cell and a blend operand) would have its gradient accumulated by
+    autograd in n - 1 binary adds; with the number of readers known up front every reader gets its own alias and the
+    gradient is ONE n-ary sum (functional.fan_out).  The schedule is static, so the counts come from a dry run of the
+    same forward code: ``put`` / ``get`` count in dry mode and hand out aliases in live mode."""
+
+    def __init__(self):
+        self.counts, self.live, self.dry = {}, {}, True
+
+    def put(self, key, value=None):
+        if self.dry:
+            self.counts[key] = 0
+        else:
+            from . import functional as F
+            n = self.counts[key]
+            self.live[key] = iter(F.fan_out(value, n)) if n > 1 else iter([value] * max(n, 1))
+        return key
+
+    def get(self, key):
+        if self.dry:
+            self.counts[key] += 1
+            return None
+        return next(self.live[key])
+
+    def start(self):
+        """Switch to live mode for one forward pass (the counts stay)."""
+        self.dry = False
+        self.live = {}
+        return self
+
+    def __deepcopy__(self, memo):
+        fresh = FanPlan()                 # (the aliases of the last pass are not part of a copied model)
+        fresh.counts, fresh.dry = dict(self.counts), self.dry
+        return fresh
+
+
 def gamma_index(i, j):
     """Index into the flat gamma table of the skip feeding row i+j from column j."""
     return sum(range(i + j)) + j

@@ -89,9 +89,10 @@ class _Node(torch.autograd.Function):
         se_a1 = torch.empty((T, n, SE_MID_MAX), device=dev, dtype=torch.float32) if ns else None
         # the node's output: a dense tensor, and / or its channel slice of the cell's concatenation buffer (meta['cat'])
         cat = meta.get('cat')
-        y2, y2s = None, 0
+        y2, y2s, y2pad = None, 0, 0
         if cat is not None:
-            buf, off, dense = cat
+            buf, off, dense = cat[:3]
+            y2pad = cat[3] if len(cat) > 3 else 0        # zero channels this node writes behind its slice
             y2s = buf.shape[1]
             y2 = torch.empty(0, device=dev, dtype=torch.float32).set_(buf.untyped_storage(), buf.storage_offset() + off, (n, c, h, w),
                                                                      (h * w * y2s, 1, w * y2s, y2s))
@@ -104,7 +105,7 @@ class _Node(torch.autograd.Function):
         zp = _arr([z.data_ptr() if z is not None else None for z in zfull])
         _lib.check(L.senas_node_fwd(C.byref(d), zp, zstrides, F._p(res), F._p(y), coefs.data_ptr(), gate.data_ptr(),
                                     scratch[0].data_ptr(), scratch[1].data_ptr(), F._p(se_m), F._p(se_a1), F._p(mask8),
-                                    F._p(meta.get('out_stats')), F._p(y2), y2s, F._stream()),
+                                    F._p(meta.get('out_stats')), F._p(y2), y2s, y2pad, F._stream()),
                    'senas_node_fwd')
         ctx.meta = meta
         ctx.has_mix, ctx.has_res, ctx.nflat = mix is not None, residual is not None, len(flat)
@@ -202,8 +203,9 @@ def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=
     SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
     and optionally ReLU -- one read of every term, one write.  ``out_stats``: also leave the per-image channel
     sums of the result on it (``y._senas_stats``), for a consumer that batch-normalises it directly.
-    ``cat = (buffer [n, C, h, w] NHWC, channel offset, dense)``: the result is (also) written into that channel slice of
-    the cell's concatenation buffer; with ``dense`` False nothing else is written and the slice itself is returned."""
+    ``cat = (buffer [n, C, h, w] NHWC, channel offset, dense[, zero_pad])``: the result is (also) written into that channel
+    slice of the cell's concatenation buffer (followed by ``zero_pad`` zero channels); with ``dense`` False nothing else is
+    written and the slice itself is returned."""
     T = len(terms)
     if T == 0 or T > _lib.MAX_TERMS:
         raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))

@@ -10,7 +10,7 @@ import torch.nn.functional as tf
 from . import functional as F
 from .cell import Cell
 from .genotype import GenoParser, Genotype
-from .grid import MacroGrid, gamma_index
+from .grid import FanPlan, MacroGrid, gamma_index
 from .operations import DownOps, NormOps, ReLUConv, UpOps
 from .utils import weights_init
 
@@ -35,12 +35,52 @@ class SenasSearch(MacroGrid):
         self._meta_node_num = meta_node_num
 
     def forward(self, x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma):
+        if self.cut is not None:              # two-part backward (several ranks): the cut tensors are re-leafed, keep it simple
+            return self._forward_plain(x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma)
+        plan = self.__dict__.get('_fan_plan')
+        if plan is None:                      # dry run of the schedule below: how many readers every tensor has
+            plan = self.__dict__['_fan_plan'] = FanPlan()
+            self._walk(plan, None, None)
+        return self._walk(plan.start(), x, (alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma))
+
+    def _walk(self, plan, x, arch):
+        """The forward schedule (search/senas_search.py:96-107) against a FanPlan: dry (x is None: count readers) or live."""
+        live = x is not None
+        if live:
+            alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma = arch
+            rows = getattr(gamma, '_senas_rows', None) or F.GammaRows(gamma)      # the blends read their gamma pair in place
+        depth = self._depth
+        s0 = plan.put('s0', self.stem0(x) if live else None)
+        outs = [plan.put(('o', 0, 0), self.stem1(plan.get(s0)) if live else (plan.get(s0), None)[1])]
+        ver = [0] * depth
+        for j in range(1, depth):
+            a, b = plan.get(s0 if j == 1 else outs[j - 2]), plan.get(outs[j - 1])
+            outs.append(plan.put(('o', j, 0), self.blocks[0][j](a, b, alpha_dn_nm, alpha_dn, beta_dn) if live else None))
+        for j in reversed(range(depth - 1)):
+            for i in range(1, depth - j):
+                skips = [plan.get(outs[j])]
+                for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
+                    a, b = plan.get(outs[j + k - 1]), plan.get(outs[j + k])
+                    skips.append(F.blend2_row(a, b, rows, gamma_index(k, j)) if live else None)
+                in1 = plan.get(outs[i + j])
+                ver[i + j] += 1
+                y = self.blocks[i][j](skips[0] if len(skips) == 1 else torch.cat(skips, dim=1), in1, alpha_up_nm, alpha_up, beta_up) if live else None
+                outs[i + j] = plan.put(('o', i + j, ver[i + j]), y)
+        head = self.head_block[-1]
+        tails = outs if self._supervision else outs[-1:]
+        res = []
+        for o in tails:
+            a, b = plan.get(s0), plan.get(o)
+            res.append(head(a, b, alpha_up_nm, alpha_up, beta_up) if live else None)
+        return res
+
+    def _forward_plain(self, x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma):
         s0 = self.stem0(x)
         outs = [self.stem1(s0)]
         for j in range(1, self._depth):
             outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1], alpha_dn_nm, alpha_dn, beta_dn))
         s0, outs = self._down_done(s0, outs)
-        rows = F.GammaRows(gamma)                    # the blends read their gamma pair in place and accumulate its gradient
+        rows = getattr(gamma, '_senas_rows', None) or F.GammaRows(gamma)      # the blends read their gamma pair in place
         for j in reversed(range(self._depth - 1)):
             for i in range(1, self._depth - j):
                 skips = [outs[j]]
@@ -120,6 +160,12 @@ class NAS(nn.Module):
                 tf.softmax(self.gamma, dim=-1))
 
     def forward(self, x):
+        if x.is_cuda and self.alphas_dn.is_cuda and self.net.cut is None and not getattr(self, '_plain_arch', False):
+            # one launch for every softmax and both mixing matrices (functional.ArchTables); the positional arguments keep
+            # the reference's meaning (search/senas_search.py:259-260).  (Not under a two-part backward: its node would be
+            # entered from both parts.)
+            return self.net(x, *F.ArchTables(self._meta_node_num, self.alphas_dn, self.alphas_up, self.alphas_dn_nm, self.alphas_up_nm,
+                                             self.betas_dn, self.betas_up, self.gamma).args())
         return self.net(x, *self._mixing_weights())
 
     def genotype(self):

@@ -92,6 +92,19 @@ int senas_conv2d_pack_layout(const senas_conv_geom* g, int direction, int32_t* d
                              int64_t* elems);
 /* One launch repacks n weight tensors; items_dev is a DEVICE array, max_elems = max over items.   */
 int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elems, void* stream);
+/* ---- two convolutions in one launch ---------------------------------------------------------------------------------------
+ * dil_3_conv_5 and dil_2_conv_5 of the same edges (utils/operations.py:69-72) read the same tensor with the same shapes and
+ * differ in the dilation only: forward and data gradient of both share a launch (grid.z doubled) on the 8-channel MFMA kernel
+ * (inner edges) and the LDS-window kernels (stacked 32 -> 32 candidates, stride 1 and 2).  Arguments as the single calls, once
+ * per problem.  Returns SENAS_EUNSUPPORTED without launching when the two do not take the same kernel of those families (the
+ * caller then makes the two single calls).                                                                               */
+int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                          float* ya, float* yb, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
+                          const float* packed_a, const float* packed_b, void* stream);
+int senas_conv2d_bwd_data_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* dya, const float* dyb,
+                               const float* wa, const float* wb, float* dxa, float* dxb, int in_relu, const float* x,
+                               void* ws_a, void* ws_b, const float* packed_a, const float* packed_b, void* stream);
+
 /* ---- the same convolutions on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -------------------------
  * Stride-1 "same" nn.Conv2d 3x3 / 5x5 with c_in a multiple of 16 (32 for terms == 1) and c_out a multiple of 32 on maps at
  * least 32 wide and 8 high -- the dense candidates and pre/post-process convolutions of the derived cell

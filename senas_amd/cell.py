@@ -92,6 +92,7 @@ class Cell(nn.Module):
     stacked = True      # run same-named candidates of the edges LEAVING one state as one convolution (class-wide switch)
     fused_tail = True   # DepSepConv candidates: batch-norm + ReLU + 1x1 convolution as one pass (functional.dstail)
     pair_tails = True   # ... and the tails of BOTH input states' candidates as one launch (Cell.forward)
+    pair_dilated = True  # dil_3_conv_5 + dil_2_conv_5 of the same edges: one forward and one data-gradient launch
 
     def _out_edges(self, j):
         """Flat indices of the edges that read state j (one per later node)."""
@@ -200,6 +201,21 @@ class Cell(nn.Module):
         k = len(edges)
         nops = len(self._ops[edges[0]]._ops)
         depsep = []
+        dil5 = {}                                            # position -> modules of a 5x5 dilated ConvBn candidate (Conv2d form)
+
+        def conv_job(mods, p):
+            """The (stacked) convolution of one ConvBn / ConvBnSe candidate over the k edges."""
+            def job(xs, mods=mods, p=p):
+                convs = [m[0] for m in mods]
+                se = isinstance(mods[0], ConvBnSe)
+                want = mods[0][1].training or se
+                z, st = self._stacked_conv(convs, xs[0], want)
+                sw = self._stack(convs)
+                parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=want, used=len(mods), owner=sw, stats=st)
+                return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
+                        for e, m, (zz, st, slot) in zip(edges, mods, parts)]
+            return job
+
         for p in range(nops):
             mods = [self._ops[e]._ops[p] for e in edges]
             m0 = mods[0]
@@ -207,19 +223,15 @@ class Cell(nn.Module):
                 fixed += [(e, p, m.raw(None)) for e, m in zip(edges, mods)]
                 continue
             stack = self.stacked and 1 < k <= F.MAX_STACK
-            if stack and isinstance(m0, (ConvBn, ConvBnSe)):
+            c0 = m0[0] if isinstance(m0, (ConvBn, ConvBnSe)) else None
+            if (self.stacked and self.pair_dilated and type(m0) is ConvBn and isinstance(c0, nn.Conv2d) and c0.kernel_size == (5, 5) and
+                    m0.drop is None and (stack or k == 1)):
+                if stack:
+                    self._stack([m[0] for m in mods])
+                dil5[p] = mods
+            elif stack and isinstance(m0, (ConvBn, ConvBnSe)):
                 self._stack([m[0] for m in mods])
-
-                def job(xs, mods=mods, p=p):
-                    convs = [m[0] for m in mods]
-                    se = isinstance(mods[0], ConvBnSe)
-                    want = mods[0][1].training or se
-                    z, st = self._stacked_conv(convs, xs[0], want)
-                    sw = self._stack(convs)
-                    parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=want, used=len(mods), owner=sw, stats=st)
-                    return [(e, p, F.Term(zz, m[1], se=m[2] if se else None, stats=st, grad_slot=slot))
-                            for e, m, (zz, st, slot) in zip(edges, mods, parts)]
-                jobs.append((job, 1))
+                jobs.append((conv_job(mods, p), 1))
             elif stack and isinstance(m0, AdapterBlock) and m0.c_in != m0.c_ot:
                 self._stack([m.conv for m in mods])
 
@@ -236,6 +248,37 @@ class Cell(nn.Module):
             else:
                 for e, m in zip(edges, mods):
                     jobs.append((lambda xs, e=e, m=m, p=p: [(e, p, m.raw(xs[0]))], 1))
+        if len(dil5) == 2:
+            # dil_3_conv_5 and dil_2_conv_5 of these edges: same tensor, same shapes, different dilation -- ONE launch forward
+            # and one for the two data gradients (functional.conv2d_pair); two aliases of the state
+            (pa, ma), (pb, mb) = sorted(dil5.items())
+
+            def pair_job(xs, pa=pa, ma=ma, pb=pb, mb=mb):
+                ca, cb = [m[0] for m in ma], [m[0] for m in mb]
+                want = ma[0][1].training
+                if k > 1:
+                    swa, swb = self._stack(ca), self._stack(cb)
+                    wa, wb = swa.tensor(), swb.tensor()
+                else:
+                    wa, wb = ca[0].weight, cb[0].weight
+                (za, sta), (zb, stb) = F.conv2d_pair(xs[0], xs[1], wa, wb, ca[0].stride[0], ca[0].padding[0], ca[0].dilation[0],
+                                                    cb[0].padding[0], cb[0].dilation[0], want_stats=want)
+                out = []
+                for p, mods, z, st, convs in ((pa, ma, za, sta, ca), (pb, mb, zb, stb, cb)):
+                    if k > 1:
+                        sw = self._stack(convs)
+                        parts = F.unstack(z, len(mods) + sw.pad_parts, want_stats=want, used=len(mods), owner=sw, stats=st)
+                        out += [(e, p, F.Term(zz, m[1], stats=st_, grad_slot=slot)) for e, m, (zz, st_, slot) in zip(edges, mods, parts)]
+                    else:
+                        out.append((edges[0], p, F.Term(z, mods[0][1], stats=st)))
+                return out
+            jobs.append((pair_job, 2))
+        else:
+            for p, mods in sorted(dil5.items()):
+                if k > 1:
+                    jobs.append((conv_job(mods, p), 1))
+                else:
+                    jobs.append((lambda xs, e=edges[0], m=mods[0], p=p: [(e, p, m.raw(xs[0]))], 1))
         for i in range(0, len(depsep), F.MAX_BNRELU):
             chunk = depsep[i:i + F.MAX_BNRELU]
             jobs.append(self._depsep_job(chunk))

@@ -210,6 +210,18 @@ struct WgradGeom {
     int n, hg, wg, B, hi, wi, A, kh, kw, stride, pad, dil, chunk;
 };
 
+// A second problem riding in the same launch (search cell: dil_3_conv_5 and dil_2_conv_5 of the same edges, utils/operations.py:
+// 69-72, differ in nothing but the dilation): grid.z is doubled, blocks with blockIdx.z >= nz work on problem 2.
+struct Pair2 {
+    const float* in;
+    const float* w;           // packed image (conv_lds) / torch weights (conv_c8)
+    float* out;
+    const float* mask;
+    double* stats;
+    int dil, pad;
+    int nz;                   // grid.z of ONE problem; 0: no second problem
+};
+
 // conv_mfma.hip
 bool mfma_gather_ok(const GatherGeom& g, bool tg);
 template <bool TG>
@@ -245,10 +257,10 @@ int launch_lds_gather_epi(const GatherGeom& g, const float* in, const float* wp,
 void lds_gather_name(const GatherGeom& g, bool tg, char* buf, int len);
 bool lds_gather_s2_ok(const GatherGeom& g);       // stride-2 plain gather (Conv2d forward, ConvTranspose2d data gradient)
 int launch_lds_gather_s2(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,
-                         double* stats, hipStream_t st);
+                         double* stats, hipStream_t st, const Pair2& pr = Pair2{});
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
-                      const float* mask, double* stats, hipStream_t st);
+                      const float* mask, double* stats, hipStream_t st, const Pair2& pr = Pair2{});
 
 // conv_bf.hip (the same convolutions on the bf16 matrix pipe: operands split into 1, 2 or 3 bf16 planes, fp32 accumulation;
 // terms = 1 plain bf16, 3 "bf16x3", 6 "bf16x6")
@@ -287,7 +299,7 @@ int launch_t2_lds(const GatherGeom& g, const float* in, const float* wp, float* 
 bool c8_mfma_ok(const GatherGeom& g);
 int c8_mfma_tiles_per_wave(const GatherGeom& g);
 int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, double* stats,
-                   hipStream_t st);
+                   hipStream_t st, const Pair2& pr = Pair2{});
 bool c8_mfma_wgrad_ok(const WgradGeom& g);
 int64_t c8_mfma_wgrad_ws_bytes(const WgradGeom& g);
 int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st);

@@ -988,6 +988,63 @@ extern "C" int senas_conv2d_bwd_data(const senas_conv_geom* g, const float* dy, 
     return launch_direct<false>(gg, dy, wp, dx, 0, mask, nullptr, st);
 }
 
+// ---- two convolutions of one launch: same tensor shapes, kernel size and stride, different dilation (the dil_3_conv_5 and
+// dil_2_conv_5 candidates of the same edges, utils/operations.py:69-72).  SENAS_EUNSUPPORTED (nothing launched) unless both
+// take the same kernel of the conv_c8 / conv_lds family; the caller then makes the two single calls.
+static bool pair_geoms_ok(const senas_conv_geom* a, const senas_conv_geom* b) {
+    return geom_ok(a) && geom_ok(b) && a->n == b->n && a->hi == b->hi && a->wi == b->wi && a->ci == b->ci && a->ho == b->ho && a->wo == b->wo &&
+           a->co == b->co && a->kh == b->kh && a->kw == b->kw && a->stride == b->stride && !a->transposed && !b->transposed &&
+           a->groups == 1 && b->groups == 1;
+}
+
+extern "C" int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                                     float* ya, float* yb, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
+                                     const float* packed_a, const float* packed_b, void* stream) {
+    if (!ga || !gb || !pair_geoms_ok(ga, gb)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && wa && wb && ya && yb, "conv2d_fwd_pair: null pointer");
+    hipStream_t st = as_stream(stream);
+    const GatherGeom g1{ga->n, ga->hi, ga->wi, ga->ci, ga->ho, ga->wo, ga->co, ga->kh, ga->kw, ga->stride, ga->pad, ga->dil};
+    const GatherGeom g2{gb->n, gb->hi, gb->wi, gb->ci, gb->ho, gb->wo, gb->co, gb->kh, gb->kw, gb->stride, gb->pad, gb->dil};
+    if (stem_mfma_ok(g1) || stem_mfma_ok(g2)) return SENAS_EUNSUPPORTED;
+    const bool c8a = !in_relu && c8_mfma_ok(g1), c8b = !in_relu && c8_mfma_ok(g2);
+    if (c8a != c8b) return SENAS_EUNSUPPORTED;
+    if (c8a) return launch_c8_mfma(g1, x, wa, ga->ci, 1, 0, ya, stats_a, st, Pair2{x, wb, yb, nullptr, stats_b, g2.dil, g2.pad, 1});
+    if (thin_k_ok(g1) || thin_k_ok(g2)) return SENAS_EUNSUPPORTED;
+    const bool lds = lds_gather_ok(g1) && lds_gather_ok(g2), s2 = lds_gather_s2_ok(g1) && lds_gather_s2_ok(g2);
+    if (!lds && !s2) return SENAS_EUNSUPPORTED;
+    if (thin_n_ok(g1) && (g1.cout <= 4 || !lds_gather_ok(g1))) return SENAS_EUNSUPPORTED;
+    const int taps = ga->kh * ga->kw;
+    const float* ia = packed_a;
+    const float* ib = packed_b;
+    if (ia == nullptr) { SENAS_REQUIRE(ws_a, "conv2d_fwd_pair: null workspace"); launch_pack_mfma(wa, reinterpret_cast<float*>(ws_a), ga->co, ga->ci, taps, 1, st); ia = reinterpret_cast<float*>(ws_a); }
+    if (ib == nullptr) { SENAS_REQUIRE(ws_b, "conv2d_fwd_pair: null workspace"); launch_pack_mfma(wb, reinterpret_cast<float*>(ws_b), gb->co, gb->ci, taps, 1, st); ib = reinterpret_cast<float*>(ws_b); }
+    const Pair2 pr{x, ib, yb, nullptr, stats_b, g2.dil, g2.pad, 1};
+    if (lds) return launch_lds_gather<false>(g1, x, ia, ya, in_relu, nullptr, stats_a, st, pr);
+    return launch_lds_gather_s2(g1, x, ia, ya, in_relu, nullptr, stats_a, st, pr);
+}
+
+extern "C" int senas_conv2d_bwd_data_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* dya, const float* dyb,
+                                          const float* wa, const float* wb, float* dxa, float* dxb, int in_relu, const float* x,
+                                          void* ws_a, void* ws_b, const float* packed_a, const float* packed_b, void* stream) {
+    if (!ga || !gb || !pair_geoms_ok(ga, gb)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(dya && dyb && wa && wb && dxa && dxb && (!in_relu || x), "conv2d_bwd_data_pair: null pointer");
+    hipStream_t st = as_stream(stream);
+    const float* mask = in_relu ? x : nullptr;
+    const GatherGeom g1{ga->n, ga->ho, ga->wo, ga->co, ga->hi, ga->wi, ga->ci, ga->kh, ga->kw, ga->stride, ga->pad, ga->dil};
+    const GatherGeom g2{gb->n, gb->ho, gb->wo, gb->co, gb->hi, gb->wi, gb->ci, gb->kh, gb->kw, gb->stride, gb->pad, gb->dil};
+    const bool c8a = mask == nullptr && c8_mfma_ok(g1), c8b = mask == nullptr && c8_mfma_ok(g2);
+    if (c8a != c8b) return SENAS_EUNSUPPORTED;
+    if (c8a) return launch_c8_mfma(g1, dya, wa, ga->ci, 0, 1, dxa, nullptr, st, Pair2{dyb, wb, dxb, nullptr, nullptr, g2.dil, g2.pad, 1});
+    if (thin_k_ok(g1) || thin_k_ok(g2)) return SENAS_EUNSUPPORTED;
+    if (!(lds_gather_ok(g1) && lds_gather_ok(g2))) return SENAS_EUNSUPPORTED;      // (stride 2: the transposed gather of conv_t2 has no pair form)
+    const int taps = ga->kh * ga->kw;
+    const float* ia = packed_a;
+    const float* ib = packed_b;
+    if (ia == nullptr) { SENAS_REQUIRE(ws_a, "conv2d_bwd_data_pair: null workspace"); launch_pack_mfma(wa, reinterpret_cast<float*>(ws_a), ga->co, ga->ci, taps, 0, st); ia = reinterpret_cast<float*>(ws_a); }
+    if (ib == nullptr) { SENAS_REQUIRE(ws_b, "conv2d_bwd_data_pair: null workspace"); launch_pack_mfma(wb, reinterpret_cast<float*>(ws_b), gb->co, gb->ci, taps, 0, st); ib = reinterpret_cast<float*>(ws_b); }
+    return launch_lds_gather<true>(g1, dya, ia, dxa, 0, mask, nullptr, st, Pair2{dyb, ib, dxb, mask, nullptr, g2.dil, g2.pad, 1});
+}
+
 // ---- split-operand / bf16 forms of the stride-1 "same" dense convolution (conv_bf.hip)
 static inline bool lp_terms_ok(int terms) { return terms == 1 || terms == 3 || terms == 6; }
 

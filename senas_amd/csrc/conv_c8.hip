@@ -33,13 +33,19 @@ constexpr int TH = 8, TW = 32;
 template <int CIN, int NT>
 __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                            int d1, int swap, int flip, float* __restrict__ out,
-                                                           double* __restrict__ stats) {
+                                                           double* __restrict__ stats, Pair2 pr) {
     constexpr int PS = CIN + 4, CG = CIN / 4, KS = 5, TAPS = 25, NA = TAPS * CG;
     constexpr int TH = 2 * NT, RW = NT / 2;                         // tile rows, rows per wave   (shadows the 8-row default)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lp = lane & 15, lk = lane >> 4;                      // pixel within a tile / k within a K-step (= channel quad of D)
-    const int n = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    int n = blockIdx.z;
+    if (pr.nz != 0 && n >= pr.nz) {                                // the launch's second problem (block-uniform)
+        n -= pr.nz;
+        in = pr.in; w = pr.w; out = pr.out; stats = pr.stats;
+        g.dil = pr.dil; g.pad = pr.pad;
+    }
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int halo = g.pad, WW = TW + 2 * halo, WH = TH + 2 * halo;
     const int cout = g.cout;
 
@@ -152,20 +158,26 @@ int c8_mfma_tiles_per_wave(const GatherGeom& g) {
 
 // w: torch layout viewed as [tap][a = input channel][b = output channel] through (d1, swap) as in conv_thin.hip
 int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, double* stats,
-                   hipStream_t st) {
+                   hipStream_t st, const Pair2& pr0) {
     // fewer than one 8 x 32 tile per CU: 4 x 32 tiles (the launch is as long as one wave's serial chain of 25 x c_in / 4 MFMAs
     // per 16-pixel tile -- half the tiles per wave, half the chain)
-    const int th = 2 * c8_mfma_tiles_per_wave(g);
-    dim3 grid((g.wout + TW - 1) / TW, (g.hout + th - 1) / th, g.n);
+    GatherGeom gmax = g;                                           // the wider halo of the two problems sizes the window
+    Pair2 pr = pr0;
+    if (pr.nz != 0) { pr.nz = g.n; if (pr.pad > gmax.pad) gmax.pad = pr.pad; }
+    const long both = pr.nz != 0 ? 2 : 1;
+    GatherGeom gt = g;
+    gt.n = (int)(g.n * both);                                      // (tile choice by the blocks of the whole launch)
+    const int th = 2 * c8_mfma_tiles_per_wave(gt);
+    dim3 grid((g.wout + TW - 1) / TW, (g.hout + th - 1) / th, (unsigned)(g.n * both));
     if (g.cin == 8) {
-        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 2>), grid, dim3(256), c8_lds_bytes<8>(g, 4), st, g, in, w, d1, swap, flip, out, stats);
-        else hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 4>), grid, dim3(256), c8_lds_bytes<8>(g), st, g, in, w, d1, swap, flip, out, stats);
+        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 2>), grid, dim3(256), c8_lds_bytes<8>(gmax, 4), st, g, in, w, d1, swap, flip, out, stats, pr);
+        else hipLaunchKernelGGL((conv_c8_mfma_kernel<8, 4>), grid, dim3(256), c8_lds_bytes<8>(gmax), st, g, in, w, d1, swap, flip, out, stats, pr);
     } else {
-        const size_t bytes = c8_lds_bytes<16>(g, th);
+        const size_t bytes = c8_lds_bytes<16>(gmax, th);
         const void* fn = th == 4 ? reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 2>) : reinterpret_cast<const void*>(&conv_c8_mfma_kernel<16, 4>);
         if (int rc = raise_lds_limit(fn, 96 * 1024, "conv_c8_mfma: raising the dynamic LDS limit")) return rc;
-        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
-        else hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats);
+        if (th == 4) hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 2>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats, pr);
+        else hipLaunchKernelGGL((conv_c8_mfma_kernel<16, 4>), grid, dim3(256), bytes, st, g, in, w, d1, swap, flip, out, stats, pr);
     }
     return launch_status("conv_c8_mfma");
 }

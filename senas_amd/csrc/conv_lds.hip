@@ -66,7 +66,7 @@ template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1,
 __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ wp, float* __restrict__ out,
                                                        int in_relu, const float* __restrict__ mask,
-                                                       double* __restrict__ stats, Epi epi) {
+                                                       double* __restrict__ stats, Epi epi, Pair2 second) {
     constexpr int RPM = 32 / TWL;                        // image rows per MFMA row
     constexpr int TH = RW * MT * RPM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
         bx = lp % gx;
         by = (lp / gx) % gy;
         bz = lp / (gx * gy);
+    }
+    if (second.nz != 0 && bz >= (unsigned)second.nz) {   // the launch's second problem (block-uniform)
+        bz -= second.nz;
+        in = second.in; wp = second.w; out = second.out; mask = second.mask; stats = second.stats;
+        g.dil = second.dil; g.pad = second.pad;
     }
     const int n = bz % g.n, cot = bz / g.n;
     const int co = cot * 32 + r;
@@ -437,15 +442,19 @@ static size_t conv_lds_bytes(const GatherGeom& g, int th, int twl, int mt, int k
 
 template <bool TG, int MT, int KS, int MAXT, int PF, int RW, int TWL, int S = 1, bool EPI = false>
 static int launch_lds_variant(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
-                              const float* mask, double* stats, hipStream_t st, const Epi& epi = Epi{}) {
+                              const float* mask, double* stats, hipStream_t st, const Epi& epi = Epi{}, const Pair2& pr0 = Pair2{}) {
     constexpr int TH = RW * MT * (32 / TWL);
-    const size_t bytes = conv_lds_bytes(g, TH, TWL, MT, KS, RW, S);
+    GatherGeom gmax = g;                                 // the wider halo of the two problems sizes the window
+    Pair2 pr = pr0;
+    const int nz1 = g.n * ((g.cout + 31) / 32);
+    if (pr.nz != 0) { pr.nz = nz1; if (pr.pad > gmax.pad) gmax.pad = pr.pad; }
+    const size_t bytes = conv_lds_bytes(gmax, TH, TWL, MT, KS, RW, S);
     if (bytes > 64 * 1024)
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>), 150 * 1024,
                                      "conv_lds: raising the dynamic LDS limit")) return rc;
-    dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, g.n * ((g.cout + 31) / 32));
+    dim3 grid((g.wout + TWL - 1) / TWL, (g.hout + TH - 1) / TH, pr.nz != 0 ? 2 * nz1 : nz1);
     hipLaunchKernelGGL((conv_lds_kernel<TG, MT, KS, MAXT, PF, RW, TWL, S, EPI>), grid, dim3(64 * RW * KS), bytes, st, g, in, wp, out, in_relu,
-                       mask, stats, epi);
+                       mask, stats, epi, pr);
     return launch_status("conv_lds");
 }
 
@@ -489,11 +498,13 @@ void lds_gather_shape(const GatherGeom& g, int& mt, int& ks, int& rw, int& twl) 
 
 template <bool TG>
 int launch_lds_gather(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu,
-                      const float* mask, double* stats, hipStream_t st) {
+                      const float* mask, double* stats, hipStream_t st, const Pair2& pr) {
     int mt, ks, rw, twl;
-    lds_gather_shape(g, mt, ks, rw, twl);
+    GatherGeom gs = g;
+    if (pr.nz != 0) gs.n *= 2;                           // (tile choice by the blocks of the whole launch)
+    lds_gather_shape(gs, mt, ks, rw, twl);
     const int taps = g.kh * g.kw;
-#define SENAS_LV(MT_, KS_, MAXT_, RW_, TWL_) return launch_lds_variant<TG, MT_, KS_, MAXT_, 0, RW_, TWL_>(g, in, wp, out, in_relu, mask, stats, st)
+#define SENAS_LV(MT_, KS_, MAXT_, RW_, TWL_) return launch_lds_variant<TG, MT_, KS_, MAXT_, 0, RW_, TWL_>(g, in, wp, out, in_relu, mask, stats, st, Epi{}, pr)
     SENAS_LDS_DISPATCH(SENAS_LV)
 #undef SENAS_LV
 }
@@ -530,17 +541,17 @@ bool lds_gather_s2_ok(const GatherGeom& g) {
 }
 
 int launch_lds_gather_s2(const GatherGeom& g, const float* in, const float* wp, float* out, int in_relu, const float* mask,
-                         double* stats, hipStream_t st) {
+                         double* stats, hipStream_t st, const Pair2& pr) {
     const int taps = g.kh * g.kw;
     if (g.wout >= 16) {
-        if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st);
-        return launch_lds_variant<false, 1, 4, 7, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st);
+        if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st, Epi{}, pr);
+        return launch_lds_variant<false, 1, 4, 7, 0, 1, 16, 2>(g, in, wp, out, in_relu, mask, stats, st, Epi{}, pr);
     }
-    if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st);
-    return launch_lds_variant<false, 1, 4, 7, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st);
+    if (taps <= 9) return launch_lds_variant<false, 1, 4, 3, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st, Epi{}, pr);
+    return launch_lds_variant<false, 1, 4, 7, 0, 1, 8, 2>(g, in, wp, out, in_relu, mask, stats, st, Epi{}, pr);
 }
 
-template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);
-template int launch_lds_gather<true>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t);
+template int launch_lds_gather<false>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t, const Pair2&);
+template int launch_lds_gather<true>(const GatherGeom&, const float*, const float*, float*, int, const float*, double*, hipStream_t, const Pair2&);
 
 }  // namespace senas

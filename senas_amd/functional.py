@@ -246,6 +246,42 @@ def conv_out_size(i, k, stride, pad, dil, transposed, out_pad):
     return (i + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+def _conv_wgrad(g, x, in_relu, dy, w):
+    """d loss / d w of one convolution call (two-stage kernels leave their sum to flush_deferred when they may): what autograd
+    is handed for w -- None when the kernel wrote into the parameter's view of the flat gradient buffer."""
+    L = _lib.lib()
+    dwt, dw = wgrad_dest(w)
+    nbytes, zero = C.c_int64(), C.c_int32()
+    if MATH_TERMS:                                  # the bf16-pipe form, where the geometry has one
+        _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), MATH_TERMS, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
+    if MATH_TERMS and nbytes.value:
+        wsw = torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
+        with _span('conv_wgrad', g, x, w, dy):
+            item = _lib.SumItem() if may_defer(dw) else None
+            _lib.check(L.senas_conv2d_bwd_weight_lp(C.byref(g), x.data_ptr(), in_relu, dy.data_ptr(), dwt.data_ptr(), wsw.data_ptr(),
+                                                    MATH_TERMS, C.byref(item) if item is not None else None, _stream()),
+                       'senas_conv2d_bwd_weight_lp')
+            if item is not None and item.kind:
+                DEFER.append((item, wsw))
+        return dw
+    _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
+    # pre-zeroed arena slice where the path accumulates with atomics (no memset launch per conv); plain
+    # scratch where it writes per-block partials
+    wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
+    with _span('conv_wgrad', g, x, w, dy):
+        if may_defer(dw):
+            item = _lib.SumItem()
+            _lib.check(L.senas_conv2d_bwd_weight_deferred(C.byref(g), x.data_ptr(), in_relu, dy.data_ptr(), dwt.data_ptr(),
+                                                          wsw.data_ptr(), int(zero.value), C.byref(item), _stream()),
+                       'senas_conv2d_bwd_weight_deferred')
+            if item.kind:
+                DEFER.append((item, wsw))             # the partial images stay alive until the batched sum has run
+        else:
+            _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), in_relu, dy.data_ptr(), dwt.data_ptr(),
+                                                 wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
+    return dw
+
+
 class _Conv2d(torch.autograd.Function):
     """y = conv(relu?(x), w) (+ producer-side batch-norm statistics of y)."""
 
@@ -307,41 +343,99 @@ class _Conv2d(torch.autograd.Function):
                                                  x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream())
                 _lib.check(rc, 'senas_conv2d_bwd_data')
         if ctx.needs_input_grad[1]:
-            dwt, dw = wgrad_dest(w)
-            nbytes, zero = C.c_int64(), C.c_int32()
-            if MATH_TERMS:                                  # the bf16-pipe form, where the geometry has one
-                _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), MATH_TERMS, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
-            if MATH_TERMS and nbytes.value:
-                wsw = torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
-                with _span('conv_wgrad', g, x, w, dy):
-                    item = _lib.SumItem() if may_defer(dw) else None
-                    _lib.check(L.senas_conv2d_bwd_weight_lp(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(), wsw.data_ptr(),
-                                                            MATH_TERMS, C.byref(item) if item is not None else None, _stream()),
-                               'senas_conv2d_bwd_weight_lp')
-                    if item is not None and item.kind:
-                        DEFER.append((item, wsw))
-                return dx, dw, None, None, None, None, None, None, None, None
-            _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
-            # pre-zeroed arena slice where the path accumulates with atomics (no memset launch per conv); plain
-            # scratch where it writes per-block partials
-            wsw = zeros32(nbytes.value // 4 + 1, x.device) if zero.value else torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
-            with _span('conv_wgrad', g, x, w, dy):
-                if may_defer(dw):
-                    item = _lib.SumItem()
-                    _lib.check(L.senas_conv2d_bwd_weight_deferred(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
-                                                                  wsw.data_ptr(), int(zero.value), C.byref(item), _stream()),
-                               'senas_conv2d_bwd_weight_deferred')
-                    if item.kind:
-                        DEFER.append((item, wsw))             # the partial images stay alive until the batched sum has run
-                else:
-                    _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), ctx.in_relu, dy.data_ptr(), dwt.data_ptr(),
-                                                         wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
+            dw = _conv_wgrad(g, x, ctx.in_relu, dy, w)
         return dx, dw, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, stride=1, pad=0, dil=1, transposed=False, out_pad=0, groups=1, in_relu=False, want_stats=False):
     """Returns (y, stats) -- stats is None unless want_stats."""
     return _Conv2d.apply(x, w, stride, pad, dil, transposed, out_pad, groups, in_relu, want_stats)
+
+
+class _Conv2dPair(torch.autograd.Function):
+    """Two "same" Conv2d of ONE tensor that differ in the dilation only -- dil_3_conv_5 and dil_2_conv_5 of the same edges
+    (utils/operations.py:69-72) -- as one forward and one data-gradient launch (senas_conv2d_fwd_pair / _bwd_data_pair; where
+    the pair has no common kernel the entry points decline and the two single launches run).  xa, xb: two aliases of the input
+    (its gradient is then ONE n-ary sum over all readers, functional.fan_out).  Outputs ya, stats_a, yb, stats_b."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats):
+        x = nhwc(xa)
+        wa, wb = _dev(wa).contiguous(), _dev(wb).contiguous()
+        n, ci, hi, wi = x.shape
+        co, k = wa.shape[0], wa.shape[2]
+        if wa.shape != wb.shape or wa.shape[1] != ci or wa.shape[2] != wa.shape[3]:
+            raise SenasHipError('conv2d_pair: weights %s / %s on %d input channels' % (tuple(wa.shape), tuple(wb.shape), ci))
+        ho, wo = conv_out_size(hi, k, stride, pad_a, dil_a, False, 0), conv_out_size(wi, k, stride, pad_a, dil_a, False, 0)
+        if (ho, wo) != (conv_out_size(hi, k, stride, pad_b, dil_b, False, 0), conv_out_size(wi, k, stride, pad_b, dil_b, False, 0)):
+            raise SenasHipError('conv2d_pair: the two convolutions disagree in their output size')
+        ga = ConvGeom(n, hi, wi, ci, ho, wo, co, k, k, stride, pad_a, dil_a, 0, 1)
+        gb = ConvGeom(n, hi, wi, ci, ho, wo, co, k, k, stride, pad_b, dil_b, 0, 1)
+        L = _lib.lib()
+        ya, yb = new_nhwc(n, co, ho, wo, x), new_nhwc(n, co, ho, wo, x)
+        sa = new_stats(n, co, x) if want_stats else None
+        sb = new_stats(n, co, x) if want_stats else None
+        nb = int(L.senas_conv2d_ws_bytes(C.byref(ga)))
+        wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for _ in range(2))
+        rc = L.senas_conv2d_fwd_pair(C.byref(ga), C.byref(gb), x.data_ptr(), wa.data_ptr(), wb.data_ptr(), ya.data_ptr(), yb.data_ptr(),
+                                     int(in_relu), _p(sa), _p(sb), wsa.data_ptr(), wsb.data_ptr(), _packed(wa, 0), _packed(wb, 0), _stream())
+        if rc == _lib.UNSUPPORTED:
+            for g, w, y, st, ws in ((ga, wa, ya, sa, wsa), (gb, wb, yb, sb, wsb)):
+                _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(st), ws.data_ptr(),
+                                              _packed(w, 0), _stream()), 'senas_conv2d_fwd')
+        else:
+            _lib.check(rc, 'senas_conv2d_fwd_pair')
+        ctx.save_for_backward(x, wa, wb)
+        ctx.geoms, ctx.in_relu = (ga, gb), int(in_relu)
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(sa, sb)
+        return ya, sa, yb, sb
+
+    @staticmethod
+    def backward(ctx, dya, _sa, dyb, _sb):
+        x, wa, wb = ctx.saved_tensors
+        (ga, gb), L = ctx.geoms, _lib.lib()
+        if dya is None and dyb is None:
+            return (None,) * 11
+        dya = nhwc(dya) if dya is not None else None
+        dyb = nhwc(dyb) if dyb is not None else None
+        dxa = dxb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            nb = int(L.senas_conv2d_ws_bytes(C.byref(ga)))
+            rc = _lib.UNSUPPORTED
+            if dya is not None and dyb is not None:
+                dxa, dxb = torch.empty_like(x, memory_format=CL), torch.empty_like(x, memory_format=CL)
+                wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for _ in range(2))
+                rc = L.senas_conv2d_bwd_data_pair(C.byref(ga), C.byref(gb), dya.data_ptr(), dyb.data_ptr(), wa.data_ptr(), wb.data_ptr(),
+                                                  dxa.data_ptr(), dxb.data_ptr(), ctx.in_relu, x.data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
+                                                  _packed(wa, 1), _packed(wb, 1), _stream())
+            if rc == _lib.UNSUPPORTED:
+                outs = []
+                for g, w, dy in ((ga, wa, dya), (gb, wb, dyb)):
+                    if dy is None:
+                        outs.append(None)
+                        continue
+                    dx = torch.empty_like(x, memory_format=CL)
+                    ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
+                    _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu, x.data_ptr(),
+                                                       ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
+                    outs.append(dx)
+                dxa, dxb = outs
+            else:
+                _lib.check(rc, 'senas_conv2d_bwd_data_pair')
+        dwa = _conv_wgrad(ga, x, ctx.in_relu, dya, wa) if (ctx.needs_input_grad[2] and dya is not None) else None
+        dwb = _conv_wgrad(gb, x, ctx.in_relu, dyb, wb) if (ctx.needs_input_grad[3] and dyb is not None) else None
+        return dxa, dxb, dwa, dwb, None, None, None, None, None, None, None
+
+
+def conv2d_pair(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu=False, want_stats=False):
+    """((ya, stats_a), (yb, stats_b)) of two convolutions of one tensor (two aliases of it) that differ in the dilation only."""
+    if MATH_TERMS:                           # the bf16-pipe kernels have no pair form: two calls
+        return (conv2d(xa, wa, stride, pad_a, dil_a, in_relu=in_relu, want_stats=want_stats),
+                conv2d(xb, wb, stride, pad_b, dil_b, in_relu=in_relu, want_stats=want_stats))
+    ya, sa, yb, sb = _Conv2dPair.apply(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats)
+    return (ya, sa), (yb, sb)
 
 
 # ------------------------------------------------------------------------------------------ pooling / resampling

@@ -74,8 +74,15 @@ struct BfArgs {
     double* stats;
     int in_relu;
     int tiles_x, tiles_y, ntiles, cot;      // ntiles = cot * n * tiles_y * tiles_x
-    int probe;                              // tuning probe (SENAS_BF_PROBE): bit 0 no staging, bit 1 no taps, bit 2 no epilogue
+    int probe;                              // tuning build only (make probe, -DSENAS_BF_PROBE): bit 0 no staging, 1 no taps, 2 no epilogue
 };
+
+// The shipped library compiles the probe tests away: no launch can skip work.
+#ifdef SENAS_BF_PROBE
+#define SENAS_BF_SKIP(a, bit) (((a).probe >> (bit)) & 1)
+#else
+#define SENAS_BF_SKIP(a, bit) false
+#endif
 
 }  // namespace
 
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
                 for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(buf + k * (XL * P16 * 16) + p * 32) = pl[p];
             }
         };
-        if (a.probe & 1) {
+        if (SENAS_BF_SKIP(a, 0)) {
             for (int j = 0; j < items; ++j) __syncthreads();
             return;
         }
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
 #pragma unroll
                 for (int f = 0; f < U2; ++f) aq[0][m][f] = lds4[lbase + m * lrow + toff + f * 2];
         }
-        if (!(a.probe & 2))
+        if (!SENAS_BF_SKIP(a, 1))
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             // weight fragments AHEAD taps ahead (the ring holds taps t .. t + AHEAD), LDS fragments one tap ahead; the
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
 #pragma unroll
                 for (int f = 0; f < U2; ++f) bq[i][f] = nx[i][f];
         }
-        if (pass == npass - 1 && !(a.probe & 4)) {
+        if (pass == npass - 1 && !SENAS_BF_SKIP(a, 2)) {
             // ---- epilogue: lane = output channel co, register v = pixel (row MT*wave + m, column acc_row(v, h))
             if (a.stats != nullptr && (n != stat_n || cot != stat_cot)) {
                 flush_stats();
@@ -407,8 +414,7 @@ bool bf_gather_ok(const GatherGeom& g, int terms) {
 static int bf_mt(const GatherGeom& g, int terms) {
     if (terms == 6) return 1;
     const long tiles8 = (long)((g.wout + 31) / 32) * ((g.hout + 7) / 8) * g.n * (g.cout / 32);
-    static const int thr = getenv("SENAS_BF_MT2_TILES") ? atoi(getenv("SENAS_BF_MT2_TILES")) : 512;       // (tuning override; measured: 8-row tiles from 2 tiles per CU on)
-    return tiles8 >= thr ? 2 : 1;
+    return tiles8 >= 512 ? 2 : 1;            // (measured: 8-row tiles from two tiles per CU on, tools/bf_probe2.py)
 }
 
 template <bool TG, int MT, int NS, int KSZ>
@@ -421,8 +427,12 @@ static int launch_bf(const GatherGeom& g, const float* in, const void* wimg, flo
     a.tiles_y = (g.hout + TH - 1) / TH;
     a.cot = g.cout / 32;
     a.ntiles = a.cot * g.n * a.tiles_y * a.tiles_x;
+#ifdef SENAS_BF_PROBE
     static const int probe = getenv("SENAS_BF_PROBE") ? atoi(getenv("SENAS_BF_PROBE")) : 0;
     a.probe = probe;
+#else
+    a.probe = 0;
+#endif
     constexpr int XL = NS == 1 ? 32 : 64;
     const size_t wbytes = (size_t)bf_pieces(MT, NS, KSZ) * XL * P16 * 16;
     const size_t bytes = 2 * wbytes;

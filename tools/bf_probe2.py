@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""conv_bf forward time on the derived net's layer shapes per math mode, for two settings of the 8-row-tile threshold."""
+"""Forward / backward kernel time (HIP-graph timed) of the dense convolutions on the derived net's layer shapes, per math mode."""
 import os
 import subprocess
 import sys
@@ -29,6 +29,4 @@ for (n, ci, co, hw, k, dil) in ((8, 32, 32, 256, 5, 3), (8, 32, 32, 128, 5, 2), 
     print('thr %%s  n%%d %%d->%%d %%d^2 k%%d d%%d fwd/bwd us: %%s' %% (sys.argv[1], n, ci, co, hw, k, dil, '  '.join(row)), flush=True)
 ''' % (ROOT, ROOT)
 
-for thr in (1024, 512, 256):
-    env = dict(os.environ, SENAS_BF_MT2_TILES=str(thr))
-    subprocess.run([sys.executable, '-c', CHILD, str(thr)], env=env, check=False)
+subprocess.run([sys.executable, '-c', CHILD, '-'], check=False)

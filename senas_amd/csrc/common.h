@@ -283,6 +283,10 @@ void bf_wgrad_name(const WgradGeom& g, int terms, char* buf, int len);
 // conv_stem.hip (stem forward: 1..4 input channels, (tap, channel) on the K axis of the fp32 MFMA)
 bool stem_mfma_ok(const GatherGeom& g);
 int launch_stem_mfma(const GatherGeom& g, const float* in, const float* w, float* out, int in_relu, double* stats, hipStream_t st);
+// ... and its weight gradient (x window + dy tile in LDS, per-block partial rows in the torch layout)
+bool stem_wgrad_ok(const WgradGeom& g);
+int64_t stem_wgrad_ws_bytes(const WgradGeom& g);
+int launch_stem_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, int* nblk_out, hipStream_t st);
 
 // conv_thin.hip (one side of the GEMM view has <= 4 channels: HBM-bound single-pass kernels; weights in torch layout)
 bool thin_k_ok(const GatherGeom& g);

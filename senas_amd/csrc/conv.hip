@@ -799,6 +799,7 @@ extern "C" int senas_conv2d_bwd_weight_ws(const senas_conv_geom* g, int64_t* byt
     if (g->groups != 1) return SENAS_OK;                           // per-block partials, overwritten
     WgradGeom wg = !g->transposed ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
                                   : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (!g->transposed && stem_wgrad_ok(wg)) { *bytes = stem_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (thin_n_wgrad_ok(wg)) { *bytes = thin_n_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (!g->transposed && c8_mfma_wgrad_ok(wg)) { *bytes = c8_mfma_wgrad_ws_bytes(wg) + 256; return SENAS_OK; }
     if (wgrad_c8_ok(wg)) { *bytes = wgrad_c8_ws_bytes(wg) + 256; return SENAS_OK; }
@@ -1275,6 +1276,14 @@ extern "C" int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const 
         else hipLaunchKernelGGL((dwconv_wgrad_kernel<5>), grid, dim3(256), 0, st, wg, I, G, dw, i_relu, g_relu);
         return launch_status("dwconv_wgrad");
     }
+    if (!g->transposed && !g_relu && stem_wgrad_ok(wg)) {         // the stem: 1..4 input channels, x window + dy tile in LDS
+        SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
+        int nblk = 0;
+        const int rc = launch_stem_wgrad(wg, I, G, reinterpret_cast<float*>(ws), i_relu, &nblk, st);
+        if (rc != SENAS_OK) return rc;
+        flat_sum(reinterpret_cast<const float*>(ws), dw, g->ci * g->co * taps, nblk, defer, st);
+        return launch_status("wgrad_stem sum");
+    }
     if (thin_n_wgrad_ok(wg)) {
         SENAS_REQUIRE(ws, "conv2d_bwd_weight: null workspace");
         int nblk = 0;
@@ -1332,6 +1341,11 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         }
         WgradGeom wg = !tr ? WgradGeom{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0}
                            : WgradGeom{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+        if (!tr && stem_wgrad_ok(wg)) {
+            static const char* names[8] = {"", "wgrad_stem_kernel<1>", "wgrad_stem_kernel<2>", "wgrad_stem_kernel<3>", "wgrad_stem_kernel<4>",
+                                           "wgrad_stem_kernel<5>", "wgrad_stem_kernel<6>", "wgrad_stem_kernel<7>"};
+            return names[(wg.A * wg.kh * wg.kw + 31) / 32];
+        }
         if (thin_n_wgrad_ok(wg)) {
             if (g->kh == 3) return wg.B <= 2 ? "wgrad_thin_n_kernel<3, 2>" : "wgrad_thin_n_kernel<3, 4>";
             return wg.B <= 2 ? "wgrad_thin_n_kernel<1, 2>" : "wgrad_thin_n_kernel<1, 4>";

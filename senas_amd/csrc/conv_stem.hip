@@ -149,3 +149,152 @@ int launch_stem_mfma(const GatherGeom& g, const float* in, const float* w, float
 }
 
 }  // namespace senas
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem convolution: dW[b][a][t] = sum_{n,p} x[n, p + t - pad][a] * dy[n, p][b], a = 1..4 input
+// channels, t = 49 taps, b = 32 output channels.  The direct-global form gathered one float per lane and tap from L1
+// (190 us at 8x1x256x256 for 1.6 GFLOP).  Here: MFMA view M = (channel, tap) pairs in 32-row tiles, N = 32 output
+// channels, K = pixels (2 per v_mfma_f32_32x32x2_f32); a block stages the x window of an 8 x 32 pixel tile in LDS (a few
+// KB) and the dy tile as it is (NHWC: a pixel's 32 channels are one 128-byte row); wave w owns rows 2w, 2w + 1.  Blocks
+// loop over tiles with their accumulators in registers, fold their 4 waves through LDS and leave ONE partial row in the
+// torch layout; the sum over the blocks is the batched second stage (kind 1).
+namespace senas {
+namespace {
+
+template <int MT>       // 32-row tiles of the (channel, tap) axis
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(WgradGeom g, const float* __restrict__ X, const float* __restrict__ G,
+                                                         float* __restrict__ part, int x_relu, int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int A = g.A, taps = g.kh * g.kw, mtot = A * taps;
+    const int halo = g.pad, WW = TWD + 2 * halo, WH = TH + 2 * halo;
+    float* xs = lds;                                  // [WH][WW][A]
+    float* gs = lds + WH * WW * A;                    // [TH * 32 pixels][32]
+    // this lane's (channel, tap) of every M tile: m = a * taps + t (the torch layout of one output channel's weights)
+    int moff[MT];
+    bool mok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 32 + r;
+        mok[t] = m < mtot;
+        const int mc = mok[t] ? m : 0;
+        const int a = mc / taps, tap = mc - a * taps;
+        moff[t] = ((tap / g.kw) * WW + (tap % g.kw)) * A + a;
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int oy0 = ty * TH, ox0 = tx * TWD;
+        __syncthreads();                              // the previous tile's readers are done
+        const float* src = X + (size_t)n * g.hi * g.wi * A;
+        for (int i = threadIdx.x; i < WH * WW * A; i += 256) {
+            const int a = i % A, p = i / A;
+            const int wy = p / WW, wx = p - wy * WW;
+            const int iy = oy0 - halo + wy, ix = ox0 - halo + wx;
+            float v = 0.f;
+            if (iy >= 0 && iy < g.hi && ix >= 0 && ix < g.wi) {
+                v = src[((size_t)iy * g.wi + ix) * A + a];
+                if (x_relu) v = fmaxf(v, 0.f);
+            }
+            xs[i] = v;
+        }
+        const float* gsrc = G + (size_t)n * g.hg * g.wg * 32;
+        for (int i = threadIdx.x; i < TH * 32 * 8; i += 256) {      // 16-byte pieces of the dy tile
+            const int q = i & 7, p = i >> 3;
+            const int gy = oy0 + (p >> 5), gx = ox0 + (p & 31);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < g.hg && gx < g.wg) v = *reinterpret_cast<const float4*>(gsrc + ((size_t)gy * g.wg + gx) * 32 + 4 * q);
+            *reinterpret_cast<float4*>(gs + (size_t)p * 32 + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            const float* xrow = xs + (size_t)row * WW * A;
+            const float* grow = gs + (size_t)row * 32 * 32 + r;
+            for (int k = 0; k < 32; k += 2) {            // K-step: pixels k + h of the row
+                const float b = grow[(k + h) * 32];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float a = mok[t] ? xrow[(k + h) * A + moff[t]] : 0.f;
+                    acc[t] = mfma32(a, b, acc[t]);
+                }
+            }
+        }
+    }
+    // ---- fold the 4 waves through LDS, then this block's partial row in the torch layout: e = (b * A + a) * taps + t = b * mtot + m
+    __syncthreads();
+    float* red = lds;                                  // [wave][MT][16 regs][64 lanes]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[((wave * MT + t) * 16 + v) * 64 + lane] = acc[t][v];
+    __syncthreads();
+    const int n_elem = 32 * mtot;
+    float* dst = part + (size_t)blockIdx.x * n_elem;
+    for (int e = threadIdx.x; e < n_elem; e += 256) {
+        const int b = e / mtot, m = e - b * mtot;
+        const int t = m >> 5, row = m & 31;                        // accumulator register / lane that holds (row, column b)
+        const int hh = (row >> 2) & 1, v = (row & 3) + 4 * (row >> 3), ln = hh * 32 + b;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[((w * MT + t) * 16 + v) * 64 + ln];
+        dst[e] = s;
+    }
+}
+
+}  // namespace
+
+bool stem_wgrad_ok(const WgradGeom& g) {
+    if (!(g.A >= 1 && g.A <= 4 && g.B == 32 && g.stride == 1 && g.dil == 1 && g.kh == g.kw && (g.kh == 7 || g.kh == 5 || g.kh == 3))) return false;
+    if (g.pad != g.kh / 2 || g.hg != g.hi || g.wg != g.wi) return false;
+    return (g.A * g.kh * g.kw + 31) / 32 <= 7 && (long)g.n * g.hi * g.wi * 32 < 0x7fffffffL;
+}
+
+static long stem_wgrad_tiles(const WgradGeom& g, int& tx, int& ty) {
+    tx = (g.wg + TWD - 1) / TWD;
+    ty = (g.hg + TH - 1) / TH;
+    return (long)tx * ty * g.n;
+}
+
+int stem_wgrad_blocks(const WgradGeom& g) {
+    int tx, ty;
+    const long nt = stem_wgrad_tiles(g, tx, ty);
+    return (int)(nt < 512 ? nt : 512);                 // two resident blocks per CU (the window is a few KB)
+}
+
+int64_t stem_wgrad_ws_bytes(const WgradGeom& g) { return (int64_t)stem_wgrad_blocks(g) * 32 * g.A * g.kh * g.kw * sizeof(float); }
+
+int launch_stem_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, int* nblk_out, hipStream_t st) {
+    int tx, ty;
+    const long nt = stem_wgrad_tiles(g, tx, ty);
+    const int nblk = stem_wgrad_blocks(g), mt = (g.A * g.kh * g.kw + 31) / 32;
+    const size_t stage = ((size_t)(TH + 2 * g.pad) * (TWD + 2 * g.pad) * g.A + (size_t)TH * 32 * 32) * sizeof(float);
+    const size_t fold = (size_t)4 * mt * 16 * 64 * sizeof(float);
+    const size_t bytes = stage > fold ? stage : fold;
+#define SENAS_WS(MT_)                                                                                                         \
+    do {                                                                                                                      \
+        if (bytes > 64 * 1024)                                                                                                \
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&wgrad_stem_kernel<MT_>), 128 * 1024, "wgrad_stem: raising the dynamic LDS limit")) return rc; \
+        hipLaunchKernelGGL((wgrad_stem_kernel<MT_>), dim3(nblk), dim3(256), bytes, st, g, X, G, part, x_relu, tx, ty, (int)nt); \
+    } while (0)
+    switch (mt) {
+        case 1: SENAS_WS(1); break;
+        case 2: SENAS_WS(2); break;
+        case 3: SENAS_WS(3); break;
+        case 4: SENAS_WS(4); break;
+        case 5: SENAS_WS(5); break;
+        case 6: SENAS_WS(6); break;
+        default: SENAS_WS(7); break;
+    }
+#undef SENAS_WS
+    *nblk_out = nblk;
+    return launch_status("wgrad_stem");
+}
+
+}  // namespace senas

@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument('--pg-timeout', type=float, default=120.0, help='N > 1: torch.distributed rendezvous / collective timeout, seconds')
     ap.add_argument('--lp-steps', type=int, default=60,
                     help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16; 0 = skip them)')
+    ap.add_argument('--profile-math', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
+                    help='PROFILING ONLY: run the primary (timed, event-probed) train step in this math mode, so that rocprofv3 sees '
+                         'the bf16-pipe kernels in the steady-state window; the JSON line says so and is not a headline')
     ap.add_argument('--cpu-uncapped', action='store_true',
                     help='also time the CPU baseline with torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3, literally)')
     return ap.parse_args(argv)
@@ -425,6 +428,9 @@ def main():
     from senas_amd.parallel import broadcast_parameters
     _lib.lib()
 
+    if args.profile_math != 'f32':
+        F.set_math(args.profile_math)
+        log('PROFILING RUN: primary train step in math mode %s' % args.profile_math)
     net = build_derived(dev)
     if world > 1:
         broadcast_parameters(net)
@@ -503,7 +509,7 @@ def main():
         'metric': 'images/sec at 256x256 - senas derived-genotype train step (fwd+loss+bwd+clip+SGD); supernet search step under search_step',
         'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (randn slices, randint labels, seed 1+rank), random-init weights',
+        'vs_baseline': None, 'dtype': 'f32' if args.profile_math == 'f32' else 'PROFILING RUN in %s (not a headline)' % args.profile_math, 'data': 'synthetic (randn slices, randint labels, seed 1+rank), random-init weights',
         'config': {'workload': 'BASELINE configs[1]: SenasModel README genotype (senas_node_4), c=32 depth=5, '
                                '%dx1x%dx%d per GPU, fp32' % (args.batch, args.size, args.size),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach()),
@@ -514,6 +520,8 @@ def main():
     log('train step: %.2f ms/step, %.2f images/s' % (ms_per_step, value))
     step.close()
     del step, net, opt
+    if args.profile_math != 'f32':
+        F.set_math('f32')
 
     if args.lp_steps > 0:
         for mode in ('bf16x6', 'bf16x3', 'bf16'):
@@ -530,6 +538,20 @@ def main():
         out['search_step'] = bench_search(dev, args.search_steps, rank, world, use_graph=not args.no_graph)
         if rank == 0:
             log('search step: %s' % json.dumps(out['search_step']))
+        if args.lp_steps > 0:
+            # labelled block: the same search step with the stacked 32 -> 32 candidates on the bf16 pipe (split operands)
+            from senas_amd import functional as F
+            prev = F.set_math('bf16x3')
+            try:
+                blk = bench_search(dev, max(10, args.search_steps // 2), rank, world, use_graph=not args.no_graph)
+            finally:
+                F.set_math(prev)
+            blk['math'] = 'bf16x3'
+            blk['dtype'] = 'f32 split into 2 bf16 planes, 3 MFMA products, f32 accumulate, f32 storage (dense stride-1 convolutions only)'
+            blk['speedup_vs_f32_step'] = round(out['search_step']['ms_per_step'] / blk['ms_per_step'], 3)
+            out['search_step_bf16x3'] = blk
+            if rank == 0:
+                log('search step [bf16x3]: %.2f ms/step' % blk['ms_per_step'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = host_threads()
         torch.set_num_threads(threads)

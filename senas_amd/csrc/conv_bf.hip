@@ -110,7 +110,10 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
     constexpr int TAPS = KSZ * KSZ;
     constexpr int TH = 4 * MT;
     constexpr int PF = bf_pieces(MT, NS, KSZ);      // staging sweeps: the largest window of this instantiation
-    constexpr int RING = NS == 1 ? 8 : (NS == 2 ? 6 : 5);   // weight fragments RING - 1 taps ahead of the MFMAs that use them
+    constexpr int RING_WANT = NS == 1 ? 12 : (NS == 2 ? 10 : 7);
+    constexpr int RING = RING_WANT < KSZ * KSZ ? RING_WANT : KSZ * KSZ;      // (the look-ahead never reaches past the NEXT item)
+    // fragments RING - 1 taps ahead of the MFMAs that use them (the epilogue's stores sit in the same in-order vmcnt queue:
+    // the look-ahead has to outlast them)
     constexpr int AHEAD = RING - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const GatherGeom& g = a.g;

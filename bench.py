@@ -363,7 +363,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of kernel ``name`` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
     separate runs over this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; aggregated by
     tools/pmc_traffic.py).  Returns (bytes or None, source)."""
-    for fname in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+    for fname in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             pmc = json.load(open(path))

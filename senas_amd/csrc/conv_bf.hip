@@ -74,7 +74,7 @@ struct BfArgs {
     double* stats;
     int in_relu;
     int tiles_x, tiles_y, ntiles, cot;      // ntiles = cot * n * tiles_y * tiles_x
-    int probe;                              // tuning build only (make probe, -DSENAS_BF_PROBE): bit 0 no staging, 1 no taps, 2 no epilogue
+    int probe;                              // tuning build only (make probe, -DSENAS_BF_PROBE): bit 0 no staging, 1 no taps, 2 no epilogue, 3 no LDS fragment reads inside the tap loop, 4 no weight-fragment loads
 };
 
 // The shipped library compiles the probe tests away: no launch can skip work.
@@ -314,10 +314,11 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
             {
                 const int tn = t + AHEAD;
                 const uint4* wp = tn < TAPS ? wptr(cot, pass, tn) : wptr(cot2, pass2, tn - TAPS);
+                if (!SENAS_BF_SKIP(a, 4))
 #pragma unroll
                 for (int f = 0; f < U2; ++f) bq[(t + AHEAD) % RING][f] = wp[f * 64];
             }
-            if (t + 1 < TAPS) {
+            if (t + 1 < TAPS && !SENAS_BF_SKIP(a, 3)) {
                 const int toff = tap_off(t + 1);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)

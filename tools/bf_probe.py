@@ -28,6 +28,6 @@ for (n, ci, co, hw, k, dil) in ((8, 32, 32, 256, 5, 3), (8, 128, 32, 256, 3, 1),
     print('probe %%s  n%%d %%d->%%d %%d^2 k%%d d%%d: %%s us' %% (sys.argv[1], n, ci, co, hw, k, dil, '  '.join(row)), flush=True)
 ''' % (ROOT, ROOT, ROOT)
 
-for mask in (0, 1, 2, 4, 3, 5, 6, 7):
+for mask in [int(m) for m in sys.argv[1:]] or (0, 1, 2, 4, 3, 5, 6, 7, 13, 21, 29):
     env = dict(os.environ, SENAS_BF_PROBE=str(mask))
     subprocess.run([sys.executable, '-c', CHILD, str(mask)], env=env, check=False)

@@ -7,7 +7,7 @@ tag=${1:-rX}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
-python3 bench.py --cpu-uncapped > $out/bench.log 2> $out/bench.err
+python3 bench.py > $out/bench.log 2> $out/bench.err
 tail -1 $out/bench.log > $out/bench.json
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --search-steps 0 --lp-steps 0 --no-cpu-baseline"

@@ -21,7 +21,7 @@ def load(path, counter):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue
-            name = r['Kernel_Name'].split('(')[0].replace("void ", "").replace("senas::", "").strip()
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace("void ", "").replace("senas::", "").strip()
             acc[name].append(float(r['Counter_Value']))
     return acc
 

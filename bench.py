@@ -455,10 +455,13 @@ def main():
     # be read back from inside a replayed graph; kernel durations are the same in both modes)
     probe_steps = 2
     step.fb._collectives = False                                # (no collective inside the probe passes)
+    from senas_amd.senas_model import BuildCell
+    BuildCell.paired = False                                    # (every convolution launched on its own: one span, one kernel, one geometry)
     F.TIMER = F.KernelTimer()
     for _ in range(probe_steps):
         step.fb._eager()
     timer, F.TIMER = F.TIMER, None
+    BuildCell.paired = True
     step.fb._collectives = True
     images = args.batch * world * args.steps
     value = images / elapsed

@@ -166,6 +166,15 @@ typedef struct senas_sum_item {
 int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const float* x, int in_relu, const float* dy,
                                      float* dw, void* ws, int ws_is_zero, senas_sum_item* defer, void* stream);
 int senas_wgrad_sum_batched(const senas_sum_item* items, int n, void* stream);
+/* The weight gradients of the two convolutions of senas_conv2d_fwd_pair (one tensor, shapes and kernel size in common, their
+ * own dilation / padding: utils/operations.py:69-72; models/senas_model.py:55-63 where two nodes take candidates of one state)
+ * as ONE first-stage launch (problem 2 on blockIdx.y) on the 8-channel MFMA kernel or the LDS kernel.  ws_a / ws_b: what
+ * senas_conv2d_bwd_weight_ws asks for each; defer_a / defer_b: both NULL (the sums run here) or both given.  dwa / dwb (torch
+ * layout) are OVERWRITTEN.  Returns SENAS_EUNSUPPORTED without launching when the two do not share a kernel and tile list
+ * (the caller then makes the two single calls).                                                                           */
+int senas_conv2d_bwd_weight_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, int in_relu,
+                                 const float* dya, const float* dyb, float* dwa, float* dwb, void* ws_a, void* ws_b,
+                                 senas_sum_item* defer_a, senas_sum_item* defer_b, void* stream);
 
 /* Weight gradient of the same convolutions on the bf16 pipe (both operands split while they are staged in LDS; fragments
  * by transposing LDS reads).  *bytes == 0: the geometry is off the path (use senas_conv2d_bwd_weight).  ws: *bytes of

@@ -141,6 +141,7 @@ SIGNATURES = {
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_fwd_pair': (_I, [_G, _G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'senas_conv2d_bwd_data_pair': (_I, [_G, _G, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    'senas_conv2d_bwd_weight_pair': (_I, [_G, _G, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(SumItem), C.POINTER(SumItem), _P]),
     'senas_conv2d_fwd_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     'senas_conv2d_bwd_data_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     'senas_conv2d_bwd_weight_ws_lp': (_I, [_G, _I, C.POINTER(C.c_int64)]),

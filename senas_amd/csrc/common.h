@@ -222,6 +222,16 @@ struct Pair2 {
     int nz;                   // grid.z of ONE problem; 0: no second problem
 };
 
+// A second weight-gradient problem riding in the same launch (blockIdx.y == 1): the same X, shapes and kernel size; its own
+// upstream gradient, partial images, dilation and padding (the two dilated 5x5 candidates of the same edges; two derived-cell
+// candidates that read one state).
+struct WPair2 {
+    const float* G;
+    float* part;
+    int dil, pad;
+    int on;                   // 0: no second problem
+};
+
 // conv_mfma.hip
 bool mfma_gather_ok(const GatherGeom& g, bool tg);
 template <bool TG>
@@ -237,6 +247,10 @@ bool lds_wgrad_ok(const WgradGeom& g);
 int64_t lds_wgrad_ws_bytes(const WgradGeom& g);
 int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
                      hipStream_t st);
+// two problems (g2: g with the second dilation / padding) in one launch; false: the two do not share a kernel and tile height
+bool lds_wgrad_pair_ok(const WgradGeom& g, const WgradGeom& g2);
+int launch_lds_wgrad_pair(const WgradGeom& g, const WgradGeom& g2, const float* X, const float* G, const float* G2, float* part, float* part2,
+                          float* dw, float* dw2, int x_relu, senas_sum_item* defer, senas_sum_item* defer2, hipStream_t st);
 void lds_wgrad_name(const WgradGeom& g, char* buf, int len);
 void launch_unpack_wgrad(const float* ws, float* dw, int A, int B, int taps, hipStream_t st);
 
@@ -306,7 +320,8 @@ int launch_c8_mfma(const GatherGeom& g, const float* in, const float* w, int d1,
                    hipStream_t st, const Pair2& pr = Pair2{});
 bool c8_mfma_wgrad_ok(const WgradGeom& g);
 int64_t c8_mfma_wgrad_ws_bytes(const WgradGeom& g);
-int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st);
+int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st,
+                         const WPair2& second = WPair2{});
 bool thin_n_ok(const GatherGeom& g);
 template <bool TG>
 int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,

@@ -1325,6 +1325,39 @@ extern "C" int senas_conv2d_bwd_weight_deferred(const senas_conv_geom* g, const 
     return launch_status("conv_wgrad");
 }
 
+// Weight gradients of TWO Conv2d of one tensor that differ in dilation / padding only (senas_conv2d_fwd_pair's backward pass) as
+// ONE first-stage launch: problem 2 on blockIdx.y.  SENAS_EUNSUPPORTED (nothing launched) unless both take the same kernel of
+// the wgrad_c8_mfma / wgrad_lds family with one tile list; the caller then makes the two single calls.  defer_a / defer_b: both
+// NULL (the second stages run here) or both given (senas_wgrad_sum_batched later).
+extern "C" int senas_conv2d_bwd_weight_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, int in_relu, const float* dya,
+                                            const float* dyb, float* dwa, float* dwb, void* ws_a, void* ws_b, senas_sum_item* defer_a,
+                                            senas_sum_item* defer_b, void* stream) {
+    if (defer_a != nullptr) defer_a->kind = 0;
+    if (defer_b != nullptr) defer_b->kind = 0;
+    if (!ga || !gb || !pair_geoms_ok(ga, gb) || (defer_a == nullptr) != (defer_b == nullptr)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(x && dya && dyb && dwa && dwb && ws_a && ws_b, "conv2d_bwd_weight_pair: null pointer");
+    hipStream_t st = as_stream(stream);
+    const WgradGeom w1{ga->n, ga->ho, ga->wo, ga->co, ga->hi, ga->wi, ga->ci, ga->kh, ga->kw, ga->stride, ga->pad, ga->dil, 0};
+    const WgradGeom w2{gb->n, gb->ho, gb->wo, gb->co, gb->hi, gb->wi, gb->ci, gb->kh, gb->kw, gb->stride, gb->pad, gb->dil, 0};
+    // (the single call's dispatch order: stem, thin-N, 8-channel MFMA, 8-channel VALU, LDS)
+    if (stem_wgrad_ok(w1) || stem_wgrad_ok(w2) || thin_n_wgrad_ok(w1) || thin_n_wgrad_ok(w2)) return SENAS_EUNSUPPORTED;
+    const int taps = ga->kh * ga->kw;
+    float* pa = reinterpret_cast<float*>(ws_a);
+    float* pb = reinterpret_cast<float*>(ws_b);
+    const bool c8a = !in_relu && c8_mfma_wgrad_ok(w1), c8b = !in_relu && c8_mfma_wgrad_ok(w2);
+    if (c8a != c8b) return SENAS_EUNSUPPORTED;
+    if (c8a) {
+        int nblk = 0;
+        const int rc = launch_c8_mfma_wgrad(w1, x, dya, pa, &nblk, st, WPair2{dyb, pb, w2.dil, w2.pad, 1});
+        if (rc != SENAS_OK) return rc;
+        flat_sum(pa, dwa, ga->ci * ga->co * taps, nblk, defer_a, st);
+        flat_sum(pb, dwb, gb->ci * gb->co * taps, nblk, defer_b, st);
+        return launch_status("wgrad_c8_mfma pair sum");
+    }
+    if (wgrad_c8_ok(w1) || wgrad_c8_ok(w2) || !lds_wgrad_pair_ok(w1, w2)) return SENAS_EUNSUPPORTED;
+    return launch_lds_wgrad_pair(w1, w2, x, dya, dyb, pa, pb, dwa, dwb, in_relu, defer_a, defer_b, st);
+}
+
 // Which kernel a convolution call dispatches to (same predicates as the launchers above), as the readable
 // symbol rocprofv3 prints -- lets bench.py attribute HIP-event time to the kernel the profile shows.
 // which: 0 forward, 1 data gradient, 2 weight gradient.

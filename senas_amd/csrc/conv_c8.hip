@@ -193,10 +193,13 @@ namespace {
 
 constexpr int PAIRS = 13;
 
-__global__ __launch_bounds__(256) void wgrad_c8_mfma_kernel(WgradGeom g, const float* __restrict__ X, const float* __restrict__ G,
-                                                            float* __restrict__ part, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256) void wgrad_c8_mfma_kernel(WgradGeom g, const float* __restrict__ X, const float* __restrict__ G1,
+                                                            float* __restrict__ part1, int tiles_x, int tiles_y, int ntiles, WPair2 second) {
     constexpr int CIN = 8, PS = CIN + 4, KS = 5;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* __restrict__ G = G1;
+    float* __restrict__ part = part1;
+    if (blockIdx.y != 0) { G = second.G; part = second.part; g.dil = second.dil; g.pad = second.pad; }     // second problem of a pair launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lk = lane >> 4;                      // A: row b = lj, pixel k = lk;  B: pixel k = lk, column lj
     const int halo = g.pad, WW = TW + 2 * halo, WH = TH + 2 * halo;
@@ -285,13 +288,15 @@ int64_t c8_mfma_wgrad_ws_bytes(const WgradGeom& g) {
     return (int64_t)c8_mfma_wgrad_blocks(g) * g.A * g.B * 25 * sizeof(float);
 }
 
-int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st) {
+int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st, const WPair2& second) {
     int tx, ty;
     const long nt = c8_wgrad_tiles(g, tx, ty);
     const int nblk = c8_mfma_wgrad_blocks(g);
-    const size_t window = (size_t)(TH + 2 * g.pad) * (TW + 2 * g.pad) * 12 * sizeof(float);
+    const int pad = second.on && second.pad > g.pad ? second.pad : g.pad;
+    const size_t window = (size_t)(TH + 2 * pad) * (TW + 2 * pad) * 12 * sizeof(float);
     const size_t fold = (size_t)4 * PAIRS * 64 * 4 * sizeof(float);
-    hipLaunchKernelGGL(wgrad_c8_mfma_kernel, dim3((unsigned)nblk), dim3(256), window > fold ? window : fold, st, g, X, G, part, tx, ty, (int)nt);
+    hipLaunchKernelGGL(wgrad_c8_mfma_kernel, dim3((unsigned)nblk, second.on ? 2 : 1), dim3(256), window > fold ? window : fold, st, g, X, G, part, tx, ty,
+                       (int)nt, second);
     *nblk_out = nblk;
     return launch_status("wgrad_c8_mfma");
 }

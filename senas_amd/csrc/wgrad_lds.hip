@@ -52,9 +52,13 @@ __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >
 // ConvTranspose2d stride 2 alike); the tile is laid out over G, the X window covers S times as many rows and columns.
 template <int A, int Q, int REM, int PFX, int TWL, int S>
 __global__ __launch_bounds__(512) void wgrad_lds_kernel(WgradGeom g, const float* __restrict__ X,
-                                                        const float* __restrict__ G, float* __restrict__ part,
-                                                        int x_relu, int th, int tiles_x, int tiles_y) {
+                                                        const float* __restrict__ G1, float* __restrict__ part1,
+                                                        int x_relu, int th, int tiles_x, int tiles_y, WPair2 second) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // blockIdx.y == 1: the second problem of a pair launch (same X and shapes; its own dy, partial images, dilation)
+    const float* __restrict__ G = G1;
+    float* __restrict__ part = part1;
+    if (blockIdx.y != 0) { G = second.G; part = second.part; g.dil = second.dil; g.pad = second.pad; }
     constexpr int UW = Q + REM;
     constexpr int RPM = 32 / TWL;                // image rows per MFMA row
     constexpr int PP = A / 4;                    // 16-byte pieces per pixel of X
@@ -375,23 +379,29 @@ int64_t lds_wgrad_ws_bytes(const WgradGeom& g) {
 }
 
 template <int A, int Q, int REM, int PFX, int TWL, int S>
-static int launch_one(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st) {
+static int launch_one(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st,
+                      const WPair2& second = WPair2{}) {
     const int th = wgrad_lds_tile_rows(g);
     size_t bytes = wgrad_lds_bytes(g, th, TWL);
+    if (second.on) {                                           // (lds_wgrad_pair_ok: both problems take this th)
+        WgradGeom g2 = g;
+        g2.dil = second.dil; g2.pad = second.pad;
+        const size_t b2 = wgrad_lds_bytes(g2, th, TWL);
+        if (b2 > bytes) bytes = b2;
+    }
     const size_t fold = (size_t)4 * REM * 4096;                // epilogue: 4 storing waves x REM accumulators x 4 KiB
     if (fold > bytes) bytes = fold;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), 150 * 1024,
                                  "wgrad_lds: raising the dynamic LDS limit")) return rc;
     const int rows = th * (32 / TWL);
     const int tiles_x = (g.wg + TWL - 1) / TWL, tiles_y = (g.hg + rows - 1) / rows;
-    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), dim3(wgrad_lds_blocks(g)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
-                       tiles_x, tiles_y);
+    hipLaunchKernelGGL((wgrad_lds_kernel<A, Q, REM, PFX, TWL, S>), dim3(wgrad_lds_blocks(g), second.on ? 2 : 1), dim3(512), bytes, st, g, X, G,
+                       part, x_relu, th, tiles_x, tiles_y, second);
     return launch_status("wgrad_lds");
 }
 
-// part: lds_wgrad_ws_bytes(g) of scratch (need not be zeroed); dw: torch layout, overwritten
-int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
-                     hipStream_t st) {
+static int launch_lds_wgrad_any(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                                hipStream_t st, const WPair2& second, float* dw2, senas_sum_item* defer2) {
     const int units = g.kh * g.kw * (g.A / 32);
     const int twl = wgrad_tile_width(g);
     int rc = SENAS_EINVAL;
@@ -401,25 +411,47 @@ int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* 
         found = true;                                                                                             \
         if (g.stride == 2) {                                                                                      \
             if constexpr (A_ == 32) {                                                                             \
-                rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 2>(g, X, G, part, x_relu, st)                  \
-                               : launch_one<A_, Q_, REM_, PF_, 8, 2>(g, X, G, part, x_relu, st);                  \
+                rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 2>(g, X, G, part, x_relu, st, second)                  \
+                               : launch_one<A_, Q_, REM_, PF_, 8, 2>(g, X, G, part, x_relu, st, second);                  \
             }                                                                                                     \
-        } else if (twl == 32) rc = launch_one<A_, Q_, REM_, PF_, 32, 1>(g, X, G, part, x_relu, st);              \
+        } else if (twl == 32) rc = launch_one<A_, Q_, REM_, PF_, 32, 1>(g, X, G, part, x_relu, st, second);              \
         else if constexpr (A_ == 32 || A_ == 128) {                                                               \
-            rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 1>(g, X, G, part, x_relu, st)                      \
-                           : launch_one<A_, Q_, REM_, PF_, 8, 1>(g, X, G, part, x_relu, st);                      \
+            rc = twl == 16 ? launch_one<A_, Q_, REM_, PF_, 16, 1>(g, X, G, part, x_relu, st, second)                      \
+                           : launch_one<A_, Q_, REM_, PF_, 8, 1>(g, X, G, part, x_relu, st, second);                      \
         }                                                                                                         \
     }
     SENAS_WGRAD_LDS_SHAPES(SENAS_CASE)
 #undef SENAS_CASE
     if (!found) { set_error_msg("wgrad_lds: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
     if (rc != SENAS_OK) return rc;
+    const int nblk = wgrad_lds_blocks(g);
     if (defer != nullptr) {              // the caller folds the partial images later, together with other convolutions' (senas_wgrad_sum_batched)
-        *defer = senas_sum_item{part, dw, 2, g.A, g.B, g.kh * g.kw, 0, wgrad_lds_blocks(g)};
+        *defer = senas_sum_item{part, dw, 2, g.A, g.B, g.kh * g.kw, 0, nblk};
+        if (second.on) *defer2 = senas_sum_item{second.part, dw2, 2, g.A, g.B, g.kh * g.kw, 0, nblk};
         return SENAS_OK;
     }
-    hipLaunchKernelGGL(wgrad_lds_sum_kernel, dim3(units * 32), dim3(256), 0, st, part, dw, g.A, g.B, g.kh * g.kw, wgrad_lds_blocks(g));
+    hipLaunchKernelGGL(wgrad_lds_sum_kernel, dim3(units * 32), dim3(256), 0, st, part, dw, g.A, g.B, g.kh * g.kw, nblk);
+    if (second.on) hipLaunchKernelGGL(wgrad_lds_sum_kernel, dim3(units * 32), dim3(256), 0, st, second.part, dw2, g.A, g.B, g.kh * g.kw, nblk);
     return launch_status("wgrad_lds sum");
+}
+
+// part: lds_wgrad_ws_bytes(g) of scratch (need not be zeroed); dw: torch layout, overwritten
+int launch_lds_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                     hipStream_t st) {
+    return launch_lds_wgrad_any(g, X, G, part, dw, x_relu, defer, st, WPair2{}, nullptr, nullptr);
+}
+
+// Two problems that differ in dilation / padding only: the tile list (a function of the map and of what fits in LDS) must be
+// the same for both, so that one grid serves both and each partial image has the block count its workspace was sized for.
+bool lds_wgrad_pair_ok(const WgradGeom& g, const WgradGeom& g2) {
+    return lds_wgrad_ok(g) && lds_wgrad_ok(g2) && g.stride == 1 && g2.stride == 1 && wgrad_lds_tile_rows(g) == wgrad_lds_tile_rows(g2) &&
+           wgrad_lds_blocks(g) == wgrad_lds_blocks(g2);
+}
+
+int launch_lds_wgrad_pair(const WgradGeom& g, const WgradGeom& g2, const float* X, const float* G, const float* G2, float* part, float* part2,
+                          float* dw, float* dw2, int x_relu, senas_sum_item* defer, senas_sum_item* defer2, hipStream_t st) {
+    if ((defer == nullptr) != (defer2 == nullptr)) { set_error_msg("wgrad_lds pair: both sums are deferred or neither"); return SENAS_EINVAL; }
+    return launch_lds_wgrad_any(g, X, G, part, dw, x_relu, defer, st, WPair2{G2, part2, g2.dil, g2.pad, 1}, dw2, defer2);
 }
 
 // the kernel symbol launch_lds_wgrad picks (for senas_conv2d_kernel_name)

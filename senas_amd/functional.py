@@ -246,11 +246,12 @@ def conv_out_size(i, k, stride, pad, dil, transposed, out_pad):
     return (i + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def _conv_wgrad(g, x, in_relu, dy, w):
+def _conv_wgrad(g, x, in_relu, dy, w, dest=None):
     """d loss / d w of one convolution call (two-stage kernels leave their sum to flush_deferred when they may): what autograd
-    is handed for w -- None when the kernel wrote into the parameter's view of the flat gradient buffer."""
+    is handed for w -- None when the kernel wrote into the parameter's view of the flat gradient buffer.  ``dest``: a
+    destination already taken from wgrad_dest (which must be asked once per gradient)."""
     L = _lib.lib()
-    dwt, dw = wgrad_dest(w)
+    dwt, dw = wgrad_dest(w) if dest is None else dest
     nbytes, zero = C.c_int64(), C.c_int32()
     if MATH_TERMS:                                  # the bf16-pipe form, where the geometry has one
         _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), MATH_TERMS, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
@@ -280,6 +281,33 @@ def _conv_wgrad(g, x, in_relu, dy, w):
             _lib.check(L.senas_conv2d_bwd_weight(C.byref(g), x.data_ptr(), in_relu, dy.data_ptr(), dwt.data_ptr(),
                                                  wsw.data_ptr(), int(zero.value), _stream()), 'senas_conv2d_bwd_weight')
     return dw
+
+
+def _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb):
+    """The weight gradients of the two convolutions of a pair as ONE first-stage launch (senas_conv2d_bwd_weight_pair); where
+    the two share no kernel, the two single calls.  Returns what autograd is handed for wa and wb."""
+    L = _lib.lib()
+    da, db = wgrad_dest(wa), wgrad_dest(wb)
+    sizes = []
+    for g in (ga, gb):
+        nbytes, zero = C.c_int64(), C.c_int32()
+        _lib.check(L.senas_conv2d_bwd_weight_ws(C.byref(g), C.byref(nbytes), C.byref(zero)), 'senas_conv2d_bwd_weight_ws')
+        sizes.append((nbytes.value, zero.value))
+    if not MATH_TERMS and not sizes[0][1] and not sizes[1][1]:
+        wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for nb, _ in sizes)
+        defer = may_defer(da[1], db[1])
+        ia, ib = (_lib.SumItem(), _lib.SumItem()) if defer else (None, None)
+        rc = L.senas_conv2d_bwd_weight_pair(C.byref(ga), C.byref(gb), x.data_ptr(), in_relu, dya.data_ptr(), dyb.data_ptr(),
+                                            da[0].data_ptr(), db[0].data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
+                                            C.byref(ia) if defer else None, C.byref(ib) if defer else None, _stream())
+        if rc != _lib.UNSUPPORTED:
+            _lib.check(rc, 'senas_conv2d_bwd_weight_pair')
+            if defer:
+                for item, ws in ((ia, wsa), (ib, wsb)):
+                    if item.kind:
+                        DEFER.append((item, ws))        # the partial images stay alive until the batched sum has run
+            return da[1], db[1]
+    return _conv_wgrad(ga, x, in_relu, dya, wa, dest=da), _conv_wgrad(gb, x, in_relu, dyb, wb, dest=db)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -424,14 +452,28 @@ class _Conv2dPair(torch.autograd.Function):
                 dxa, dxb = outs
             else:
                 _lib.check(rc, 'senas_conv2d_bwd_data_pair')
-        dwa = _conv_wgrad(ga, x, ctx.in_relu, dya, wa) if (ctx.needs_input_grad[2] and dya is not None) else None
-        dwb = _conv_wgrad(gb, x, ctx.in_relu, dyb, wb) if (ctx.needs_input_grad[3] and dyb is not None) else None
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and dya is not None and dyb is not None and wa.data_ptr() != wb.data_ptr():
+            dwa, dwb = _conv_wgrad_pair(ga, gb, x, ctx.in_relu, dya, dyb, wa, wb)
+        else:
+            dwa = _conv_wgrad(ga, x, ctx.in_relu, dya, wa) if (ctx.needs_input_grad[2] and dya is not None) else None
+            dwb = _conv_wgrad(gb, x, ctx.in_relu, dyb, wb) if (ctx.needs_input_grad[3] and dyb is not None) else None
         return dxa, dxb, dwa, dwb, None, None, None, None, None, None, None
+
+
+def _lp_serves(x, w, stride, pad, dil):
+    """Does the bf16-pipe forward kernel take this Conv2d in the current math mode?"""
+    n, ci, hi, wi = x.shape
+    co, k = w.shape[0], w.shape[2]
+    ho, wo = conv_out_size(hi, k, stride, pad, dil, False, 0), conv_out_size(wi, k, stride, pad, dil, False, 0)
+    g = ConvGeom(n, hi, wi, ci, ho, wo, co, k, k, stride, pad, dil, 0, 1)
+    return bool(_lib.lib().senas_conv2d_kernel_name_lp(C.byref(g), 0, MATH_TERMS))
 
 
 def conv2d_pair(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu=False, want_stats=False):
     """((ya, stats_a), (yb, stats_b)) of two convolutions of one tensor (two aliases of it) that differ in the dilation only."""
-    if MATH_TERMS:                           # the bf16-pipe kernels have no pair form: two calls
+    if MATH_TERMS and _lp_serves(xa, wa, stride, pad_a, dil_a):
+        # the bf16-pipe kernels have no pair form: two calls where they serve the shape (what they do not serve -- the search
+        # cell's 8-channel edges, small maps -- keeps its fp32 pair launch in every math mode)
         return (conv2d(xa, wa, stride, pad_a, dil_a, in_relu=in_relu, want_stats=want_stats),
                 conv2d(xb, wb, stride, pad_b, dil_b, in_relu=in_relu, want_stats=want_stats))
     ya, sa, yb, sb = _Conv2dPair.apply(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats)

@@ -43,15 +43,48 @@ class BuildCell(nn.Module):
             OPS[name](c_in1 if idx < self._input_num else c_part, c_part, edge_type(idx), dropout_prob)
             for name, idx in gene)
 
+    paired = True       # dense stride-1 candidates that read the SAME state run two to a launch (class-wide switch)
+
+    def _pairs(self):
+        """{state: [(edge a, edge b)]}: ConvBn candidates (plain Conv2d, same kernel size and channels, no dropout) that read
+        one state -- two nodes taking the same op from the same state, or dil_3_conv_5 beside dil_2_conv_5.  Each pair is ONE
+        forward launch and one for its two data gradients (functional.conv2d_pair): on the small maps of the deep cells a
+        launch of either alone leaves most CUs idle."""
+        from .operations import ConvBn
+        plan = self.__dict__.get('_pair_plan')
+        if plan is None:
+            by_key = {}
+            for e, idx in enumerate(self._indices):
+                m = self._ops[e]
+                if type(m) is ConvBn and type(m.conv) is nn.Conv2d and m.drop is None and m.conv.groups == 1:
+                    c = m.conv
+                    by_key.setdefault((idx, tuple(c.weight.shape), c.stride), []).append(e)
+            plan = {}
+            for (idx, _, _), es in by_key.items():
+                for i in range(0, len(es) - 1, 2):
+                    plan.setdefault(idx, []).append((es[i], es[i + 1]))
+            self.__dict__['_pair_plan'] = plan
+        return plan
+
     def forward(self, in0, in1):
         # every consumer of a state (ops reading it, the output concat) gets its own alias, so that the state's
         # gradient is ONE n-ary sum (functional.fan_out) instead of n-1 autograd accumulations
         total = self._input_num + self._num_meta_node
         uses = [sum(1 for idx in self._indices if idx == k) + (1 if k in self._concat else 0) for k in range(total)]
         states = []
+        ready = {}                       # edge -> Term of a candidate that already ran beside its partner
+        pairs = self._pairs() if self.paired else {}
 
         def add_state(h):
-            states.append(iter(F.fan_out(h, uses[len(states)])))
+            k = len(states)
+            it = iter(F.fan_out(h, uses[k]))
+            states.append(it)
+            for ea, eb in pairs.get(k, ()):
+                ma, mb = self._ops[ea], self._ops[eb]
+                ca, cb = ma.conv, mb.conv
+                (za, sta), (zb, stb) = F.conv2d_pair(next(it), next(it), ca.weight, cb.weight, ca.stride[0], ca.padding[0],
+                                                    ca.dilation[0], cb.padding[0], cb.dilation[0], want_stats=ma.norm.training)
+                ready[ea], ready[eb] = F.Term(za, ma.norm, stats=sta), F.Term(zb, mb.norm, stats=stb)
 
         add_state(self.preprocess0(in0))
         add_state(self.preprocess1(in1))
@@ -61,7 +94,7 @@ class BuildCell(nn.Module):
         direct = all(k >= self._input_num for k in concat) and len(set(concat)) == len(concat)
         catbuf = None
         for i in range(self._num_meta_node):
-            pair = [self._ops[e].raw(next(states[self._indices[e]])) for e in (2 * i, 2 * i + 1)]
+            pair = [ready.pop(e) if e in ready else self._ops[e].raw(next(states[self._indices[e]])) for e in (2 * i, 2 * i + 1)]
             k = self._input_num + i
             cat = None
             if direct and k in concat:

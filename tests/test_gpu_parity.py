@@ -466,6 +466,79 @@ def test_derived_full_width_vs_oracle():
         assert err <= 1e-2, 'grad %s: L2 rel err %.2e' % (k, err)
 
 
+@pytest.mark.parametrize('case', [(4, 8, 8, 64, 64, 5, 3, 2), (4, 8, 16, 32, 48, 5, 3, 2), (4, 32, 32, 64, 64, 5, 3, 2), (2, 32, 32, 16, 16, 5, 3, 3),
+                                  (8, 32, 32, 128, 128, 5, 2, 3), (2, 32, 32, 40, 72, 3, 1, 2), (3, 16, 32, 24, 24, 5, 2, 1), (2, 64, 32, 32, 32, 3, 1, 1)])
+def test_conv_pair_launches_vs_single_calls(case):
+    """functional.conv2d_pair -- forward, both data gradients and both weight gradients of two convolutions of one tensor as
+    one launch each (senas_conv2d_fwd_pair / _bwd_data_pair / _bwd_weight_pair; problem 2 on blockIdx.z / .y) -- against the
+    two single calls: every problem of a pair launch is computed exactly as its own launch would (same kernel, same tile
+    order, fixed-order second stages), so outputs and all four gradients are bit-identical; shapes off the pair
+    kernels take the two single calls inside the same entry points."""
+    from senas_amd import functional as F
+    n, ci, co, h, w, k, da, db = case
+    gen = torch.Generator().manual_seed(sum(case))
+    cl = torch.channels_last
+    x0 = torch.randn(n, ci, h, w, generator=gen)
+    wa0, wb0 = (torch.randn(co, ci, k, k, generator=gen) * 0.1 for _ in range(2))
+    ga, gb = (torch.randn(n, co, h, w, generator=gen).to(dev()).contiguous(memory_format=cl) for _ in range(2))
+    res = []
+    for paired in (True, False):
+        x = x0.to(dev()).contiguous(memory_format=cl).requires_grad_(True)
+        wa, wb = wa0.to(dev()).requires_grad_(True), wb0.to(dev()).requires_grad_(True)
+        xa, xb = F.fan_out(x, 2)
+        if paired:
+            (ya, sa), (yb, sb) = F.conv2d_pair(xa, xb, wa, wb, 1, da * (k // 2), da, db * (k // 2), db, want_stats=True)
+        else:
+            ya, sa = F.conv2d(xa, wa, 1, da * (k // 2), da, want_stats=True)
+            yb, sb = F.conv2d(xb, wb, 1, db * (k // 2), db, want_stats=True)
+        torch.autograd.backward([ya, yb], [ga, gb])
+        res.append([t.detach().cpu() for t in (ya, sa, yb, sb, x.grad, wa.grad, wb.grad)])
+    for name, a, b in zip(('ya', 'stats a', 'yb', 'stats b', 'dx', 'dwa', 'dwb'), *res):
+        if name.startswith('stats'):                 # fp64 sums folded by atomics: the order of the blocks is not fixed
+            assert torch.allclose(a, b, rtol=1e-11, atol=1e-9), name
+        elif name.startswith('dw') and ci % 32 != 0 and ci != 8:
+            # off the two-stage kernels (split-K accumulated with atomics): the last bits move from run to run
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), name
+        else:
+            assert torch.equal(a, b), name
+    ref = torch.nn.functional.conv2d(x0.double(), wb0.double(), padding=db * (k // 2), dilation=db)
+    close(res[0][2], ref.numpy(), 'yb vs torch', rel=5e-5)
+
+
+def test_derived_cell_pair_launches_change_nothing():
+    """BuildCell runs two same-state dense candidates per launch (senas_model.BuildCell.paired: one forward launch, one for
+    the two data gradients).  A pair launch computes each problem exactly as its single launch would: logits and EVERY
+    gradient of the README genotype (c=32, depth 5, 2x1x64x64) are the same with the pairing on and off (logits bit for bit),
+    and the pairing is really taken (12 cells: one pair per down cell, two per up cell)."""
+    import copy
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import BuildCell, SenasModel
+    base = SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4)
+    _randomize(base, 5)
+    cells = [m for m in base.modules() if isinstance(m, BuildCell)]
+    assert sum(len(v) for m in cells for v in m._pairs().values()) == 4 * 1 + 8 * 2
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 64, 64, generator=gen).to(dev())
+    y = torch.randint(0, 2, (2, 64, 64), generator=gen).to(dev())
+    res = []
+    was = BuildCell.paired
+    try:
+        for paired in (True, False):
+            BuildCell.paired = paired
+            net = copy.deepcopy(base).to(dev()).train()
+            out = net(x)
+            SegmentationLosses('dice_ce')(out, y).backward()
+            res.append((out[-1].detach().cpu(), grads_of(net)))
+    finally:
+        BuildCell.paired = was
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:        # (some small-map weight gradients end in atomics: their last bit moves from run to run)
+        a, b = res[0][1][k], res[1][1][k]
+        assert float(np.abs(a - b).max()) <= 1e-6 * float(np.abs(b).max()) + 1e-12, k
+
+
 def test_supernet_full_width_vs_oracle():
     """The supernet at its real width (c=32: 32 -> 8 candidates, 8 -> 8 inner edges, 1x1 adapters, 24 -> 32 cell outputs),
     depth 3, 2x1x64x64: forward + backward + architecture gradients vs the CPU oracle."""

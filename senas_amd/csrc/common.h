@@ -204,6 +204,20 @@ __device__ __forceinline__ bool tap_src(const GatherGeom& g, int o, int k, int l
     return i >= 0 && i < lim;
 }
 
+// XCD-aware block coordinates of an (nx, ny) grid whose x walks a tensor in memory order and whose y counts problems that read
+// the same tensor (1 for single-problem launches).  Workgroups are placed on the 8 XCDs round-robin in dispatch order, and each
+// XCD has its own L2: with the plain order the rows a stencil shares with its neighbours -- and the input the problems share --
+// are fetched by several XCDs (counters: 3x the input for a 3x3 stencil, 16x for six depthwise problems of 3x3 / 5x5 taps).
+// Here XCD k takes the CONTIGUOUS eighth [k nx/8, (k+1) nx/8) of x, and walks it problem-fastest: the blocks that run together on
+// an XCD read the same rows.  A bijection of the grid whenever nx is a multiple of 8; the plain coordinates otherwise.
+struct VBlock { unsigned x, y; };
+__device__ __forceinline__ VBlock xcd_block() {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    if ((nx & 7u) != 0u) return VBlock{blockIdx.x, blockIdx.y};
+    const unsigned lin = blockIdx.x + nx * blockIdx.y, k = lin & 7u, j = lin >> 3;
+    return VBlock{k * (nx >> 3) + j / ny, j % ny};
+}
+
 // Weight-gradient geometry: G lives on the coarse grid (hg x wg, B channels), I on the fine grid
 // (hi x wi, A channels); dW[b][a][tap] = sum_{n,p} I[n, p*stride - pad + k*dil][a] * G[n, p][b].
 struct WgradGeom {
@@ -304,6 +318,7 @@ int launch_stem_wgrad(const WgradGeom& g, const float* X, const float* G, float*
 
 // conv_thin.hip (one side of the GEMM view has <= 4 channels: HBM-bound single-pass kernels; weights in torch layout)
 bool thin_k_ok(const GatherGeom& g);
+bool thin_k3_ok(const GatherGeom& g);      // ... and its straight-line 3x3 form (2 or 4 input channels)
 bool thin_k4_ok(const GatherGeom& g);     // stride-1 plain gather, 4 output columns per thread
 int launch_thin_k4(const GatherGeom& g, const float* in, const float* w, int d1, int swap, int flip, float* out, int in_relu,
                    double* stats, hipStream_t st);
@@ -323,6 +338,7 @@ int64_t c8_mfma_wgrad_ws_bytes(const WgradGeom& g);
 int launch_c8_mfma_wgrad(const WgradGeom& g, const float* X, const float* G, float* part, int* nblk_out, hipStream_t st,
                          const WPair2& second = WPair2{});
 bool thin_n_ok(const GatherGeom& g);
+bool thin_n3_ok(const GatherGeom& g);      // ... and its straight-line 3x3 form (at most 4 output channels)
 template <bool TG>
 int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, int swap, float* out, int in_relu,
                   double* stats, hipStream_t st);

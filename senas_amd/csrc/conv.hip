@@ -190,7 +190,7 @@ __device__ __forceinline__ void dwconv_body(const GatherGeom& g, const float* __
     const int cv = g.cout / V;
     int n_blk = 0, c_thr = 0;
     for (int kk = 0; kk < chunks; ++kk) {
-        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        long idx = ((long)xcd_block().x * chunks + kk) * 256 + threadIdx.x;
         const bool active = idx < total;
         if (!active) idx = total - 1;
         const int c = (int)(idx % cv) * V;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void dwconv_x4_body(const GatherGeom& g, const float*
     const int cv = C >> 2, wq = g.wout >> 2;
     int n_blk = 0, c_thr = 0;
     for (int kk = 0; kk < chunks; ++kk) {
-        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        long idx = ((long)xcd_block().x * chunks + kk) * 256 + threadIdx.x;
         const bool active = idx < total;
         if (!active) idx = total - 1;
         const int c = (int)(idx % cv) * 4;
@@ -348,14 +348,14 @@ struct DwTab {
 template <bool TG>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                long total, int P) {
-    const int p = blockIdx.y;
+    const int p = (int)xcd_block().y;
     dwconv_body<TG, 4, false>(p < ka ? ga : gb, tab.a[p] ? tab.a[p] : in, tab.w[p], tab.out[p], 0, nullptr, tab.stats[p], total, P, Epi{});
 }
 
 template <int KSA, int KSB, int S>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_x4_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                   long total, int P) {
-    const int p = blockIdx.y;
+    const int p = (int)xcd_block().y;
     const float* src = tab.a[p] ? tab.a[p] : in;          // a problem may bring its own input (the two input states of a search cell)
     if (KSA == KSB || p < ka) dwconv_x4_body<KSA, S>(ga, src, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
     else dwconv_x4_body<KSB, S>(gb, src, tab.w[p], tab.out[p], 0, tab.stats[p], total, P);
@@ -385,7 +385,7 @@ __device__ __forceinline__ void dwconv_t2_quad_body(const GatherGeom& g, const f
     const int cv = C >> 2;
     int n_blk = 0, c_thr = 0;
     for (int kk = 0; kk < chunks; ++kk) {
-        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;
+        long idx = ((long)xcd_block().x * chunks + kk) * 256 + threadIdx.x;
         const bool active = idx < total;
         if (!active) idx = total - 1;
         const int c = (int)(idx % cv) * 4;
@@ -433,7 +433,7 @@ __device__ __forceinline__ void dwconv_t2_quad_body(const GatherGeom& g, const f
 template <int KSA, int KSB>
 __global__ __launch_bounds__(256) void dwconv_multi_fwd_t2_kernel(GatherGeom ga, GatherGeom gb, int ka, const float* __restrict__ in, DwTab tab,
                                                                   long total, int P) {
-    const int p = blockIdx.y;
+    const int p = (int)xcd_block().y;
     const float* src = tab.a[p] ? tab.a[p] : in;
     if (KSA == KSB || p < ka) dwconv_t2_quad_body<KSA>(ga, src, tab.w[p], tab.out[p], tab.stats[p], total, P);
     else dwconv_t2_quad_body<KSB>(gb, src, tab.w[p], tab.out[p], tab.stats[p], total, P);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom ga, 
         wl[na + i] = tab.w[ka + p][cc * tapsb + t];
     }
     __syncthreads();
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)xcd_block().x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int cv = C / 4;
     const int c = (int)(idx % cv) * 4;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_x4_kernel(GatherGeom g
         wl[na + i] = tab.w[ka + p][cc * TB + (flip ? TB - 1 - t : t)];
     }
     __syncthreads();
-    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) / PS;
+    const long idx = ((long)xcd_block().x * 256 + threadIdx.x) / PS;
     const int sp = PS > 1 ? (int)(threadIdx.x % PS) : 0;
     if (idx >= total) return;                                        // (the PS lanes of an output leave together)
     const int cv = C >> 2, wq = ga.wout >> 2;
@@ -650,7 +650,8 @@ __device__ __forceinline__ void dwconv_wgrad_part_body(const WgradGeom& g, const
     const int lanes = 256 / C4;                                     // pixel lanes per block
     const int per_img = g.hg * g.wg;
     const long total = (long)g.n * per_img;
-    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    const unsigned vbx = xcd_block().x;
+    long p0 = (long)vbx * g.chunk, p1 = p0 + g.chunk;
     if (p1 > total) p1 = total;
     float acc[TAPS][4];
 #pragma unroll
@@ -710,7 +711,7 @@ __device__ __forceinline__ void dwconv_wgrad_part_body(const WgradGeom& g, const
         const int j = i & 3, t = (i >> 2) % TAPS, cg = (i >> 2) / TAPS;
         float v = 0.f;
         for (int w = 0; w < nparts; ++w) v += red[((size_t)(w * C4 + cg) * TAPS + t) * 4 + j];
-        part[((size_t)blockIdx.x * C + cg * 4 + j) * TAPS + t] = v;
+        part[((size_t)vbx * C + cg * 4 + j) * TAPS + t] = v;
     }
     SENAS_PHASE(4);
 }
@@ -732,7 +733,7 @@ struct DwWgradTab {
 
 template <int KSA, int KSB>
 __global__ __launch_bounds__(256) void dwconv_wgrad_part_multi_kernel(WgradGeom ga, WgradGeom gb, int ka, DwWgradTab tab) {
-    const int p = blockIdx.y;
+    const int p = (int)xcd_block().y;
     if (KSA == KSB || p < ka) dwconv_wgrad_part_body<KSA>(ga, tab.I[p], tab.G[p], tab.part[p], 0, 0);
     else dwconv_wgrad_part_body<KSB>(gb, tab.I[p], tab.G[p], tab.part[p], 0, 0);
 }
@@ -1415,12 +1416,16 @@ extern "C" const char* senas_conv2d_kernel_name(const senas_conv_geom* g, int wh
         snprintf(c8name, sizeof c8name, "conv_c8_mfma_kernel<%d, %d>", gg.cin == 8 ? 8 : 16, c8_mfma_tiles_per_wave(gg));
         return c8name;
     }
+    if (thin_k_ok(gg) && thin_k3_ok(gg)) {
+        if (gg.cin == 2) return tg ? "conv_thin_k3_kernel<2, true>" : "conv_thin_k3_kernel<2, false>";
+        return tg ? "conv_thin_k3_kernel<4, true>" : "conv_thin_k3_kernel<4, false>";
+    }
     if (thin_k_ok(gg)) return tg ? "conv_thin_k_kernel<true>" : "conv_thin_k_kernel<false>";
     if (which == 0 && thin_n_ok(gg) && (gg.cout <= 4 || tr || !lds_gather_ok(gg))) {
         static char buf[8][48];
         static int slot = 0;
         char* b = buf[slot++ & 7];
-        snprintf(b, 48, "conv_thin_n_kernel<%d, %s>", gg.cout <= 2 ? 2 : (gg.cout <= 4 ? 4 : 8), tr ? "true" : "false");
+        snprintf(b, 48, "conv_thin_n%s_kernel<%d, %s>", thin_n3_ok(gg) ? "3" : "", gg.cout <= 2 ? 2 : (gg.cout <= 4 ? 4 : 8), tr ? "true" : "false");
         return b;
     }
     if (!tr && lds_gather_ok(gg)) {

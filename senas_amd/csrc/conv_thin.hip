@@ -199,6 +199,107 @@ __global__ __launch_bounds__(256) void conv_thin_k4_kernel(GatherGeom g, const f
     }
 }
 
+// thin-K gather, 3x3, stride 1, dilation 1, padding 1 (the segmentation head's data gradient: n_class -> 32 channels at full
+// resolution), CIN in {2, 4}: the generic kernel above walks its taps behind bounds tests, and hipcc puts a full
+// `s_waitcnt vmcnt(0)` after every load that sits behind control flow -- 18 dependent L2 round trips per thread (92 us where the
+// output alone is 67 MB = 15 us of HBM time).  Here the nine taps are nine unconditional loads of clamped addresses, issued
+// back to back; borders are zeroed by selects.  Same thread mapping, weights, mask and statistics as above.
+template <int CIN, bool TG>
+__global__ __launch_bounds__(256) void conv_thin_k3_kernel(GatherGeom g, const float* __restrict__ in, const float* __restrict__ w, int d1,
+                                                           int swap, float* __restrict__ out, int in_relu, const float* __restrict__ mask,
+                                                           double* __restrict__ stats, int passes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wfloats = 9 * CIN * g.cout;
+    for (int i = threadIdx.x; i < wfloats; i += 256) {
+        const int b = i % g.cout, a = (i / g.cout) % CIN, t = i / (g.cout * CIN);
+        lds[i] = weight_at(w, d1, 9, swap, t, a, b);
+    }
+    double* sred = reinterpret_cast<double*>(lds + ((wfloats + 3) & ~3));
+    if (stats != nullptr && threadIdx.x < 2 * g.cout) sred[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int Q = g.cout >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, ppb = 256 / Q;
+    const int n = blockIdx.y, hw = g.hout * g.wout;
+    int bx = blockIdx.x;                                   // XCD-aware order (see conv_thin_n3_kernel)
+    if ((gridDim.x & 7u) == 0) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int p0 = bx * ppb * passes;
+    const float* __restrict__ img = in + (size_t)n * g.hin * g.win * CIN;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < passes; ++it) {
+        const int pix = p0 + it * ppb + pl;
+        const bool live = pix < hw;
+        const int pc = live ? pix : hw - 1;
+        const int oy = pc / g.wout, ox = pc - oy * g.wout;
+        float v[9][CIN];
+        bool ok[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const int iy = TG ? oy + 1 - ky : oy - 1 + ky, ix = TG ? ox + 1 - kx : ox - 1 + kx;
+            ok[t] = iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            const int cy = min(max(iy, 0), g.hin - 1), cx = min(max(ix, 0), g.win - 1);
+            const float* ip = img + ((size_t)cy * g.win + cx) * CIN;
+            if (CIN == 2) {
+                const float2 u = *reinterpret_cast<const float2*>(ip);
+                v[t][0] = u.x; v[t][1] = u.y;
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(ip);
+                v[t][0] = u.x; v[t][1] = u.y; v[t][CIN - 2] = u.z; v[t][CIN - 1] = u.w;
+            }
+        }
+        const size_t o = ((size_t)n * hw + pc) * g.cout + q * 4;
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mask != nullptr) m = *reinterpret_cast<const float4*>(mask + o);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                float x = ok[t] ? v[t][ci] : 0.f;
+                if (in_relu) x = fmaxf(x, 0.f);
+                const float4 w4 = *reinterpret_cast<const float4*>(lds + (t * CIN + ci) * g.cout + q * 4);
+                acc[0] = fmaf(x, w4.x, acc[0]);
+                acc[1] = fmaf(x, w4.y, acc[1]);
+                acc[2] = fmaf(x, w4.z, acc[2]);
+                acc[3] = fmaf(x, w4.w, acc[3]);
+            }
+        }
+        if (!(m.x > 0.f)) acc[0] = 0.f;
+        if (!(m.y > 0.f)) acc[1] = 0.f;
+        if (!(m.z > 0.f)) acc[2] = 0.f;
+        if (!(m.w > 0.f)) acc[3] = 0.f;
+        if (live) {
+            *reinterpret_cast<float4*>(out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[j] += (double)acc[j];
+                ss[j] += (double)acc[j] * (double)acc[j];
+            }
+        }
+    }
+    if (stats != nullptr) {           // as conv_thin_k_kernel: lanes that share q -> LDS -> one atomic per channel per block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int o = Q; o < 64; o <<= 1) {
+                s[j] += __shfl_xor(s[j], o, 64);
+                ss[j] += __shfl_xor(ss[j], o, 64);
+            }
+        }
+        if ((threadIdx.x & 63) < Q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&sred[(q * 4 + j) * 2], s[j]);
+                atomicAdd(&sred[(q * 4 + j) * 2 + 1], ss[j]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * g.cout) atomicAdd(stats + (size_t)n * g.cout * 2 + threadIdx.x, sred[threadIdx.x]);
+    }
+}
+
+bool thin_k3_ok(const GatherGeom& g) {
+    return g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil == 1 && g.pad == 1 && g.hout == g.hin && g.wout == g.win && (g.cin == 2 || g.cin == 4);
+}
+
 bool thin_k4_ok(const GatherGeom& g) {
     const int q = g.cout >> 2;
     // (a quarter of the one-pixel form's threads: only where that still fills the chip -- measured: 128x128x4 images up)
@@ -231,6 +332,11 @@ int launch_thin_k(const GatherGeom& g, const float* in, const float* w, int d1, 
     while (passes > 1 && (long)g.n * ((hw + ppb * passes - 1) / (ppb * passes)) < 1024) passes >>= 1;
     dim3 grid((hw + ppb * passes - 1) / (ppb * passes), g.n);
     const size_t bytes = (size_t)((g.kh * g.kw * g.cin * g.cout + 3) & ~3) * sizeof(float) + (size_t)2 * g.cout * sizeof(double);
+    if (thin_k3_ok(g)) {
+        if (g.cin == 2) hipLaunchKernelGGL((conv_thin_k3_kernel<2, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, mask, stats, passes);
+        else hipLaunchKernelGGL((conv_thin_k3_kernel<4, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, mask, stats, passes);
+        return launch_status("conv_thin_k3");
+    }
     hipLaunchKernelGGL((conv_thin_k_kernel<TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, mask, stats, passes);
     return launch_status("conv_thin_k");
 }
@@ -322,6 +428,101 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(GatherGeom g, const fl
     }
 }
 
+// thin-N gather, 3x3, stride 1, dilation 1, padding 1 (the segmentation head: 32 -> n_class at full resolution): as
+// conv_thin_k3_kernel, the nine taps are nine unconditional loads of clamped addresses issued back to back (the generic
+// kernel's bounds tests serialise its loads), borders zeroed by selects.
+template <int CO, bool TG>
+__global__ __launch_bounds__(256) void conv_thin_n3_kernel(GatherGeom g, const float* __restrict__ in, const float* __restrict__ w, int d1,
+                                                           int swap, float* __restrict__ out, int in_relu, double* __restrict__ stats,
+                                                           int passes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [9*cin][CO] (zero-padded columns), then fp64 [CO][2]
+    const int rows = 9 * g.cin;
+    for (int i = threadIdx.x; i < rows * CO; i += 256) {
+        const int b = i % CO, a = (i / CO) % g.cin, t = i / (CO * g.cin);
+        lds[i] = b < g.cout ? weight_at(w, d1, 9, swap, t, a, b) : 0.f;
+    }
+    double* sred = reinterpret_cast<double*>(lds + ((rows * CO + 3) & ~3));
+    if (threadIdx.x < 2 * CO) sred[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int Q = g.cin >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, ppb = 256 / Q;
+    const int n = blockIdx.y, hw = g.hout * g.wout;
+    // XCD-aware order: workgroups b and b + 8 share an XCD (round-robin placement), and a block's three input rows are its
+    // neighbours' too -- an XCD takes a CONTIGUOUS eighth of the image so that those re-reads meet in one L2 (else every row
+    // is fetched by three XCDs: 47 us for one pass over 67 MB)
+    int bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int p0 = bx * ppb * passes;
+    const float* __restrict__ img = in + (size_t)n * g.hin * g.win * g.cin + q * 4;
+    double s[CO], ss[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) s[j] = ss[j] = 0.0;
+    for (int it = 0; it < passes; ++it) {
+        const int pix = p0 + it * ppb + pl;
+        const bool live = pix < hw;                       // dead lanes keep shuffling with the live ones
+        const int pc = live ? pix : 0;
+        const int oy = pc / g.wout, ox = pc - oy * g.wout;
+        float4 v[9];
+        bool ok[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const int iy = TG ? oy + 1 - ky : oy - 1 + ky, ix = TG ? ox + 1 - kx : ox - 1 + kx;
+            ok[t] = iy >= 0 && iy < g.hin && ix >= 0 && ix < g.win;
+            const int cy = min(max(iy, 0), g.hin - 1), cx = min(max(ix, 0), g.win - 1);
+            v[t] = *reinterpret_cast<const float4*>(img + ((size_t)cy * g.win + cx) * g.cin);
+        }
+        float acc[CO];
+#pragma unroll
+        for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float4 x = ok[t] ? v[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in_relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+            const float* wt = lds + (t * g.cin + q * 4) * CO;
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                acc[j] = fmaf(x.x, wt[j], acc[j]);
+                acc[j] = fmaf(x.y, wt[CO + j], acc[j]);
+                acc[j] = fmaf(x.z, wt[2 * CO + j], acc[j]);
+                acc[j] = fmaf(x.w, wt[3 * CO + j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CO; ++j) acc[j] = group_sum(acc[j], Q);          // Q <= 16: inside a 16-lane row, DPP
+        if (live && q == 0) {
+            float* op = out + ((size_t)n * hw + pix) * g.cout;
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                if (j < g.cout) {
+                    op[j] = acc[j];
+                    s[j] += (double)acc[j];
+                    ss[j] += (double)acc[j] * (double)acc[j];
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+            s[j] = row_strided_sum(s[j], Q);
+            ss[j] = row_strided_sum(ss[j], Q);
+        }
+        if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < CO; ++j) {
+                atomicAdd(&sred[j * 2], s[j]);
+                atomicAdd(&sred[j * 2 + 1], ss[j]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * g.cout) atomicAdd(stats + (size_t)n * g.cout * 2 + threadIdx.x, sred[threadIdx.x]);
+    }
+}
+
+bool thin_n3_ok(const GatherGeom& g) {
+    return g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil == 1 && g.pad == 1 && g.hout == g.hin && g.wout == g.win && g.cout <= 4;
+}
+
 bool thin_n_ok(const GatherGeom& g) {
     const int q = g.cin >> 2;
     return g.cout <= 8 && g.cin % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh * g.kw * g.cin <= 2048 &&
@@ -337,6 +538,11 @@ int launch_thin_n(const GatherGeom& g, const float* in, const float* w, int d1, 
     dim3 grid((hw + ppb * passes - 1) / (ppb * passes), g.n);
     const int co = g.cout <= 2 ? 2 : (g.cout <= 4 ? 4 : 8);
     const size_t bytes = (size_t)((g.kh * g.kw * g.cin * co + 3) & ~3) * sizeof(float) + (size_t)2 * co * sizeof(double);
+    if (thin_n3_ok(g)) {
+        if (co == 2) hipLaunchKernelGGL((conv_thin_n3_kernel<2, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+        else hipLaunchKernelGGL((conv_thin_n3_kernel<4, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
+        return launch_status("conv_thin_n3");
+    }
     if (co == 2) hipLaunchKernelGGL((conv_thin_n_kernel<2, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
     else if (co == 4) hipLaunchKernelGGL((conv_thin_n_kernel<4, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
     else hipLaunchKernelGGL((conv_thin_n_kernel<8, TG>), grid, dim3(256), bytes, st, g, in, w, d1, swap, out, in_relu, stats, passes);
@@ -360,7 +566,11 @@ __global__ __launch_bounds__(256) void wgrad_thin_n_kernel(WgradGeom g, const fl
     const int Q = g.A >> 2, q = threadIdx.x & (Q - 1), pl = threadIdx.x / Q, lanes = 256 / Q;
     const int per_img = g.hg * g.wg;
     const long total = (long)g.n * per_img;
-    long p0 = (long)blockIdx.x * g.chunk, p1 = p0 + g.chunk;
+    // XCD-aware order: an XCD (workgroups b, b + 8, ...) takes a contiguous eighth of the pixels, so the taps' re-reads of
+    // neighbouring rows meet in one L2; the partial row stays indexed by blockIdx.x (any order: the sum launch adds them all)
+    unsigned bx = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    long p0 = (long)bx * g.chunk, p1 = p0 + g.chunk;
     if (p1 > total) p1 = total;
     float acc[TAPS][4][BB];
 #pragma unroll
@@ -427,14 +637,16 @@ bool thin_n_wgrad_ok(const WgradGeom& g) {
     return g.B <= 4 && g.A % 4 == 0 && q >= 1 && q <= 16 && (q & (q - 1)) == 0 && g.kh == g.kw && (g.kh == 1 || g.kh == 3);
 }
 
-int64_t thin_n_wgrad_ws_bytes(const WgradGeom& g) { return (int64_t)512 * g.B * g.A * g.kh * g.kw * sizeof(float); }
+// (at most 2048 partial rows: 512 left two waves per SIMD walking 32 dependent iterations each on the head's 256 x 256 maps -- 58 us
+// for one pass over 67 MB)
+int64_t thin_n_wgrad_ws_bytes(const WgradGeom& g) { return (int64_t)2048 * g.B * g.A * g.kh * g.kw * sizeof(float); }
 
 // part: >= thin_n_wgrad_ws_bytes(g); returns the number of partial rows (blocks) written
 int launch_thin_n_wgrad(WgradGeom g, const float* I, const float* G, float* part, int i_relu, int g_relu, int* nblk_out,
                         hipStream_t st) {
     const long total = (long)g.n * g.hg * g.wg;
     long nblk = (total + 255) / 256;
-    if (nblk > 512) nblk = 512;
+    if (nblk > 2048) nblk = 2048;
     g.chunk = (int)((total + nblk - 1) / nblk);
     nblk = (total + g.chunk - 1) / g.chunk;
     const int bb = g.B <= 2 ? 2 : 4;

@@ -28,7 +28,7 @@ __device__ __forceinline__ void decode(long idx, int cv, int wo, int ho, int& c,
     const int chunks = uniform ? (P_) : 1;                                                      \
     int n_blk = 0, ch_thr = 0;                                                                  \
     for (int kk = 0; kk < chunks; ++kk) {                                                       \
-        long idx = ((long)blockIdx.x * chunks + kk) * 256 + threadIdx.x;                        \
+        long idx = ((long)xcd_block().x * chunks + kk) * 256 + threadIdx.x;                        \
         const bool active = idx < (total_);                                                     \
         if (!active) idx = (total_) - 1;
 #define SENAS_FWD_LOOP_END(stats_, c_)                                                          \
@@ -94,7 +94,7 @@ __device__ __forceinline__ int window_count(int o, int stride, int lim) {
 template <int V>
 __global__ __launch_bounds__(256) void avgpool3_bwd_kernel(PoolGeom g, const float* __restrict__ dy, int in_relu,
                                                            const float* __restrict__ x, float* __restrict__ dx, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)xcd_block().x * 256 + threadIdx.x;     // (XCD-aware order: common.h)
     if (idx >= total) return;
     int ch, ix, iy, n;
     decode<V>(idx, g.c / V, g.w, g.h, ch, ix, iy, n);
@@ -172,7 +172,7 @@ template <int V>
 __global__ __launch_bounds__(256) void maxpool3_bwd_kernel(PoolGeom g, const float* __restrict__ dy,
                                                            const uint8_t* __restrict__ amax, int in_relu,
                                                            const float* __restrict__ x, float* __restrict__ dx, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)xcd_block().x * 256 + threadIdx.x;     // (XCD-aware order: common.h)
     if (idx >= total) return;
     int ch, ix, iy, n;
     decode<V>(idx, g.c / V, g.w, g.h, ch, ix, iy, n);
@@ -251,7 +251,7 @@ __device__ __forceinline__ float bilinear_w(int d, int lim_src, int i) {
 template <int V>
 __global__ __launch_bounds__(256) void bilinear2x_bwd_kernel(PoolGeom g, const float* __restrict__ dy,
                                                              float* __restrict__ dx, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)xcd_block().x * 256 + threadIdx.x;     // (XCD-aware order: common.h)
     if (idx >= total) return;
     int ch, ix, iy, n;
     decode<V>(idx, g.c / V, g.w, g.h, ch, ix, iy, n);
@@ -357,7 +357,7 @@ struct UnstackParts {
 template <int V>
 __global__ __launch_bounds__(256) void unstack_kernel(PoolGeom g, const float* __restrict__ src, UnstackParts parts, int k,
                                                       long total, int P) {
-    const int e = blockIdx.y;
+    const int e = (int)xcd_block().y;                      // (with the loop's xcd_block().x: one decode of the grid)
     float* __restrict__ dst = parts.dst[e];
     double* __restrict__ stats = parts.stats[e];
     if (dst == nullptr) return;                            // a padding part of the stack: nobody reads it

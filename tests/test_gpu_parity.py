@@ -616,7 +616,11 @@ _CONV_CASES = [
     (2, 32, 32, 16, 24, 5, 2, 2, True, False),      # ConvTranspose2d (UP ops), even dilation: 3 empty phases
     (2, 32, 32, 16, 24, 3, 2, 1, True, True),
     (3, 1, 32, 40, 40, 7, 1, 1, False, False),      # stem: small-c_in weight gradient
-    (2, 32, 2, 24, 24, 3, 1, 1, False, True),       # segmentation head (2 classes)
+    (2, 32, 2, 24, 24, 3, 1, 1, False, True),       # segmentation head (2 classes): straight-line 3x3 thin-N forward / thin-K data gradient
+    (2, 32, 4, 30, 22, 3, 1, 1, False, True),       # ... 4 classes
+    (3, 32, 2, 70, 50, 3, 1, 1, False, True),       # ... several pixel passes per thread, ragged last block
+    (2, 2, 16, 12, 12, 3, 1, 1, True, False),       # ... the transposed-gather instantiations (ConvTranspose2d 3x3 stride 1 from 2 channels)
+    (8, 32, 2, 256, 256, 3, 1, 1, False, True),     # ... at the BASELINE size (2 048 partial rows in the weight gradient)
     (2, 8, 8, 20, 20, 5, 1, 3, False, False),       # inner supernet edge
     (2, 3, 16, 20, 28, 3, 2, 1, False, False),      # thin-K gather: RGB stem, stride 2
     (2, 32, 4, 18, 30, 1, 1, 1, False, False),      # thin-N: 1x1 head, 4 classes

@@ -455,13 +455,10 @@ def main():
     # be read back from inside a replayed graph; kernel durations are the same in both modes)
     probe_steps = 2
     step.fb._collectives = False                                # (no collective inside the probe passes)
-    from senas_amd.senas_model import BuildCell
-    BuildCell.paired = False                                    # (every convolution launched on its own: one span, one kernel, one geometry)
-    F.TIMER = F.KernelTimer()
+    F.TIMER = F.KernelTimer()                                   # (a pair launch is one span: one kernel instance, two problems' flops)
     for _ in range(probe_steps):
         step.fb._eager()
     timer, F.TIMER = F.TIMER, None
-    BuildCell.paired = True
     step.fb._collectives = True
     images = args.batch * world * args.steps
     value = images / elapsed
@@ -485,7 +482,7 @@ def main():
         for rname, flops, nbytes, e0, e1, tag in timer.records:
             if rname == name and tag is not None:
                 ms = e0.elapsed_time(e1)
-                b = by_geo.setdefault(tag[1:13], [0, 0.0, 0.0])
+                b = by_geo.setdefault(tag[1:13] + tag[15:], [0, 0.0, 0.0])        # (+ 'pair': two problems of this geometry in one launch)
                 b[0] += 1
                 b[1] += max(ms - event_overhead_ms, 0.5 * ms)
                 b[2] += flops

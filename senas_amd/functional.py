@@ -226,17 +226,25 @@ def may_defer(*autograd_grads):
     return DEFER is not None and all(g is None for g in autograd_grads)
 
 
-def _span(kind, g, x, w, y):
+def _span(kind, g, x, w, y, problems=1):
+    """HIP-event span of one convolution launch (bench.py's roofline probe).  ``problems``: 2 for a pair launch -- one kernel
+    instance working on two problems of this geometry: twice the flops and bytes under the same kernel symbol."""
     if TIMER is None:
         return _NOSPAN
-    macs = (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
+    macs = problems * (g.n * g.hi * g.wi * g.ci * (g.co // g.groups) if g.transposed else g.n * g.ho * g.wo * g.co * (g.ci // g.groups)) * g.kh * g.kw
     which = {'conv_fwd': 0, 'conv_dgrad': 1, 'conv_wgrad': 2}[kind]
     name = b''
     if MATH_TERMS:
         name = _lib.lib().senas_conv2d_kernel_name_lp(C.byref(g), which, MATH_TERMS)
     name = (name or _lib.lib().senas_conv2d_kernel_name(C.byref(g), which)).decode()      # the symbol rocprofv3 reports
-    tag = (kind,) + tuple(getattr(g, f) for f, _ in g._fields_)
-    return TIMER.span(name, 2.0 * macs, 4.0 * (x.numel() + y.numel() + w.numel()), tag)
+    tag = (kind,) + tuple(getattr(g, f) for f, _ in g._fields_) + (('pair',) if problems > 1 else ())
+    return TIMER.span(name, 2.0 * macs, 4.0 * problems * (x.numel() + y.numel() + w.numel()), tag)
+
+
+def _unspan():
+    """Drop the span just recorded: the entry point inside it declined without launching."""
+    if TIMER is not None and TIMER.records:
+        TIMER.records.pop()
 
 
 # ------------------------------------------------------------------------------------------ convolution
@@ -297,10 +305,13 @@ def _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb):
         wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for nb, _ in sizes)
         defer = may_defer(da[1], db[1])
         ia, ib = (_lib.SumItem(), _lib.SumItem()) if defer else (None, None)
-        rc = L.senas_conv2d_bwd_weight_pair(C.byref(ga), C.byref(gb), x.data_ptr(), in_relu, dya.data_ptr(), dyb.data_ptr(),
-                                            da[0].data_ptr(), db[0].data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
-                                            C.byref(ia) if defer else None, C.byref(ib) if defer else None, _stream())
-        if rc != _lib.UNSUPPORTED:
+        with _span('conv_wgrad', ga, x, wa, dya, problems=2):
+            rc = L.senas_conv2d_bwd_weight_pair(C.byref(ga), C.byref(gb), x.data_ptr(), in_relu, dya.data_ptr(), dyb.data_ptr(),
+                                                da[0].data_ptr(), db[0].data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
+                                                C.byref(ia) if defer else None, C.byref(ib) if defer else None, _stream())
+        if rc == _lib.UNSUPPORTED:
+            _unspan()
+        else:
             _lib.check(rc, 'senas_conv2d_bwd_weight_pair')
             if defer:
                 for item, ws in ((ia, wsa), (ib, wsb)):
@@ -405,12 +416,15 @@ class _Conv2dPair(torch.autograd.Function):
         sb = new_stats(n, co, x) if want_stats else None
         nb = int(L.senas_conv2d_ws_bytes(C.byref(ga)))
         wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for _ in range(2))
-        rc = L.senas_conv2d_fwd_pair(C.byref(ga), C.byref(gb), x.data_ptr(), wa.data_ptr(), wb.data_ptr(), ya.data_ptr(), yb.data_ptr(),
-                                     int(in_relu), _p(sa), _p(sb), wsa.data_ptr(), wsb.data_ptr(), _packed(wa, 0), _packed(wb, 0), _stream())
+        with _span('conv_fwd', ga, x, wa, ya, problems=2):
+            rc = L.senas_conv2d_fwd_pair(C.byref(ga), C.byref(gb), x.data_ptr(), wa.data_ptr(), wb.data_ptr(), ya.data_ptr(), yb.data_ptr(),
+                                         int(in_relu), _p(sa), _p(sb), wsa.data_ptr(), wsb.data_ptr(), _packed(wa, 0), _packed(wb, 0), _stream())
         if rc == _lib.UNSUPPORTED:
+            _unspan()
             for g, w, y, st, ws in ((ga, wa, ya, sa, wsa), (gb, wb, yb, sb, wsb)):
-                _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(st), ws.data_ptr(),
-                                              _packed(w, 0), _stream()), 'senas_conv2d_fwd')
+                with _span('conv_fwd', g, x, w, y):
+                    _lib.check(L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(st), ws.data_ptr(),
+                                                  _packed(w, 0), _stream()), 'senas_conv2d_fwd')
         else:
             _lib.check(rc, 'senas_conv2d_fwd_pair')
         ctx.save_for_backward(x, wa, wb)
@@ -435,9 +449,12 @@ class _Conv2dPair(torch.autograd.Function):
             if dya is not None and dyb is not None:
                 dxa, dxb = torch.empty_like(x, memory_format=CL), torch.empty_like(x, memory_format=CL)
                 wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for _ in range(2))
-                rc = L.senas_conv2d_bwd_data_pair(C.byref(ga), C.byref(gb), dya.data_ptr(), dyb.data_ptr(), wa.data_ptr(), wb.data_ptr(),
-                                                  dxa.data_ptr(), dxb.data_ptr(), ctx.in_relu, x.data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
-                                                  _packed(wa, 1), _packed(wb, 1), _stream())
+                with _span('conv_dgrad', ga, x, wa, dya, problems=2):
+                    rc = L.senas_conv2d_bwd_data_pair(C.byref(ga), C.byref(gb), dya.data_ptr(), dyb.data_ptr(), wa.data_ptr(), wb.data_ptr(),
+                                                      dxa.data_ptr(), dxb.data_ptr(), ctx.in_relu, x.data_ptr(), wsa.data_ptr(), wsb.data_ptr(),
+                                                      _packed(wa, 1), _packed(wb, 1), _stream())
+                if rc == _lib.UNSUPPORTED:
+                    _unspan()
             if rc == _lib.UNSUPPORTED:
                 outs = []
                 for g, w, dy in ((ga, wa, dya), (gb, wb, dyb)):
@@ -446,8 +463,9 @@ class _Conv2dPair(torch.autograd.Function):
                         continue
                     dx = torch.empty_like(x, memory_format=CL)
                     ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
-                    _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu, x.data_ptr(),
-                                                       ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
+                    with _span('conv_dgrad', g, x, w, dy):
+                        _lib.check(L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu, x.data_ptr(),
+                                                           ws.data_ptr(), _packed(w, 1), _stream()), 'senas_conv2d_bwd_data')
                     outs.append(dx)
                 dxa, dxb = outs
             else:

@@ -7,8 +7,6 @@ tag=${1:-rX}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
-python3 bench.py > $out/bench.log 2> $out/bench.err
-tail -1 $out/bench.log > $out/bench.json
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --search-steps 0 --lp-steps 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o st -- $B --steps 20 --warmup 5 > $out/stats.log 2>&1
@@ -35,6 +33,11 @@ python3 tools/pmc_traffic.py $out/pmcFx3 $out/pmcWx3 $out/pmc_traffic_bf16x3.jso
 # (search_profile.py --eager: 2 warm-up + 2 timed steps, all launched eagerly: 4 steps in the counters)
 python3 tools/pmc_traffic.py $out/spF $out/spW $out/pmc_traffic_search.json --all --steps 4 > $out/pmc_traffic_search.txt
 cp $out/stats/*kernel_stats.csv $out/kernel_stats.csv
+# the bench line last: its `traffic` fields are read from the counter aggregates of THIS run
+cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+cp $out/pmc_traffic_search.json profiles/${tag}_pmc_traffic_search.json
+python3 bench.py > $out/bench.log 2> $out/bench.err
+tail -1 $out/bench.log > $out/bench.json
 # keep what travels back small: the raw traces are only needed for the aggregates above
 rm -rf $out/train $out/trainx3 $out/search $out/stats $out/pmcM $out/pmcMx3 $out/pmcF $out/pmcW $out/pmcFx3 $out/pmcWx3 $out/spF $out/spW
 echo done

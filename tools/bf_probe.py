@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where conv_bf's time goes: forward launches per math mode under SENAS_BF_PROBE masks (1 no staging, 2 no taps, 4 no
-epilogue) -- one process per mask (the library reads the variable once).  Needs the tuning build of the library
+epilogue, 8 no LDS fragment reads inside the tap loop, 16 no weight-fragment loads; masks as arguments, default: a sweep) -- one process per mask (the library reads the variable once).  Needs the tuning build of the library
 (`make -C senas_amd/csrc probe` -> senas_amd/libsenas_hip_probe.so); the shipped library has no such switch."""
 import os
 import subprocess

@@ -112,7 +112,7 @@ def test_derived_net_split_modes_vs_reference(fixture, tag, mode, math_mode):
     T.close(outs[-1], z[tag + '/logits'], tag + ' logits', rel=2e-4 if mode == 'bf16x6' else 1e-3)
     crit = MultiSegmentationLosses('dice_ce', kw['depth']) if tag.endswith('msup') else SegmentationLosses('dice_ce')
     loss = crit(outs, tgt)
-    assert abs(float(loss) - float(z[tag + '/loss64'])) <= (1e-5 if mode == 'bf16x6' else 1e-4) * abs(float(z[tag + '/loss64']))
+    assert abs(float(loss.detach()) - float(z[tag + '/loss64'])) <= (1e-5 if mode == 'bf16x6' else 1e-4) * abs(float(z[tag + '/loss64']))
     loss.backward()
     got = T.grads_of(net)
     exp = gio.unpack(z, tag + '/grad64/')

@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument('--rank-timeout', type=float, default=540.0,
                     help='N > 1: seconds the parent waits for the ranks before it kills them and exits non-zero')
     ap.add_argument('--pg-timeout', type=float, default=120.0, help='N > 1: torch.distributed rendezvous / collective timeout, seconds')
-    ap.add_argument('--lp-steps', type=int, default=60,
-                    help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16; 0 = skip them)')
+    ap.add_argument('--lp-steps', type=int, default=None,
+                    help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16; 0 = skip them).  Default: 60 on '
+                         'one GPU, 0 on N > 1 -- a scaling run times the fp32 train step and the search step, nothing else')
     ap.add_argument('--profile-math', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
                     help='PROFILING ONLY: run the primary (timed, event-probed) train step in this math mode, so that rocprofv3 sees '
                          'the bf16-pipe kernels in the steady-state window; the JSON line says so and is not a headline')
@@ -405,6 +406,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.lp_steps is None:
+        args.lp_steps = 60 if world == 1 else 0
     if world != args.gpus:
         log('WORLD_SIZE=%d but --gpus %d: reporting the world size actually running' % (world, args.gpus))
     dev_index = 0 if args.one_device else local_rank

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What do the channel-slice reads of stacked convolution outputs cost the cell node?  One search-cell node (24 terms of 8
 channels, mixing weights, ReLU, training mode) forward + backward on 4 x 8 x H x W terms that are (a) channel slices of
-stacked [4, 32, H, W] tensors (pixel stride 32: what the state-major search cell feeds its nodes), (b) dense tensors.
+stacked [4, 32, H, W] tensors (pixel stride 32: what the state-major search cell feeds its nodes), (b) dense tensors;
+`zstrided` / `dzstrided`: only the terms / only their gradients in the stacked layout.
 
 Run under the profiler, one layout per process (eager launches; the kernel table gives the times):
 
@@ -33,9 +34,14 @@ def main():
             st = F.chan_stats(zst)
             landing = F.GradLanding(4, (n, c, h, h), 4, persistent=True)      # the stacked gradient buffer the nodes write into
             for e in range(4):
-                if layout == 'strided':
+                if layout in ('strided', 'zstrided'):          # zstrided: slices forward, dense gradients
                     zs.append(zst[:, e * c:(e + 1) * c])
                     sts.append(st[:, e * c:(e + 1) * c])
+                    slots.append((landing, e) if layout == 'strided' else None)
+                elif layout == 'dzstrided':                    # dense terms, gradients written into the stacked buffer
+                    z = zst[:, e * c:(e + 1) * c].contiguous(memory_format=torch.channels_last)
+                    zs.append(z)
+                    sts.append(F.chan_stats(z))
                     slots.append((landing, e))
                 else:
                     z = zst[:, e * c:(e + 1) * c].contiguous(memory_format=torch.channels_last)

@@ -232,7 +232,8 @@ int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1, const floa
  * kind 0 = down cell (NORM edges: input state >= 2), kind 1 = up cell (NORM edges: every input state but 1); edges in the
  * order node 0 (states 0, 1), node 1 (states 0..2), ...  k = sum over nodes of (2 + i).
  * Backward: dM[kind] / dG are the tables the cell nodes (senas_node_bwd, dmix_accumulate) and the blends (senas_blend2_bwd)
- * ADDED their gradients into; the seven parameter gradients are OVERWRITTEN.  d_alpha[3] == NULL: alphas_up_nm IS alphas_dn_nm
+ * ADDED their gradients into -- dM[kind] with one [k][ops] row block ("slot") per cell of the kind, because the cells of one
+ * macro-grid column run on their own HIP stream and a plain read-modify-write table must have one writer at a time; the seven parameter gradients are OVERWRITTEN.  d_alpha[3] == NULL: alphas_up_nm IS alphas_dn_nm
  * (NAS(use_sharing=True), senas_search.py:148-150) and d_alpha[2] receives both contributions.                          */
 typedef struct senas_arch_mix {
     const float* alpha[4];      /* dn, up, dn_nm, up_nm */
@@ -248,6 +249,7 @@ typedef struct senas_arch_mix {
     float* d_beta[2];
     float* d_gamma;
     int32_t k, ops, nodes, grows;
+    int32_t slots;              /* backward: dM[kind] is [slots][k][ops]; the rows are folded in slot order (1..256)    */
 } senas_arch_mix;
 int senas_arch_mix_fwd(const senas_arch_mix* a, void* stream);
 int senas_arch_mix_bwd(const senas_arch_mix* a, void* stream);

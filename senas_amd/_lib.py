@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
+EXPECTED_ABI = 25          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
 MAX_STACK = 4
 
@@ -48,7 +49,7 @@ class ArchMix(C.Structure):
     _fields_ = [('alpha', C.c_void_p * 4), ('beta', C.c_void_p * 2), ('gamma', C.c_void_p), ('s_alpha', C.c_void_p * 4),
                 ('s_beta', C.c_void_p * 2), ('s_gamma', C.c_void_p), ('M', C.c_void_p * 2), ('dM', C.c_void_p * 2), ('dG', C.c_void_p),
                 ('d_alpha', C.c_void_p * 4), ('d_beta', C.c_void_p * 2), ('d_gamma', C.c_void_p),
-                ('k', C.c_int32), ('ops', C.c_int32), ('nodes', C.c_int32), ('grows', C.c_int32)]
+                ('k', C.c_int32), ('ops', C.c_int32), ('nodes', C.c_int32), ('grows', C.c_int32), ('slots', C.c_int32)]
 
 
 class SumItem(C.Structure):
@@ -174,6 +175,12 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the .so does not export the symbol
             fn.restype, fn.argtypes = res, args
+        abi = handle.senas_abi_version()
+        if abi != EXPECTED_ABI:
+            # a stale build product would read the arguments of a changed entry point as something else (a stream pointer
+            # as an int, ...): a wild launch instead of an error
+            raise SenasHipError('%s reports ABI %d, these bindings expect %d: rebuild it with `make -C senas_amd/csrc`'
+                                % (LIB_PATH, abi, EXPECTED_ABI))
         _lib = handle
     return _lib
 

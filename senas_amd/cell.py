@@ -65,11 +65,15 @@ class Cell(nn.Module):
     _norm_masks = {}                  # (edge kinds, device) -> bool [edges, 1] constant
 
     def _node_mixes(self, weights_norm, weights_chg, betas):
+        """This cell's slot of the mixing table (cells of different lanes never share one)."""
+        return self._mix_slots(weights_norm, weights_chg, betas).take()
+
+    def _mix_slots(self, weights_norm, weights_chg, betas):
         """Per node, the concatenated ``beta_j * alpha_row_j`` of its incoming edges (search/cell.py:100-106), as rows
         of ONE matrix per cell kind (functional._EdgeMix).  They depend on the architecture tensors and the cell KIND
         only, so all cells of a kind share them within a forward pass: the matrix is parked on the ``betas`` tensor
         (fresh softmax outputs every pass, so nothing goes stale) and the nodes of all those cells accumulate their
-        d loss / d mix into one buffer -- a handful of tiny launches per kind and pass instead of ~10 per cell."""
+        d loss / d mix into one table (a slot per cell) -- a handful of tiny launches per kind and pass instead of ~10 per cell."""
         kinds = tuple(edge._op_type == OpType.NORM for edge in self._ops)
         key = (id(weights_norm), id(weights_chg), kinds)
         cache = betas.__dict__.setdefault('_senas_mix', {}) if hasattr(betas, '__dict__') else {}
@@ -78,14 +82,9 @@ class Cell(nn.Module):
             if mkey not in Cell._norm_masks:
                 Cell._norm_masks[mkey] = torch.tensor(kinds, device=betas.device).unsqueeze(1)
             nops = weights_norm.shape[1]
-            dM = torch.zeros((len(kinds), nops), device=betas.device, dtype=torch.float32)
+            dM = torch.zeros((F.MIX_SLOTS, len(kinds), nops), device=betas.device, dtype=torch.float32)
             M = F._EdgeMix.apply(weights_norm, weights_chg, betas, Cell._norm_masks[mkey], dM)
-            mixes, offset = [], 0
-            for i in range(self._meta_node_num):
-                cnt = self._input_num + i
-                mixes.append(F.SharedMix(M, offset * nops, cnt * nops, dM))
-                offset += cnt
-            cache[key] = mixes
+            cache[key] = F.MixSlots(M, dM, [self._input_num + i for i in range(self._meta_node_num)])
         return cache[key]
 
     # ------------------------------------------------------------------ state-major execution

@@ -20,12 +20,13 @@ struct ArchMix {            // = senas_arch_mix
     float* s_beta[2];
     float* s_gamma;
     float* M[2];            // dn, up: [k][ops]
-    const float* dM[2];     // backward: accumulated d loss / d M
+    const float* dM[2];     // backward: accumulated d loss / d M, [slots][k][ops] -- one slot per cell of the kind
     const double* dG;       // backward: accumulated d loss / d softmax(gamma)  [grows][2]
     float* d_alpha[4];      // backward outputs (d_alpha[3] == nullptr: up_nm IS dn_nm, its gradient is added to d_alpha[2])
     float* d_beta[2];
     float* d_gamma;
     int k, ops, nodes, grows;
+    int slots;              // backward: rows of dM[kind] (the cells of a kind run on several streams: each adds into its own)
 };
 
 __device__ __forceinline__ bool edge_is_norm(int kind, int j) { return kind == 0 ? j >= 2 : j != 1; }
@@ -82,7 +83,16 @@ __global__ __launch_bounds__(256) void arch_mix_fwd_kernel(ArchMix a) {
 
 __global__ __launch_bounds__(256) void arch_mix_bwd_kernel(ArchMix a) {
     __shared__ float dbs[2][64];          // d loss / d beta_soft
+    __shared__ float dMs[2][60 * 16];     // d loss / d M per kind: the cells' slots folded in slot order (fixed: bitwise reproducible)
     const int t = threadIdx.x;
+    const int ko = a.k * a.ops;
+    for (int i = t; i < 2 * ko; i += 256) {
+        const int kind = i / ko, idx = i % ko;
+        float s = 0.f;
+        for (int q = 0; q < a.slots; ++q) s += a.dM[kind][(size_t)q * ko + idx];
+        dMs[kind][idx] = s;
+    }
+    __syncthreads();
     // per (kind, edge): d beta_soft, and the softmax backward of the alpha row the edge reads; the other table's row gets 0
     if (t < 2 * a.k) {
         const int kind = t / a.k, e = t % a.k;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void arch_mix_bwd_kernel(ArchMix a) {
         const bool norm = edge_is_norm(kind, j);
         const int used = norm ? 2 + kind : kind, other = norm ? kind : 2 + kind;
         const float* S = a.s_alpha[used] + (size_t)e * a.ops;
-        const float* dM = a.dM[kind] + (size_t)e * a.ops;
+        const float* dM = dMs[kind] + e * a.ops;
         const float bs = a.s_beta[kind][e];
         float db = 0.f, dot = 0.f;
         for (int o = 0; o < a.ops; ++o) { db = fmaf(dM[o], S[o], db); dot = fmaf(dM[o] * bs, S[o], dot); }
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void arch_mix_bwd_kernel(ArchMix a) {
         for (int o = 0; o < a.ops; ++o) acc[o] = 0.f;
         for (int kind = 0; kind < 2; ++kind) {
             if (!edge_is_norm(kind, j)) continue;
-            const float* dM = a.dM[kind] + (size_t)e * a.ops;
+            const float* dM = dMs[kind] + e * a.ops;
             const float bs = a.s_beta[kind][e];
             float dot = 0.f;
             for (int o = 0; o < a.ops; ++o) dot = fmaf(dM[o] * bs, S[o], dot);
@@ -164,6 +174,7 @@ static bool arch_mix_ok(const senas_arch_mix* a, bool bwd) {
     if (bwd) {
         for (int i = 0; i < 3; ++i) if (!a->d_alpha[i]) return false;
         for (int i = 0; i < 2; ++i) if (!a->dM[i] || !a->d_beta[i]) return false;
+        if (a->slots < 1 || a->slots > 256) return false;
         if (a->grows > 0 && (!a->dG || !a->d_gamma)) return false;
     }
     return true;

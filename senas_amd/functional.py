@@ -204,6 +204,32 @@ def flush_deferred(reopen=False):
         _lib.check(L.senas_wgrad_sum_batched(arr, len(chunk), _stream()), 'senas_wgrad_sum_batched')
 
 
+# HIP streams that carry part of the pass in flight besides the caller's: the macro grid runs every column of up cells on a
+# stream of its own (senas_amd.grid.Lanes), and autograd replays every node's backward pass on the stream its forward pass ran
+# on.  Whatever reads a table that kernels of several lanes ADD into (the mixing-weight gradients, the gamma table, the flat
+# gradient buffer at the end of backward) joins them first.
+LANES = set()
+MIX_SLOTS = 32          # rows of a d loss / d M table: one per cell of a kind within a pass (cells of different lanes never share one)
+
+
+def join_lanes():
+    """Make the current stream wait for everything launched so far on the lanes of the running pass."""
+    if not LANES:
+        return
+    cur = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
+    for s in LANES:
+        if s == cur or s.device != cur.device:
+            continue
+        if capturing:
+            # a lane that is not part of this capture holds nothing of this pass (and waiting for it would tie the graph to
+            # work outside the capture)
+            with torch.cuda.stream(s):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        cur.wait_stream(s)
+
+
 def wgrad_dest(w):
     """Where a backward kernel writes d loss / d w, and what autograd is handed for it: the parameter's view in the
     flat gradient buffer and None (first gradient of the pass under a step driver), or a fresh tensor twice."""
@@ -689,6 +715,7 @@ class _GammaRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (acc,) = ctx.saved_tensors
+        join_lanes()                              # the blends of every lane have added into acc
         d = acc.float()
         return (d if g is None else d + g), None
 
@@ -736,8 +763,9 @@ class _EdgeMix(torch.autograd.Function):
     """M[e][k] = beta[e] * (w_norm[e][k] if edge e is a NORM edge else w_chg[e][k]) for all edges of a cell kind at once
     (search/cell.py:33-36,100-106: every MixedOp scales its candidates by its alpha row, every node scales the edge by
     beta).  The cells of one kind share M within a forward pass; their nodes read their rows of it in place and ADD
-    d loss / d M into the zero-filled ``dM`` in stream order (senas_node_bwd, dmix_accumulate), which this backward pass turns into the
-    three gradients -- a handful of tiny launches per pass instead of ~10 per cell."""
+    d loss / d M into the zero-filled ``dM`` (senas_node_bwd, dmix_accumulate: every cell into its own slot, the nodes of one
+    cell in stream order), which this backward pass turns into the three gradients -- a handful of tiny launches per pass
+    instead of ~10 per cell."""
 
     @staticmethod
     def forward(ctx, w_norm, w_chg, betas, is_norm, dM):
@@ -750,6 +778,8 @@ class _EdgeMix(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gM):
         W, betas, is_norm, dM = ctx.saved_tensors
+        join_lanes()                              # the nodes of every lane have added into their cell's slot of dM
+        dM = dM.sum(0) if dM.dim() == 3 else dM
         g = dM if gM is None else dM + gM
         dW = g * betas.unsqueeze(1)
         zero = torch.zeros((), device=g.device, dtype=g.dtype)
@@ -812,6 +842,8 @@ class _ArchMix(torch.autograd.Function):
         a.dM[0], a.dM[1], a.dG = dM_dn.data_ptr(), dM_up.data_ptr(), dG.data_ptr()
         a.gamma, a.s_gamma, a.d_gamma = params[6].data_ptr(), soft[6].data_ptr(), dests[6].data_ptr()
         a.k, a.ops, a.nodes, a.grows = k, ops, ctx.nodes, params[6].shape[0]
+        a.slots = dM_dn.shape[0]
+        join_lanes()                              # nodes and blends of every lane have added into dM / dG
         _lib.check(_lib.lib().senas_arch_mix_bwd(C.byref(a), _stream()), 'senas_arch_mix_bwd')
         return (None, None, None, None) + tuple(outs)
 
@@ -824,7 +856,7 @@ class ArchTables(object):
     def __init__(self, nodes, a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma):
         k, ops = a_dn.shape
         dev_ = a_dn.device
-        dM = [zeros32(k * ops, dev_).view(k, ops) for _ in range(2)]
+        dM = [zeros32(MIX_SLOTS * k * ops, dev_).view(MIX_SLOTS, k, ops) for _ in range(2)]
         dG = zeros64(tuple(gamma.shape), dev_)
         out = _ArchMix.apply(nodes, dM[0], dM[1], dG, a_dn, a_up, a_dn_nm, a_up_nm, b_dn, b_up, gamma)
         M_dn, M_up, s_gamma = out[:3]
@@ -834,13 +866,8 @@ class ArchTables(object):
         rows.table, rows.acc = s_gamma, dG
         s_gamma._senas_rows = rows
         for kind, (M, bs, w_norm, w_chg) in enumerate(((M_dn, self.bs_dn, self.s_dn_nm, self.s_dn), (M_up, self.bs_up, self.s_up_nm, self.s_up))):
-            kinds, mixes, offset = [], [], 0
-            for i in range(nodes):
-                cnt = 2 + i
-                kinds += [(j >= 2) if kind == 0 else (j != 1) for j in range(cnt)]
-                mixes.append(SharedMix(M, offset * ops, cnt * ops, dM[kind]))
-                offset += cnt
-            bs._senas_mix = {(id(w_norm), id(w_chg), tuple(kinds)): mixes}
+            kinds = [(j >= 2) if kind == 0 else (j != 1) for i in range(nodes) for j in range(2 + i)]
+            bs._senas_mix = {(id(w_norm), id(w_chg), tuple(kinds)): MixSlots(M, dM[kind], [2 + i for i in range(nodes)])}
 
     def args(self):
         """(alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma) as SenasSearch.forward takes them."""
@@ -849,11 +876,34 @@ class ArchTables(object):
 
 class SharedMix(object):
     """Rows [off, off + rows) of an _EdgeMix matrix as the mixing weights of one node: ``M`` (for autograd ordering and
-    the kernel's read), the flat offset / length of the node's weights in it, and the accumulation buffer ``dM``."""
+    the kernel's read), the flat offset / length of the node's weights in it, and the accumulation buffer ``dM`` (the [k][ops]
+    slot of the node's cell)."""
     __slots__ = ('M', 'off', 'count', 'dM')
 
     def __init__(self, M, off, count, dM):
         self.M, self.off, self.count, self.dM = M, off, count, dM
+
+
+class MixSlots(object):
+    """The mixing matrix of a cell kind for one pass and its gradient table ``dM`` [MIX_SLOTS][k][ops].  Every cell forward
+    takes the next slot (host order, so the assignment is the same on every pass and rank): the nodes of a cell add their
+    d loss / d mix into the cell's own rows, cells on different lanes never write the same address, and the fold over the
+    slots runs in slot order (bitwise reproducible)."""
+
+    def __init__(self, M, dM, counts):
+        self.M, self.dM, self.counts, self.taken = M, dM, counts, 0
+
+    def take(self):
+        if self.taken >= self.dM.shape[0]:
+            raise SenasHipError('more than %d cells of one kind in a pass (functional.MIX_SLOTS)' % self.dM.shape[0])
+        row = self.dM[self.taken]
+        self.taken += 1
+        ops = self.dM.shape[2]
+        mixes, offset = [], 0
+        for cnt in self.counts:
+            mixes.append(SharedMix(self.M, offset * ops, cnt * ops, row))
+            offset += cnt
+        return mixes
 
 
 class _FanOut(torch.autograd.Function):
@@ -909,6 +959,32 @@ class _FanOut(torch.autograd.Function):
         for g in rest:                                    # odd layouts: let torch add them
             out = g if out is None else out + g
         return out, None
+
+
+class _Hop(torch.autograd.Function):
+    """An alias of x behind an autograd node of the CURRENT stream.  Autograd replays a node on the stream its forward pass
+    ran on and makes that stream wait for the producer of every gradient it receives: a tensor that goes from one lane of
+    the macro grid to another passes a hop made on the caller's stream, so that on the way back, too, lanes only ever wait
+    for that stream and only that stream waits for lanes (senas_amd.grid.Lanes: the star topology the HIP runtime's
+    capture bookkeeping needs)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def hop(x):
+    if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        return x
+    y = _Hop.apply(x)
+    st = getattr(x, '_senas_stats', None)
+    if st is not None:
+        y._senas_stats = st
+    return y
 
 
 def fan_out(x, n):

@@ -7,6 +7,9 @@ as in1 the output at position i+j, and overwrites position i+j.
 Reference: search/senas_search.py:16-112 and models/senas_model.py:78-179 build and walk the same
 grid; here the bookkeeping lives in one place.
 """
+import contextlib
+
+import torch
 import torch.nn as nn
 
 from .operations import ConvBn, Stem1
@@ -47,6 +50,119 @@ class FanPlan(object):
         fresh = FanPlan()                 # (the aliases of the last pass are not part of a copied model)
         fresh.counts, fresh.dry = dict(self.counts), self.dry
         return fresh
+
+
+class NoPlan(object):
+    """The FanPlan interface without aliases: every reader takes the tensor itself and autograd accumulates (the two-part
+    backward of a multi-rank step re-leafs tensors in the middle of the schedule, which aliases made earlier would miss)."""
+    dry = False
+
+    def put(self, key, value=None):
+        return value
+
+    def get(self, key):
+        return key
+
+
+class Lanes(object):
+    """The macro grid on several HIP streams: one lane per column of up cells.
+
+    Up cell (i, j) reads the outputs of the cells below it in ITS column (levels < i) and the output of cell (i-1, j+1):
+    the columns are chains that meet along the diagonals, and the six small-map cells of a depth-5 grid (64 x 64 ... 16 x 16
+    maps: kernels of a few blocks each, bound by launch latency) can run under the four 128 x 128 cells of column 0 instead of
+    in front of them.  Lane j is an ordinary stream; ``on(j)`` makes it torch's current stream, so every kernel of the cell --
+    and, through autograd's stream rule, every kernel of the cell's backward pass -- is launched on it.  Inside a HIP-graph
+    capture the waits become the fork / join edges of the graph.  The reference walks the same cells one after the other
+    (search/senas_search.py:96-107, models/senas_model.py:160-175); the outputs are functions of the inputs, so any schedule
+    that respects the data flow gives its results.
+
+    **Star topology, and why.**  Lanes only ever wait for events recorded on the caller's stream ("main": stems, down path,
+    head -- under capture the ORIGIN stream of the capture), and only main waits for lane events.  A tensor that goes from
+    lane a to lane b is handed over THROUGH main: main waits for a's event, the tensor passes an identity autograd node made
+    on main (functional.hop), b waits for main's event -- and autograd, which replays every node on its forward stream and
+    synchronises producer and consumer streams itself, then does the same in the other direction on the way back.  The HIP
+    runtime under this torch build (ROCm 7.0 libamdhip64) keeps, for every stream of a capture, the list of streams that
+    waited on one of its events, and ``hip::Stream::EndCapture()`` walks those lists recursively before clearing them; only
+    the origin stream is never entered in a list.  Lane j waiting on lane j+1 in the forward pass and lane j+1 on lane j in
+    the backward pass makes the lists cyclic, and hipStreamEndCapture recurses until the stack is gone (measured:
+    profiles/r4_endcapture_recursion.txt -- 174 575 frames of hip::Stream::EndCapture).  Main records no kernel between two
+    hand-overs, so a hand-over also waits for the producers of the earlier ones (the order of the schedule below keeps that
+    harmless)."""
+
+    enabled = True          # class-wide switch (False: every cell on the caller's stream, as the reference's loop)
+    _pool = {}              # device index -> streams
+
+    def __init__(self, device, columns):
+        from . import functional as F
+        self.F = F
+        self.main = torch.cuda.current_stream(device)
+        pool = Lanes._pool.setdefault(device.index, [])
+        while len(pool) < columns:
+            pool.append(torch.cuda.Stream(device))
+        self.streams = pool[:columns]
+        self.events = {}
+        self.used = []
+
+    def mark(self, key):
+        """``key`` is produced by what the current stream holds so far."""
+        s = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(s)
+        self.events[key] = (ev, s)
+
+    def lane(self, j):
+        s = self.streams[j]
+        if s not in self.used:
+            self.used.append(s)
+            self.F.LANES.add(s)
+        return s
+
+    def after(self, j, keys):
+        """Lane j waits for the producers of ``keys`` that ran on main (for those of other lanes: ``hand``)."""
+        s = self.lane(j)
+        for key in keys:
+            ev, src = self.events[key]
+            if src == self.main:
+                s.wait_event(ev)
+            elif src != s:
+                raise RuntimeError('lane %d may not wait for another lane directly (grid.Lanes)' % j)
+
+    def hand(self, t, key, j):
+        """Tensor ``t``, produced under ``key`` on another lane, for a reader on lane j: through main (see the class text)."""
+        ev, src = self.events[key]
+        s = self.lane(j)
+        if src == s:
+            return t
+        if src != self.main:
+            self.main.wait_event(ev)
+            with torch.cuda.stream(self.main):
+                t = self.F.hop(t)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        s.wait_event(ev)
+        return t
+
+    @contextlib.contextmanager
+    def on(self, j):
+        with torch.cuda.stream(self.lane(j)):
+            yield
+
+    @staticmethod
+    def take(t):
+        """A tensor made on another stream is read on the current one: tell the caching allocator, which otherwise hands the
+        block to the next allocation of the PRODUCER's stream as soon as the last reference dies, ordered or not."""
+        if t is not None and t.is_cuda:
+            s = torch.cuda.current_stream()
+            t.record_stream(s)
+            st = getattr(t, '_senas_stats', None)
+            if st is not None:
+                st.record_stream(s)
+        return t
+
+    def join(self):
+        """The caller's stream waits for every lane."""
+        for s in self.used:
+            self.main.wait_stream(s)
 
 
 def gamma_index(i, j):
@@ -90,7 +206,8 @@ class MacroGrid(nn.Module):
             widths.append(wrow)
         self.head_block = nn.ModuleList([make_head(c, widths[-1][0], nclass)])
         # step drivers may cut the autograd graph at the outputs of the down path (senas_amd.step: backward is then run
-        # -- and captured -- in two parts, so that the up-path gradients are all-reduced while the rest still runs)
+        # -- and captured -- in two parts, so that the up-path gradients are all-reduced while the rest still runs):
+        # cut(tensor) -> the leaf the up path reads in its place
         self.cut = None
 
     def down_parameters(self):
@@ -103,9 +220,83 @@ class MacroGrid(nn.Module):
                     out.append(p)
         return out
 
-    def _down_done(self, s0, outs):
-        """Called by the subclasses' forward with the stem output and the down-path outputs."""
-        if self.cut is None:
-            return s0, outs
-        cut = self.cut([s0] + list(outs))
-        return cut[0], list(cut[1:])
+    def _walk_grid(self, plan, x, run, skips):
+        """The forward schedule of both networks against a FanPlan / NoPlan: dry (``x is None``: count the readers of every
+        tensor) or live.  ``run(module, kind, a, b)`` applies a cell or the head; ``skips(plan, G, i, j, live)`` returns the
+        list of tensors whose concatenation is in0 of up cell (i, j) (and takes its readers from ``plan``).  G[i][j]: output
+        of grid slot (i, j) -- level 0 is the down path.
+
+        Order: down cell j + 1 is followed at once by up cell (1, j), which needs nothing else; then the levels 2, 3, ... with
+        j ascending.  With ``Lanes.enabled`` column j of the up cells runs on lane j.  The order matters beyond the data flow:
+        autograd replays the nodes in reverse creation order and makes a consumer's STREAM wait when a gradient is handed
+        over, so whatever the host launches later on that stream waits too -- with this order the backward pass of down cell
+        j + 1 is launched after that of up cell (1, j) and before that of (1, j - 1), and waits for exactly what it needs."""
+        live = x is not None
+        depth = self._depth
+        lanes = Lanes(x.device, depth - 1) if (live and Lanes.enabled and x.is_cuda and depth > 2) else None
+        cut = self.cut if live else None
+        G = [[None] * (depth - i) for i in range(depth)]
+
+        def up_cell(i, j):
+            cell = self.blocks[i][j]
+            if cell is None:                                   # pruned skip cell of a derived network
+                return
+            if G[i - 1][j + 1] is None:
+                raise TypeError('up cell (%d, %d) is alive but its input cell (%d, %d) is pruned' % (i, j, i - 1, j + 1))
+            in1 = plan.get(G[i - 1][j + 1])
+            if lanes is None:
+                ins = skips(plan, G, i, j, live)
+                y = run(cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), in1) if live else None
+                G[i][j] = plan.put(('o', i, j), y)
+                return
+            lanes.after(j, [(0, j)])
+            in1 = lanes.hand(in1, (i - 1, j + 1), j)
+            with lanes.on(j):
+                ins = [Lanes.take(t) for t in skips(plan, G, i, j, live)]
+                y = run(cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), Lanes.take(in1))
+                G[i][j] = plan.put(('o', i, j), y)
+                lanes.mark((i, j))
+
+        def cut_here(t):
+            # the two-part backward of a multi-rank step (senas_amd.step) re-leafs the down-path outputs: what the up path
+            # reads is the leaf, behind an identity node made on THIS stream (the leaf's gradient is then accumulated here,
+            # whichever lanes its readers run on)
+            if cut is None:
+                return t
+            from . import functional as F
+            return F.hop(cut(t))
+
+        s0 = plan.put('s0', self.stem0(x) if live else None)
+        first = plan.get(s0)
+        D = [plan.put(('o', 0, 0), self.stem1(first) if live else None)]             # the down path as the down path reads it
+        G[0][0] = cut_here(D[0])
+        if lanes is not None:
+            lanes.mark((0, 0))
+        for j in range(1, depth):
+            a, b = plan.get(s0 if j == 1 else D[j - 2]), plan.get(D[j - 1])
+            D.append(plan.put(('o', 0, j), run(self.blocks[0][j], 'down', a, b) if live else None))
+            G[0][j] = cut_here(D[j])
+            if lanes is not None:
+                lanes.mark((0, j))
+            up_cell(1, j - 1)
+        s0 = cut_here(s0)
+        for i in range(2, depth):
+            for j in range(depth - i):
+                up_cell(i, j)
+        if lanes is not None:
+            lanes.join()
+        head = self.head_block[-1]
+        tails = [G[m][0] for m in range(depth)] if self._supervision else [G[depth - 1][0]]
+        self._check_tails(tails)
+        res = []
+        for o in tails:
+            a, b = plan.get(s0), plan.get(o)
+            if lanes is not None:
+                Lanes.take(b)                                  # made on lane 0, read here
+            res.append(run(head, 'head', a, b) if live else None)
+        return res
+
+    def _check_tails(self, tails):
+        if any(o is None for o in tails):
+            raise TypeError('deep supervision needs every grid column alive; this genotype prunes some '
+                            '(the reference fails the same way, models/senas_model.py:177)')

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
-from .grid import FanPlan, MacroGrid, gamma_index
+from .grid import FanPlan, MacroGrid, NoPlan, gamma_index
 from .operations import OPS, OpType, RectifyBlock, ReLUConv, ShrinkBlock, build_activation, build_rectify
 
 
@@ -141,65 +141,21 @@ class SenasModel(MacroGrid):
         self.gamma = gamma
 
     def forward(self, x):
-        if self.cut is not None:              # two-part backward (several ranks): the cut tensors are re-leafed, keep it simple
-            return self._forward_plain(x)
+        if self.cut is not None:              # two-part backward (several ranks): the cut tensors are re-leafed, no aliases
+            return self._walk(NoPlan(), x)
         plan = self.__dict__.get('_fan_plan')
         if plan is None:                      # dry run of the schedule: how many readers every tensor has (grid.FanPlan)
             plan = self.__dict__['_fan_plan'] = FanPlan()
             self._walk(plan, None)
         return self._walk(plan.start(), x)
 
-    def _check_tails(self, tails):
-        if any(o is None for o in tails):
-            raise TypeError('deep supervision needs every grid column alive; this genotype prunes some '
-                            '(the reference fails the same way, models/senas_model.py:177)')
-
     def _walk(self, plan, x):
-        """The forward schedule (models/senas_model.py:150-179) against a FanPlan: dry (x is None: count readers) or live."""
-        live = x is not None
-        depth = self._depth
-        s0 = plan.put('s0', self.stem0(x) if live else None)
-        first = plan.get(s0)
-        outs = [plan.put(('o', 0, 0), self.stem1(first) if live else None)]
-        ver = [0] * depth
-        for j in range(1, depth):
-            a, b = plan.get(s0 if j == 1 else outs[j - 2]), plan.get(outs[j - 1])
-            outs.append(plan.put(('o', j, 0), self.blocks[0][j](a, b) if live else None))
-        for j in reversed(range(depth - 1)):
-            for i in range(1, depth - j):
-                cell = self.blocks[i][j]
-                if cell is None:
-                    outs[i + j] = None
-                    continue
-                skips = [plan.get(outs[t]) for t in range(j, i + j) if outs[t] is not None]
-                in1 = plan.get(outs[i + j])
-                ver[i + j] += 1
-                y = cell(skips[0] if len(skips) == 1 else torch.cat(skips, dim=1), in1) if live else None
-                outs[i + j] = plan.put(('o', i + j, ver[i + j]), y)
-        head = self.head_block[-1]
-        tails = outs if self._supervision else outs[-1:]
-        self._check_tails(tails)
-        res = []
-        for o in tails:
-            a, b = plan.get(s0), plan.get(o)
-            res.append(head(a, b) if live else None)
-        return res
+        """The reference's forward pass (models/senas_model.py:150-179) on the shared schedule (grid.MacroGrid._walk_grid):
+        in0 of up cell (i, j) is the concatenation of the column's outputs below it that the genotype keeps (:165-170)."""
+        def run(module, kind, a, b):
+            return module(a, b)
 
-    def _forward_plain(self, x):
-        s0 = self.stem0(x)
-        outs = [self.stem1(s0)]
-        for j in range(1, self._depth):
-            outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1]))
-        s0, outs = self._down_done(s0, outs)
-        for j in reversed(range(self._depth - 1)):
-            for i in range(1, self._depth - j):
-                cell = self.blocks[i][j]
-                if cell is None:
-                    outs[i + j] = None
-                    continue
-                skips = [outs[t] for t in range(j, i + j) if outs[t] is not None]
-                outs[i + j] = cell(skips[0] if len(skips) == 1 else torch.cat(skips, dim=1), outs[i + j])
-        head = self.head_block[-1]
-        tails = outs if self._supervision else outs[-1:]
-        self._check_tails(tails)
-        return [head(s0, o) for o in tails]
+        def skips(plan, G, i, j, live):
+            return [plan.get(G[k][j]) for k in range(i) if G[k][j] is not None]
+
+        return self._walk_grid(plan, x, run, skips)

@@ -10,7 +10,7 @@ import torch.nn.functional as tf
 from . import functional as F
 from .cell import Cell
 from .genotype import GenoParser, Genotype
-from .grid import FanPlan, MacroGrid, gamma_index
+from .grid import FanPlan, MacroGrid, NoPlan, gamma_index
 from .operations import DownOps, NormOps, ReLUConv, UpOps
 from .utils import weights_init
 
@@ -35,61 +35,41 @@ class SenasSearch(MacroGrid):
         self._meta_node_num = meta_node_num
 
     def forward(self, x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma):
-        if self.cut is not None:              # two-part backward (several ranks): the cut tensors are re-leafed, keep it simple
-            return self._forward_plain(x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma)
+        arch = (alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma)
+        if self.cut is not None:              # two-part backward (several ranks): the cut tensors are re-leafed, no aliases
+            return self._walk(NoPlan(), x, arch)
         plan = self.__dict__.get('_fan_plan')
         if plan is None:                      # dry run of the schedule below: how many readers every tensor has
             plan = self.__dict__['_fan_plan'] = FanPlan()
             self._walk(plan, None, None)
-        return self._walk(plan.start(), x, (alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma))
+        return self._walk(plan.start(), x, arch)
 
     def _walk(self, plan, x, arch):
-        """The forward schedule (search/senas_search.py:96-107) against a FanPlan: dry (x is None: count readers) or live."""
-        live = x is not None
-        if live:
+        """The reference's forward pass (search/senas_search.py:96-107) on the shared schedule (grid.MacroGrid._walk_grid):
+        in0 of up cell (i, j) is the concatenation of the column's down-path output and the gamma-gated blends of
+        neighbouring outputs below it in the column (:98-102)."""
+        rows = None
+        if x is not None:
             alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma = arch
             rows = getattr(gamma, '_senas_rows', None) or F.GammaRows(gamma)      # the blends read their gamma pair in place
-        depth = self._depth
-        s0 = plan.put('s0', self.stem0(x) if live else None)
-        outs = [plan.put(('o', 0, 0), self.stem1(plan.get(s0)) if live else (plan.get(s0), None)[1])]
-        ver = [0] * depth
-        for j in range(1, depth):
-            a, b = plan.get(s0 if j == 1 else outs[j - 2]), plan.get(outs[j - 1])
-            outs.append(plan.put(('o', j, 0), self.blocks[0][j](a, b, alpha_dn_nm, alpha_dn, beta_dn) if live else None))
-        for j in reversed(range(depth - 1)):
-            for i in range(1, depth - j):
-                skips = [plan.get(outs[j])]
-                for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
-                    a, b = plan.get(outs[j + k - 1]), plan.get(outs[j + k])
-                    skips.append(F.blend2_row(a, b, rows, gamma_index(k, j)) if live else None)
-                in1 = plan.get(outs[i + j])
-                ver[i + j] += 1
-                y = self.blocks[i][j](skips[0] if len(skips) == 1 else torch.cat(skips, dim=1), in1, alpha_up_nm, alpha_up, beta_up) if live else None
-                outs[i + j] = plan.put(('o', i + j, ver[i + j]), y)
-        head = self.head_block[-1]
-        tails = outs if self._supervision else outs[-1:]
-        res = []
-        for o in tails:
-            a, b = plan.get(s0), plan.get(o)
-            res.append(head(a, b, alpha_up_nm, alpha_up, beta_up) if live else None)
-        return res
+            args = {'down': (alpha_dn_nm, alpha_dn, beta_dn), 'up': (alpha_up_nm, alpha_up, beta_up),
+                    'head': (alpha_up_nm, alpha_up, beta_up)}
+            # the mixing matrices of both cell kinds are made HERE, on the caller's stream (not by the first cell that asks,
+            # on its lane): their backward nodes wait for every lane (functional.join_lanes), which only this stream may do
+            self.blocks[0][1]._mix_slots(*args['down'])
+            self.head_block[-1].up_cell._mix_slots(*args['up'])
 
-    def _forward_plain(self, x, alpha_dn_nm, alpha_up_nm, alpha_dn, alpha_up, beta_dn, beta_up, gamma):
-        s0 = self.stem0(x)
-        outs = [self.stem1(s0)]
-        for j in range(1, self._depth):
-            outs.append(self.blocks[0][j](s0 if j == 1 else outs[-2], outs[-1], alpha_dn_nm, alpha_dn, beta_dn))
-        s0, outs = self._down_done(s0, outs)
-        rows = getattr(gamma, '_senas_rows', None) or F.GammaRows(gamma)      # the blends read their gamma pair in place
-        for j in reversed(range(self._depth - 1)):
-            for i in range(1, self._depth - j):
-                skips = [outs[j]]
-                for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
-                    skips.append(F.blend2_row(outs[j + k - 1], outs[j + k], rows, gamma_index(k, j)))
-                outs[i + j] = self.blocks[i][j](torch.cat(skips, dim=1), outs[i + j], alpha_up_nm, alpha_up, beta_up)
-        head = self.head_block[-1]
-        tails = outs if self._supervision else outs[-1:]
-        return [head(s0, o, alpha_up_nm, alpha_up, beta_up) for o in tails]
+        def run(module, kind, a, b):
+            return module(a, b, *args[kind])
+
+        def skips(plan, G, i, j, live):
+            out = [plan.get(G[0][j])]
+            for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
+                a, b = plan.get(G[k - 1][j]), plan.get(G[k][j])
+                out.append(F.blend2_row(a, b, rows, gamma_index(k, j)) if live else None)
+            return out
+
+        return self._walk_grid(plan, x, run, skips)
 
 
 def _node_softmax(beta, nodes):

@@ -87,11 +87,12 @@ class GraphedForwardBackward(object):
             p.requires_grad_(False)
         cut = self.early is not None
         if cut:
-            self._cut_src = self._cut_leaf = None
+            self._cut_src, self._cut_leaf = [], []
             self.grid.cut = self._cut
         try:
             loss = self.criterion(self.model(self.x), self.y)
             loss.backward()
+            F.join_lanes()                # the macro grid's columns ran on their own streams (grid.Lanes): the flat gradient buffer is complete after this
         finally:
             if cut:
                 self.grid.cut = None
@@ -101,10 +102,16 @@ class GraphedForwardBackward(object):
         self.reducer.after_backward()
         return loss.detach()
 
-    def _cut(self, tensors):
-        self._cut_src = [t for t in tensors if t.requires_grad]
-        self._cut_leaf = [t.detach().requires_grad_(t.requires_grad) for t in tensors]
-        return self._cut_leaf
+    def _cut(self, t):
+        """grid.MacroGrid.cut: one tensor of the down path (the stem output, a down cell's output) -> the leaf the up path reads."""
+        leaf = t.detach().requires_grad_(t.requires_grad)
+        st = getattr(t, '_senas_stats', None)
+        if st is not None:
+            leaf._senas_stats = st
+        if t.requires_grad:
+            self._cut_src.append(t)
+        self._cut_leaf.append(leaf)
+        return leaf
 
     def _tail(self):
         """The rest of backward below the cut."""
@@ -114,6 +121,7 @@ class GraphedForwardBackward(object):
             pairs = [(s, l.grad) for s, l in zip(self._cut_src, leaves) if l.grad is not None]
             if pairs:
                 torch.autograd.backward([s for s, _ in pairs], [g for _, g in pairs])
+            F.join_lanes()
         finally:
             self._cut_src = self._cut_leaf = None
             for p in self.frozen:

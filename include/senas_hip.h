@@ -212,6 +212,27 @@ int senas_bilinear2x_bwd(int n, int h, int w, int c, const float* dy, float* dx,
 int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* const* dst, double* const* stats,
                       void* stream);
 
+/* ---- lane scheduler: a captured multi-stream HIP graph replayed as linear segments on streams of its own ---------------
+ * Replaces the runtime's executor for the step drivers' captured passes (senas_amd/step.py; why: csrc/sched.hip).  The
+ * reference has no counterpart -- its step loop launches eagerly (experiments/train_model.py:264-305, search_arc.py:252-299).
+ * hip_graph: a captured, NOT instantiated hipGraph_t that outlives the scheduler (kernel / memset / memcpy / empty nodes only,
+ * else SENAS_EUNSUPPORTED).  max_lanes: streams the pieces are spread over, 1..16 (lane 0 is the `stream` given at launch).
+ * senas_sched_launch enqueues one replay: the lanes wait for `stream`, and `stream` waits for the lanes at the end, so
+ * successive launches on one stream are ordered like ordinary graph launches.  Not thread-safe per scheduler.
+ * senas_sched_info: out8 = {nodes run, lanes used, segments, cross-lane dependencies, kernel, memset, memcpy nodes, nodes
+ * contracted away (empty nodes and relay markers)}.
+ * senas_relay_marker: an empty kernel launched on the capture's origin stream at every hand-over between two lanes; the
+ * scheduler cuts the false marker -> marker chain the capture records and contracts the markers away (csrc/sched.hip).  */
+int senas_relay_marker(void* stream);
+int senas_sched_create(void* hip_graph, int max_lanes, void** out);
+int senas_sched_launch(void* sched, void* stream);
+int senas_sched_info(void* sched, int32_t* out8);
+void senas_sched_destroy(void* sched);
+
+/* ---- time stamp in stream order (measurement only: tools/lane_timeline.py) ------------------------------------------
+ * *slot = the device's constant-rate wall clock (100 MHz ticks) when the stream reaches this launch.                   */
+int senas_stamp(uint64_t* slot, void* stream);
+
 /* ---- elementwise ReLU (Cell.preprocess1, search/cell.py:66,94; senas_model.py:15,52) ---------- */
 int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream);
 int senas_relu_bwd(int64_t numel, const float* dy, const float* y, float* dx, void* stream);

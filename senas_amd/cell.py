@@ -354,7 +354,7 @@ class Cell(nn.Module):
             offset += nin + i
             cat = None
             ref = next((t.z for t in node_terms if t.z is not None), None)
-            if ref is not None and self._post_padded(ref.shape[1] * nodes) and (catbuf is not None or i == 0):
+            if ref is not None and ref.shape[1] % 4 == 0 and self._post_padded(ref.shape[1] * nodes) and (catbuf is not None or i == 0):
                 n, c, h, w = ref.shape
                 if catbuf is None:
                     catbuf, c_cat = F.new_nhwc(n, 32, h, w, ref), c

@@ -1,0 +1,348 @@
+// Lane scheduler: replays a CAPTURED multi-stream HIP graph as linear segments on streams of its own.
+//
+// Why this exists.  The step drivers capture forward + backward of a network whose macro-grid columns run on several HIP
+// streams (senas_amd/grid.py: Lanes), so the captured graph is a DAG with ~5 branches in flight.  The runtime's own graph
+// executor (ROCm 7.0 libamdhip64 under this torch build) does not run such a DAG well: it re-derives a node -> stream
+// assignment of its own by a depth-first walk, in which every branch forked off the origin stream lands on the same
+// internal stream (measured: 2 graph queues give the same step time as 8), and `hip::Graph::UpdateStreams` indexes its
+// stream table out of bounds for some fork / join shapes (SIGSEGV inside hipGraphLaunch: profiles/r4_graph_executor.txt).
+// A linear graph on one stream is the path of that executor that has replayed this package's steps since round 1.
+//
+// So: take the captured hipGraph_t (never instantiated), read its nodes and edges, cover the DAG with at most L chains
+// ("lanes"), cut every chain where a dependency crosses lanes, rebuild every piece as a single-branch graph (kernel / memset
+// / memcpy nodes re-added from their own parameters, each depending on its predecessor only), and at launch time issue the
+// pieces in topological order on L streams with an event per cross-lane dependency.  Dependencies are exactly the captured
+// ones (+ the chain order inside a lane); memory safety is the capture's (torch's caching allocator saw every lane as a
+// stream of its own).
+#include "common.h"
+
+#include <algorithm>
+#include <mutex>
+#include <queue>
+#include <unordered_map>
+#include <vector>
+
+namespace senas {
+
+struct Segment {
+    int lane = 0;
+    std::vector<int> nodes;      // indices into Sched::node (topological positions)
+    std::vector<int> deps;       // segments whose `done` event this one waits for
+    bool signals = false;        // somebody waits for it
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+struct Sched {
+    std::vector<Segment> segs;
+    std::vector<hipStream_t> lanes;      // lanes[0] is unused: lane 0 is the caller's stream; the others come from a process-wide pool
+    std::vector<hipEvent_t> lane_done;
+    hipEvent_t start = nullptr;
+    int n_nodes = 0, n_lanes = 0, n_cross = 0, n_kernel = 0, n_memset = 0, n_memcpy = 0, n_empty = 0, n_marker = 0, n_captured = 0;
+};
+
+static void sched_free(Sched* s) {
+    if (!s) return;
+    for (auto& g : s->segs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.done) (void)hipEventDestroy(g.done);
+    }
+    for (auto e : s->lane_done) if (e) (void)hipEventDestroy(e);
+    if (s->start) (void)hipEventDestroy(s->start);
+    delete s;
+}
+
+// Lane streams are shared by every scheduler of a device (the two passes of a search step, successive step drivers): the
+// hardware runs four queues per process by default (GPU_MAX_HW_QUEUES) and the runtime deals streams onto them by load, so
+// every extra stream is another chance of two busy lanes sharing a queue.  Never destroyed (process lifetime).
+static std::vector<hipStream_t>& lane_pool() {
+    static std::vector<hipStream_t> pool[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return pool[dev & 63];
+}
+
+#define SCHED_HIP(call, what)                                                   \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) { set_error(what, e__); sched_free(S); return SENAS_ELAUNCH; } \
+    } while (0)
+
+}  // namespace senas
+
+// A hand-over between two lanes passes through the capture's origin stream (grid.Lanes: the star topology).  The origin stream
+// records no kernel between two hand-overs, so the runtime's capture bookkeeping makes every hand-over depend on the producers
+// of all earlier ones.  A marker launched on the origin stream at each hand-over gives the chain a node the scheduler can
+// recognise: it drops marker -> marker edges and then contracts the markers (and empty nodes) out of the graph, which leaves
+// consumer <- producer, the dependency that was meant.
+__global__ void relay_marker_kernel() {}
+
+using namespace senas;
+
+extern "C" int senas_relay_marker(void* stream) {
+    hipLaunchKernelGGL(relay_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream));
+    return launch_status("relay_marker");
+}
+
+extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
+    SENAS_REQUIRE(hip_graph && out && max_lanes >= 1 && max_lanes <= 16, "sched_create: bad argument");
+    *out = nullptr;
+    hipGraph_t G = reinterpret_cast<hipGraph_t>(hip_graph);
+    Sched* S = new Sched();
+    size_t n = 0, m = 0;
+    SCHED_HIP(hipGraphGetNodes(G, nullptr, &n), "hipGraphGetNodes");
+    if (n == 0) { set_error_msg("sched_create: the graph has no nodes"); sched_free(S); return SENAS_EINVAL; }
+    std::vector<hipGraphNode_t> raw(n);
+    SCHED_HIP(hipGraphGetNodes(G, raw.data(), &n), "hipGraphGetNodes");
+    SCHED_HIP(hipGraphGetEdges(G, nullptr, nullptr, &m), "hipGraphGetEdges");
+    std::vector<hipGraphNode_t> ef(m), et(m);
+    if (m) SCHED_HIP(hipGraphGetEdges(G, ef.data(), et.data(), &m), "hipGraphGetEdges");
+    std::unordered_map<hipGraphNode_t, int> index;
+    for (size_t i = 0; i < n; ++i) index[raw[i]] = (int)i;
+    std::vector<std::vector<int>> par0(n), chi0(n);
+    for (size_t e = 0; e < m; ++e) {
+        auto a = index.find(ef[e]), b = index.find(et[e]);
+        if (a == index.end() || b == index.end()) { set_error_msg("sched_create: an edge names a node the graph does not list"); sched_free(S); return SENAS_EINVAL; }
+        par0[b->second].push_back(a->second);
+        chi0[a->second].push_back(b->second);
+    }
+    // ---- markers and empty nodes: drop marker -> marker edges, then contract both kinds out of the graph
+    {
+        std::vector<char> marker(n, 0), gone(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            hipGraphNodeType t;
+            SCHED_HIP(hipGraphNodeGetType(raw[i], &t), "hipGraphNodeGetType");
+            if (t == hipGraphNodeTypeEmpty) { gone[i] = 1; ++S->n_empty; }
+            if (t == hipGraphNodeTypeKernel) {
+                hipKernelNodeParams p;
+                SCHED_HIP(hipGraphKernelNodeGetParams(raw[i], &p), "hipGraphKernelNodeGetParams");
+                if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { marker[i] = gone[i] = 1; ++S->n_marker; }
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (!marker[i]) continue;
+            auto& ps = par0[i];
+            for (int p : ps) if (marker[p]) chi0[p].erase(std::remove(chi0[p].begin(), chi0[p].end(), (int)i), chi0[p].end());
+            ps.erase(std::remove_if(ps.begin(), ps.end(), [&](int p) { return marker[p] != 0; }), ps.end());
+        }
+        // contract in creation order: a removed node hands its parents to its children
+        for (size_t i = 0; i < n; ++i) {
+            if (!gone[i]) continue;
+            for (int c : chi0[i]) {
+                auto& cp = par0[c];
+                cp.erase(std::remove(cp.begin(), cp.end(), (int)i), cp.end());
+                for (int p : par0[i]) if (std::find(cp.begin(), cp.end(), p) == cp.end()) cp.push_back(p);
+            }
+            for (int p : par0[i]) {
+                auto& pc = chi0[p];
+                pc.erase(std::remove(pc.begin(), pc.end(), (int)i), pc.end());
+                for (int c : chi0[i]) if (std::find(pc.begin(), pc.end(), c) == pc.end()) pc.push_back(c);
+            }
+            par0[i].clear();
+            chi0[i].clear();
+        }
+        // compact: only the surviving nodes take part from here on
+        std::vector<int> newidx(n, -1);
+        std::vector<hipGraphNode_t> kept;
+        for (size_t i = 0; i < n; ++i) if (!gone[i]) { newidx[i] = (int)kept.size(); kept.push_back(raw[i]); }
+        if (kept.empty()) { set_error_msg("sched_create: the graph has no nodes to run"); sched_free(S); return SENAS_EINVAL; }
+        std::vector<std::vector<int>> np(kept.size()), nc(kept.size());
+        for (size_t i = 0; i < n; ++i) {
+            if (gone[i]) continue;
+            for (int p : par0[i]) np[newidx[i]].push_back(newidx[p]);
+            for (int c : chi0[i]) nc[newidx[i]].push_back(newidx[c]);
+        }
+        S->n_captured = (int)n;
+        raw.swap(kept);
+        par0.swap(np);
+        chi0.swap(nc);
+        n = raw.size();
+    }
+    // topological order, ties broken by the runtime's own node order (creation order)
+    std::vector<int> indeg(n), topo, pos(n);
+    for (size_t i = 0; i < n; ++i) indeg[i] = (int)par0[i].size();
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (size_t i = 0; i < n; ++i) if (!indeg[i]) ready.push((int)i);
+    while (!ready.empty()) {
+        const int v = ready.top();
+        ready.pop();
+        pos[v] = (int)topo.size();
+        topo.push_back(v);
+        for (int c : chi0[v]) if (--indeg[c] == 0) ready.push(c);
+    }
+    if (topo.size() != n) { set_error_msg("sched_create: the captured graph has a cycle"); sched_free(S); return SENAS_EINVAL; }
+    // from here on a node is its topological position
+    std::vector<std::vector<int>> par(n), chi(n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int p : par0[i]) par[pos[i]].push_back(pos[p]);
+        for (int c : chi0[i]) chi[pos[i]].push_back(pos[c]);
+    }
+    std::vector<hipGraphNodeType> type(n);
+    for (size_t v = 0; v < n; ++v) SCHED_HIP(hipGraphNodeGetType(raw[topo[v]], &type[v]), "hipGraphNodeGetType");
+
+    // ---- chain cover with at most max_lanes chains
+    const int L = max_lanes;
+    std::vector<int> lane(n, -1), tail(L, -1), placed_children(n, 0), last_use(L, -1);
+    for (int v = 0; v < (int)n; ++v) {
+        int best = -1;
+        for (int p : par[v])                                   // continue the lane of a parent that still ends its lane
+            if (tail[lane[p]] == p && (best < 0 || p > best)) best = p;
+        int l;
+        if (best >= 0) {
+            l = lane[best];
+        } else {
+            l = -1;
+            for (int q = 0; q < L && l < 0; ++q) if (tail[q] < 0) l = q;                       // an unused lane
+            if (l < 0) {                                                                       // a lane whose tail has nothing left to feed, idle longest
+                for (int q = 0; q < L; ++q) {
+                    const bool dead = placed_children[tail[q]] == (int)chi[tail[q]].size();
+                    if (dead && (l < 0 || last_use[q] < last_use[l])) l = q;
+                }
+            }
+            if (l < 0) { l = 0; for (int q = 1; q < L; ++q) if (last_use[q] < last_use[l]) l = q; }
+        }
+        lane[v] = l;
+        tail[l] = v;
+        last_use[l] = v;
+        for (int p : par[v]) ++placed_children[p];
+    }
+    // lane 0 = the lane of the first node (the caller's stream carries what the capture's origin stream started with)
+    if (lane[0] != 0) { const int a = lane[0]; for (auto& x : lane) x = (x == a ? 0 : (x == 0 ? a : x)); }
+    int used = 0;
+    for (int v = 0; v < (int)n; ++v) used = std::max(used, lane[v] + 1);
+
+    // ---- segments: cut before a node with a parent on another lane, cut after a node with a child on another lane
+    std::vector<int> seg_of(n, -1), open(used, -1);
+    for (int v = 0; v < (int)n; ++v) {
+        const int l = lane[v];
+        // a memcpy node is a segment of its own: it is not rebuilt from parameters (the runtime's 1-D copy nodes do not hand
+        // theirs out) but kept as the one survivor of a clone of the captured graph
+        const bool solo = type[v] == hipGraphNodeTypeMemcpy;
+        bool waits = false, feeds = false;
+        for (int p : par[v]) waits |= lane[p] != l;
+        for (int c : chi[v]) feeds |= lane[c] != l;
+        if (waits || solo || open[l] < 0) {
+            S->segs.emplace_back();
+            S->segs.back().lane = l;
+            open[l] = (int)S->segs.size() - 1;
+        }
+        Segment& sg = S->segs[open[l]];
+        sg.nodes.push_back(v);
+        seg_of[v] = open[l];
+        if (feeds) sg.signals = true;
+        if (feeds || solo) open[l] = -1;
+    }
+    for (size_t k = 0; k < S->segs.size(); ++k) {
+        Segment& sg = S->segs[k];
+        std::vector<int> latest(used, -1);                     // per source lane only the latest segment matters
+        for (int p : par[sg.nodes[0]])
+            if (lane[p] != sg.lane) { latest[lane[p]] = std::max(latest[lane[p]], seg_of[p]); ++S->n_cross; }
+        for (int q = 0; q < used; ++q) if (latest[q] >= 0) sg.deps.push_back(latest[q]);
+    }
+
+    // ---- every segment as a single-branch graph
+    for (auto& sg : S->segs) {
+        {
+            SCHED_HIP(hipGraphCreate(&sg.graph, 0), "hipGraphCreate");
+            hipGraphNode_t prev = nullptr;
+            for (int v : sg.nodes) {
+                hipGraphNode_t src = raw[topo[v]], made = nullptr;
+                const hipGraphNode_t* deps = prev ? &prev : nullptr;
+                const size_t nd = prev ? 1 : 0;
+                switch (type[v]) {
+                    case hipGraphNodeTypeKernel: {
+                        hipKernelNodeParams p;
+                        SCHED_HIP(hipGraphKernelNodeGetParams(src, &p), "hipGraphKernelNodeGetParams");
+                        SCHED_HIP(hipGraphAddKernelNode(&made, sg.graph, deps, nd, &p), "hipGraphAddKernelNode");
+                        ++S->n_kernel;
+                        break;
+                    }
+                    case hipGraphNodeTypeMemset: {
+                        hipMemsetParams p;
+                        SCHED_HIP(hipGraphMemsetNodeGetParams(src, &p), "hipGraphMemsetNodeGetParams");
+                        SCHED_HIP(hipGraphAddMemsetNode(&made, sg.graph, deps, nd, &p), "hipGraphAddMemsetNode");
+                        ++S->n_memset;
+                        break;
+                    }
+                    case hipGraphNodeTypeMemcpy: {
+                        // (alone in its segment: see the segmentation above)
+                        SCHED_HIP(hipGraphDestroy(sg.graph), "hipGraphDestroy");
+                        sg.graph = nullptr;
+                        SCHED_HIP(hipGraphClone(&sg.graph, G), "hipGraphClone");
+                        hipGraphNode_t keep = nullptr;
+                        SCHED_HIP(hipGraphNodeFindInClone(&keep, src, sg.graph), "hipGraphNodeFindInClone");
+                        size_t cn = 0;
+                        SCHED_HIP(hipGraphGetNodes(sg.graph, nullptr, &cn), "hipGraphGetNodes");
+                        std::vector<hipGraphNode_t> all(cn);
+                        SCHED_HIP(hipGraphGetNodes(sg.graph, all.data(), &cn), "hipGraphGetNodes");
+                        for (hipGraphNode_t x : all) if (x != keep) SCHED_HIP(hipGraphDestroyNode(x), "hipGraphDestroyNode");
+                        made = keep;
+                        ++S->n_memcpy;
+                        break;
+                    }
+                    default:
+                        set_error_msg("sched_create: the captured graph holds a node type the lane scheduler does not rebuild");
+                        sched_free(S);
+                        return SENAS_EUNSUPPORTED;
+                }
+                prev = made;
+            }
+            SCHED_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        }
+        if (sg.signals) SCHED_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+    S->lanes.assign(used, nullptr);
+    S->lane_done.assign(used, nullptr);
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        auto& pool = lane_pool();
+        while ((int)pool.size() < used - 1) {
+            hipStream_t st = nullptr;
+            SCHED_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+            pool.push_back(st);
+        }
+        for (int q = 1; q < used; ++q) S->lanes[q] = pool[q - 1];
+    }
+    for (int q = 1; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
+    SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");
+    S->n_nodes = (int)n;
+    S->n_lanes = used;
+    *out = S;
+    return SENAS_OK;
+}
+
+extern "C" int senas_sched_launch(void* sched, void* stream) {
+    SENAS_REQUIRE(sched != nullptr, "sched_launch: bad argument");
+    Sched* S = reinterpret_cast<Sched*>(sched);
+    hipStream_t main = as_stream(stream);
+#define LAUNCH_HIP(call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error(what, e__); return SENAS_ELAUNCH; } } while (0)
+    if (S->n_lanes > 1) {
+        LAUNCH_HIP(hipEventRecord(S->start, main), "hipEventRecord");
+        for (int q = 1; q < S->n_lanes; ++q) LAUNCH_HIP(hipStreamWaitEvent(S->lanes[q], S->start, 0), "hipStreamWaitEvent");
+    }
+    for (auto& sg : S->segs) {
+        hipStream_t s = sg.lane == 0 ? main : S->lanes[sg.lane];
+        for (int d : sg.deps) LAUNCH_HIP(hipStreamWaitEvent(s, S->segs[d].done, 0), "hipStreamWaitEvent");
+        if (sg.exec) LAUNCH_HIP(hipGraphLaunch(sg.exec, s), "hipGraphLaunch");
+        if (sg.signals) LAUNCH_HIP(hipEventRecord(sg.done, s), "hipEventRecord");
+    }
+    for (int q = 1; q < S->n_lanes; ++q) {
+        LAUNCH_HIP(hipEventRecord(S->lane_done[q], S->lanes[q]), "hipEventRecord");
+        LAUNCH_HIP(hipStreamWaitEvent(main, S->lane_done[q], 0), "hipStreamWaitEvent");
+    }
+#undef LAUNCH_HIP
+    return SENAS_OK;
+}
+
+extern "C" int senas_sched_info(void* sched, int32_t* out8) {
+    SENAS_REQUIRE(sched != nullptr && out8 != nullptr, "sched_info: bad argument");
+    Sched* S = reinterpret_cast<Sched*>(sched);
+    out8[0] = S->n_nodes; out8[1] = S->n_lanes; out8[2] = (int)S->segs.size(); out8[3] = S->n_cross;
+    out8[4] = S->n_kernel; out8[5] = S->n_memset; out8[6] = S->n_memcpy; out8[7] = S->n_empty + S->n_marker;
+    return SENAS_OK;
+}
+
+extern "C" void senas_sched_destroy(void* sched) { sched_free(reinterpret_cast<Sched*>(sched)); }

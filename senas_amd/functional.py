@@ -961,6 +961,56 @@ class _FanOut(torch.autograd.Function):
         return out, None
 
 
+# tools/lane_timeline.py: a StampRecorder while a timeline is being taken, else None (no stamp is launched)
+STAMPS = None
+
+
+class StampRecorder(object):
+    """Device time stamps in stream order at named points of a pass (senas_stamp), forward and backward: every ``stamp`` call
+    takes the next pair of slots; under HIP-graph replay the captured stamps are rewritten by every replay."""
+
+    def __init__(self, device, capacity=16384):
+        self.buf = torch.zeros(capacity, device=device, dtype=torch.int64)
+        self.names = []
+
+    def slots(self, name):
+        k = len(self.names)
+        if 2 * k + 1 >= self.buf.numel():
+            raise SenasHipError('stamp recorder full')
+        self.names.append(name)
+        return self.buf.data_ptr() + 16 * k, self.buf.data_ptr() + 16 * k + 8
+
+    def read(self):
+        """[(name, forward ticks, backward ticks)] of the slots written since the buffer was last zeroed (100 MHz ticks)."""
+        v = self.buf.cpu().tolist()
+        return [(n, v[2 * k], v[2 * k + 1]) for k, n in enumerate(self.names) if v[2 * k] or v[2 * k + 1]]
+
+
+class _Stamp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd_slot, bwd_slot):
+        _lib.check(_lib.lib().senas_stamp(fwd_slot, _stream()), 'senas_stamp')
+        ctx.slot = bwd_slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        _lib.check(_lib.lib().senas_stamp(ctx.slot, _stream()), 'senas_stamp')
+        return g, None, None
+
+
+def stamp(x, name):
+    """x, with a time stamp launched on the current stream now and another where its gradient passes on the way back."""
+    if STAMPS is None:
+        return x
+    f, b = STAMPS.slots(name)
+    y = _Stamp.apply(x, f, b)
+    st = getattr(x, '_senas_stats', None)
+    if st is not None:
+        y._senas_stats = st
+    return y
+
+
 class _Hop(torch.autograd.Function):
     """An alias of x behind an autograd node of the CURRENT stream.  Autograd replays a node on the stream its forward pass
     ran on and makes that stream wait for the producer of every gradient it receives: a tensor that goes from one lane of
@@ -970,15 +1020,26 @@ class _Hop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        relay_marker()
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
+        relay_marker()
         return g
+
+
+def relay_marker():
+    """An empty kernel on the current (origin) stream while a pass is being captured: the lane scheduler recognises it, cuts the
+    false dependency chain between successive hand-overs and contracts it away (csrc/sched.hip)."""
+    if torch.cuda.is_current_stream_capturing():
+        _lib.check(_lib.lib().senas_relay_marker(_stream()), 'senas_relay_marker')
 
 
 def hop(x):
     if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        if torch.is_tensor(x) and x.is_cuda:
+            relay_marker()
         return x
     y = _Hop.apply(x)
     st = getattr(x, '_senas_stats', None)

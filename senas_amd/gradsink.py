@@ -134,6 +134,7 @@ class GradSink(object):
         table is built once per set of stacks -- under graph replay, once)."""
         from . import functional as F
         if self.flat.is_cuda:
+            F.join_lanes()               # the backward kernels of the macro grid's columns ran on their own streams (grid.Lanes)
             F.flush_deferred()
         if not self._stacks_written:
             return

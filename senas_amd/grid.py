@@ -209,6 +209,7 @@ class MacroGrid(nn.Module):
         # -- and captured -- in two parts, so that the up-path gradients are all-reduced while the rest still runs):
         # cut(tensor) -> the leaf the up path reads in its place
         self.cut = None
+        self.lanes = True        # this grid's columns may run on lanes (grid.Lanes; a step driver turns it off where it must)
 
     def down_parameters(self):
         """Parameters of the down path (stems, down cells): the ones whose gradients backward produces last."""
@@ -233,9 +234,16 @@ class MacroGrid(nn.Module):
         j + 1 is launched after that of up cell (1, j) and before that of (1, j - 1), and waits for exactly what it needs."""
         live = x is not None
         depth = self._depth
-        lanes = Lanes(x.device, depth - 1) if (live and Lanes.enabled and x.is_cuda and depth > 2) else None
+        lanes = Lanes(x.device, depth - 1) if (live and Lanes.enabled and self.lanes and x.is_cuda and depth > 2) else None
         cut = self.cut if live else None
         G = [[None] * (depth - i) for i in range(depth)]
+
+        def call(name, module, kind, a, b):
+            """run(...), between time stamps when a timeline is being taken (tools/lane_timeline.py)."""
+            from . import functional as F
+            if F.STAMPS is None:
+                return run(module, kind, a, b)
+            return F.stamp(run(module, kind, F.stamp(a, name + '.in0'), F.stamp(b, name + '.in1')), name + '.out')
 
         def up_cell(i, j):
             cell = self.blocks[i][j]
@@ -246,14 +254,14 @@ class MacroGrid(nn.Module):
             in1 = plan.get(G[i - 1][j + 1])
             if lanes is None:
                 ins = skips(plan, G, i, j, live)
-                y = run(cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), in1) if live else None
+                y = call('up%d%d' % (i, j), cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), in1) if live else None
                 G[i][j] = plan.put(('o', i, j), y)
                 return
             lanes.after(j, [(0, j)])
             in1 = lanes.hand(in1, (i - 1, j + 1), j)
             with lanes.on(j):
                 ins = [Lanes.take(t) for t in skips(plan, G, i, j, live)]
-                y = run(cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), Lanes.take(in1))
+                y = call('up%d%d' % (i, j), cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), Lanes.take(in1))
                 G[i][j] = plan.put(('o', i, j), y)
                 lanes.mark((i, j))
 
@@ -274,7 +282,7 @@ class MacroGrid(nn.Module):
             lanes.mark((0, 0))
         for j in range(1, depth):
             a, b = plan.get(s0 if j == 1 else D[j - 2]), plan.get(D[j - 1])
-            D.append(plan.put(('o', 0, j), run(self.blocks[0][j], 'down', a, b) if live else None))
+            D.append(plan.put(('o', 0, j), call('down%d' % j, self.blocks[0][j], 'down', a, b) if live else None))
             G[0][j] = cut_here(D[j])
             if lanes is not None:
                 lanes.mark((0, j))
@@ -293,7 +301,7 @@ class MacroGrid(nn.Module):
             a, b = plan.get(s0), plan.get(o)
             if lanes is not None:
                 Lanes.take(b)                                  # made on lane 0, read here
-            res.append(run(head, 'head', a, b) if live else None)
+            res.append(call('head', head, 'head', a, b) if live else None)
         return res
 
     def _check_tails(self, tails):

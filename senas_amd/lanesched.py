@@ -1,0 +1,44 @@
+"""The lane scheduler (csrc/sched.hip) behind a captured pass: the captured multi-stream graph is never instantiated; its
+nodes are re-issued as single-branch graphs on a handful of streams with an event per cross-lane dependency."""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+MAX_LANES = int(os.environ.get('SENAS_MAX_LANES', 5))           # streams per captured pass (lane 0 = the caller's stream)
+
+
+class LaneSchedule(object):
+    def __init__(self, graph, max_lanes=None):
+        """``graph``: a ``torch.cuda.CUDAGraph(keep_graph=True)`` whose capture has ended; it is kept alive here (it owns the
+        captured hipGraph_t and the memory pool the pass lives in)."""
+        self.graph = graph
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().senas_sched_create(C.c_void_p(graph.raw_cuda_graph()), int(max_lanes or MAX_LANES), C.byref(self.handle)),
+                   'senas_sched_create')
+        if os.environ.get('SENAS_SCHED_VERBOSE'):
+            import sys
+            sys.stderr.write('[lanesched] %s\n' % self.info())
+
+    def launch(self):
+        _lib.check(_lib.lib().senas_sched_launch(self.handle, torch.cuda.current_stream().cuda_stream), 'senas_sched_launch')
+
+    def info(self):
+        out = (C.c_int32 * 8)()
+        _lib.check(_lib.lib().senas_sched_info(self.handle, out), 'senas_sched_info')
+        keys = ('nodes', 'lanes', 'segments', 'cross_lane_dependencies', 'kernel_nodes', 'memset_nodes', 'memcpy_nodes', 'empty_nodes')
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            _lib.lib().senas_sched_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown
+            pass

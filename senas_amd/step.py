@@ -20,7 +20,8 @@ from . import functional as F
 from . import optim
 from .arena import reset_arena
 from .gradsink import GradSink
-from .grid import MacroGrid
+from .grid import Lanes, MacroGrid
+from .lanesched import LaneSchedule
 from .packing import WeightPacker
 from .parallel import SinkReducer
 
@@ -65,8 +66,13 @@ class GraphedForwardBackward(object):
         self.x, self.y = x, y                      # static buffers; refill with .copy_() between steps
         self.loss = None
         self.graph = self.graph_tail = None
+        self.sched = self.sched_tail = None        # lane schedulers of the captured passes (None: the runtime's own graph replay)
         self.frozen = [p for p in frozen if p.requires_grad]
         self.grid = _macro_grid(model)
+        if self.grid is not None and any(isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0 for m in model.modules()):
+            # torch's graph replay advances the Philox offsets of the captured dropout draws; the lane scheduler replays the
+            # captured launches as they are -- a network with dropout keeps the serial schedule and torch's own replay
+            self.grid.lanes = False
         self.early = early if (early is not None and early.world > 1 and self.grid is not None) else None
         self._work = None
         self._collectives = True
@@ -157,17 +163,26 @@ class GraphedForwardBackward(object):
         torch.cuda.synchronize()
         self._collectives = True
         reset_arena()
-        graph = torch.cuda.CUDAGraph(keep_graph=True) if self.count_nodes else torch.cuda.CUDAGraph()
+        # a pass that runs on several lanes (grid.Lanes) is captured but never handed to the runtime's graph executor: the
+        # captured graph is replayed by the lane scheduler (lanesched.LaneSchedule, csrc/sched.hip)
+        lanes = Lanes.enabled and self.grid is not None and self.grid.lanes and self.grid._depth > 2
+        keep = lanes or self.count_nodes
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
             self.loss = self._head()
         if self.count_nodes:
             self.nodes = _graph_nodes(graph)
+        if lanes:
+            self.sched = LaneSchedule(graph)
+        elif keep:
             graph.instantiate()
         if self.early is not None:
-            tail = torch.cuda.CUDAGraph()
+            tail = torch.cuda.CUDAGraph(keep_graph=True) if lanes else torch.cuda.CUDAGraph()
             with torch.cuda.graph(tail, pool=graph.pool(), capture_error_mode='thread_local'):
                 self._tail()
             self.graph_tail = tail
+            if lanes:
+                self.sched_tail = LaneSchedule(tail)
         reset_arena()
         self.graph = graph
         with torch.no_grad():
@@ -178,12 +193,18 @@ class GraphedForwardBackward(object):
         if self.graph is None:
             self.loss = self._eager()
         else:
-            self.graph.replay()
+            if self.sched is not None:
+                self.sched.launch()
+            else:
+                self.graph.replay()
             if self.refresh:
                 self.packer.mark_refreshed()       # the replay starts with the packer's refresh launches
             if self.graph_tail is not None:
                 self._launch_early()
-                self.graph_tail.replay()
+                if self.sched_tail is not None:
+                    self.sched_tail.launch()
+                else:
+                    self.graph_tail.replay()
         return self.loss
 
     def finish(self):

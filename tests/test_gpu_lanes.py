@@ -1,0 +1,234 @@
+"""GPU checks of the macro grid on several HIP streams (senas_amd/grid.py: Lanes), of the lane scheduler that replays the
+captured passes (csrc/sched.hip, senas_amd/lanesched.py) and of the fused architecture tables against the torch path.
+The reference walks the grid cell by cell on one stream (search/senas_search.py:96-107, models/senas_model.py:160-175);
+every schedule that respects the data flow must give its results."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def _batch(n=2, size=64, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 1, size, size, generator=g).to(dev()), torch.randint(0, 2, (n, size, size), generator=g).to(dev())
+
+
+def _make(kind):
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import NAS
+    torch.manual_seed(0)
+    if kind == 'nas.c8.d5':
+        return NAS(1, 8, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False).to(dev()).train()
+    if kind == 'nas.c32.d4.sup.share':
+        return NAS(1, 32, 2, 4, meta_node_num=3, use_sharing=True, double_down_channel=False, supervision=True).to(dev()).train()
+    if kind == 'nas.c8.d3.dd':
+        return NAS(1, 8, 2, 3, meta_node_num=3, use_sharing=False, double_down_channel=True).to(dev()).train()
+    if kind == 'derived.c32.d5':
+        return SenasModel(2, 1, c=32, depth=5, genotype=senas_node_4).to(dev()).train()
+    if kind == 'derived.c8.d4.all':
+        return SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4._replace(gamma=[1] * 6), supervision=True).to(dev()).train()
+    raise KeyError(kind)
+
+
+def _pass(net, crit, x, y):
+    for p in net.parameters():
+        p.grad = None
+    out = net(x)
+    crit(out, y).backward()
+    torch.cuda.synchronize()
+    return [o.detach().clone() for o in out], {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+@pytest.fixture
+def lanes_switch():
+    from senas_amd import grid
+    keep = grid.Lanes.enabled
+    yield grid.Lanes
+    grid.Lanes.enabled = keep
+
+
+@pytest.mark.parametrize('kind', ['nas.c8.d5', 'nas.c32.d4.sup.share', 'nas.c8.d3.dd', 'derived.c32.d5', 'derived.c8.d4.all'])
+def test_lanes_give_the_serial_schedules_results(kind, lanes_switch):
+    """Columns of up cells on their own streams against every cell on the caller's stream: identical logits (no atomics
+    in the forward pass), every gradient equal up to the summation order of atomics."""
+    from senas_amd.loss import MultiSegmentationLosses, SegmentationLosses
+    net = _make(kind)
+    crit = MultiSegmentationLosses('dice_ce', len(net(_batch()[0]))) if ('sup' in kind or 'all' in kind) else SegmentationLosses('dice_ce')
+    x, y = _batch()
+    state = copy.deepcopy(net.state_dict())
+    res = []
+    for on in (False, True, True):
+        lanes_switch.enabled = on
+        net.load_state_dict(state)
+        res.append(_pass(net, crit, x, y))
+    (o0, g0), (o1, g1), (o2, g2) = res
+    assert set(g0) == set(g1) == set(g2) and len(g0) > 100
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for ga, gb in ((g0, g1), (g1, g2)):
+        worst = max(float((ga[k] - gb[k]).abs().max() / (ga[k].abs().max() + 1e-30)) for k in ga)
+        assert worst < 2e-5, worst
+
+
+def test_lane_scheduler_replays_a_captured_multi_stream_graph():
+    """csrc/sched.hip on a small hand-made capture: two side streams forked off the capture stream, a hand-over through it,
+    a memset node, a join -- replayed by the scheduler (never instantiated by the runtime) on fresh inputs."""
+    from senas_amd.lanesched import LaneSchedule
+    a = torch.zeros(1 << 16, device=dev())
+    out = torch.zeros_like(a)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    main = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main):
+        with torch.cuda.graph(g, stream=main, capture_error_mode='thread_local'):
+            b = a * 2.0
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                c = torch.sin(b) + 1.0
+                for _ in range(5):
+                    c = c * 1.5 - 0.25
+            with torch.cuda.stream(s2):
+                d = torch.zeros_like(b)              # a memset node
+                d = d + b * b
+            main.wait_stream(s1)                     # hand c over to s2 through the origin stream
+            s2.wait_stream(main)
+            with torch.cuda.stream(s2):
+                e = d - c
+            main.wait_stream(s2)
+            out.copy_(e + b)
+    sched = LaneSchedule(g, max_lanes=3)
+    info = sched.info()
+    assert info['lanes'] >= 2 and info['kernel_nodes'] >= 10 and info['segments'] >= 3, info
+    for seed in (1, 2, 3):
+        a.copy_(torch.randn(a.shape, generator=torch.Generator().manual_seed(seed)).to(dev()))
+        with torch.cuda.stream(main):
+            sched.launch()
+        torch.cuda.synchronize()
+        b_ = a * 2.0
+        c_ = torch.sin(b_) + 1.0
+        for _ in range(5):
+            c_ = c_ * 1.5 - 0.25
+        want = (b_ * b_) - c_ + b_
+        assert torch.allclose(out, want, rtol=1e-6, atol=1e-6), float((out - want).abs().max())
+    sched.close()
+
+
+@pytest.mark.parametrize('kind', ['search', 'train'])
+def test_step_drivers_on_lanes_track_the_serial_eager_step(kind, lanes_switch):
+    """The captured step (lanes + lane scheduler) against the same driver run eagerly on one stream: same losses and same
+    weights after three optimizer steps, to the summation order of atomics."""
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import NAS
+    from senas_amd.step import SearchStep, TrainStep
+    crit = SegmentationLosses('dice_ce')
+    x, y = _batch(2, 64, 5)
+    xv, yv = _batch(2, 64, 6)
+    runs = []
+    for lanes, graphed in ((False, False), (True, True)):
+        lanes_switch.enabled = lanes
+        torch.manual_seed(1)
+        if kind == 'search':
+            net = NAS(1, 8, 2, 4, meta_node_num=3, use_sharing=False, double_down_channel=False).to(dev()).train()
+            ow = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
+            # (plain SGD on the architecture tensors: Adam's normalised step turns the last bits of a near-zero gradient into a
+            # full step, and the weight pass behind it amplifies that -- the trajectory tests against the oracle use Adam)
+            oa = torch.optim.SGD(net.arch_parameters(), lr=1e-2)
+            drv = SearchStep(net, crit, ow, oa, x.clone(), y.clone(), use_graph=graphed)
+            step = lambda: drv(x, y, xv, yv)
+            sched = drv.fb.sched
+        else:
+            net = SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4).to(dev()).train()
+            opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)
+            drv = TrainStep(net, crit, opt, x, y, use_graph=graphed)
+            step = drv
+            sched = drv.fb.sched
+        if graphed:
+            assert sched is not None and sched.info()['lanes'] >= 2, 'the captured pass does not run on the lane scheduler'
+        losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+        drv.close()
+    (l0, s0), (l1, s1) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
+    for k in s0:
+        if s0[k].is_floating_point():
+            # three steps of lr ~5e-3 on gradients that agree to ~1e-5: to 1e-6 + 2e-4 of the tensor's scale.  The architecture
+            # gradients of a c = 8 supernet are conditioned 1e4 worse (1e-7 on the mixing weights moves them
+            # by 5e-4): 2e-2 of their scale here -- the tight statement is test_search_step_driver_trajectory against the oracle
+            scale = float(s0[k].abs().max()) + 1e-12
+            arch = k.startswith(('alphas', 'betas', 'gamma'))
+            bound = 2e-2 * scale if arch else 1e-6 + 2e-4 * scale
+            assert float((s0[k] - s1[k]).abs().max()) <= bound, (k, float((s0[k] - s1[k]).abs().max()), scale)
+
+
+def test_a_network_with_dropout_keeps_the_serial_schedule():
+    """torch's graph replay advances the Philox offsets of captured dropout draws; the lane scheduler replays launches as they
+    are -- so a driver over a network with dropout captures one stream and uses torch's replay."""
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.step import TrainStep
+    torch.manual_seed(2)
+    net = SenasModel(2, 1, c=8, depth=4, genotype=senas_node_4, dropout_prob=0.2).to(dev()).train()
+    x, y = _batch(2, 64, 7)
+    drv = TrainStep(net, SegmentationLosses('dice_ce'), torch.optim.SGD(net.parameters(), lr=1e-3), x, y)
+    assert drv.fb.sched is None and drv.fb.graph is not None
+    a, b = float(drv()), float(drv())
+    assert a == a and b == b and a != b            # finite, and a fresh mask per replay
+    drv.close()
+
+
+@pytest.mark.parametrize('sharing,depth,nodes', [(False, 4, 3), (True, 4, 3), (False, 2, 3), (True, 3, 4), (False, 3, 4)])
+def test_arch_tables_against_the_torch_path(sharing, depth, nodes):
+    """senas_arch_mix_fwd / _bwd (all softmaxes, the overlapping beta windows, both mixing matrices, the seven parameter
+    gradients -- search/senas_search.py:252-260, search/cell.py:33-36,100-106) against NAS._mixing_weights + _EdgeMix on the
+    same network: tables to 1e-6, gradients to 1e-5 of their scale.  use_sharing: alphas_up_nm IS alphas_dn_nm (the NORM rows of
+    both kinds land in one gradient); depth 2: gamma is empty."""
+    from senas_amd import functional as F
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    torch.manual_seed(11)
+    net = NAS(1, 8, 2, depth, meta_node_num=nodes, use_sharing=sharing, double_down_channel=False).to(dev()).train()
+    with torch.no_grad():
+        for p in net.arch_parameters():
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev()) * 0.5)
+    crit = SegmentationLosses('dice_ce')
+    x, y = _batch(2, 32 if depth > 2 else 16, 9)
+    # tables
+    tabs = F.ArchTables(nodes, net.alphas_dn, net.alphas_up, net.alphas_dn_nm, net.alphas_up_nm, net.betas_dn, net.betas_up, net.gamma).args()
+    want = net._mixing_weights()
+    for a, b in zip(tabs, want):
+        assert a.shape == b.shape
+        if a.numel():
+            assert float((a.detach() - b.detach()).abs().max()) < 1e-6
+    state = copy.deepcopy(net.state_dict())
+    grads = []
+    for plain in (True, False):
+        net.load_state_dict(state)
+        net._plain_arch = plain
+        for p in net.parameters():
+            p.grad = None
+        crit(net(x), y).backward()
+        torch.cuda.synchronize()
+        grads.append([None if p.grad is None else p.grad.detach().clone() for p in net.arch_parameters()])
+    net._plain_arch = False
+    names = ['alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'gamma']
+    for name, a, b in zip(names, *grads):
+        if a is None or a.numel() == 0:
+            assert b is None or b.numel() == 0 or float(b.abs().max()) == 0.0, name
+            continue
+        assert b is not None, name
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (name, float((a - b).abs().max()), scale)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""What really overlaps in a step that runs on several HIP streams (senas_amd.grid.Lanes) under HIP-graph replay: device
+time stamps in stream order at the boundaries of every cell, forward and backward (senas_stamp; functional.stamp), read
+after ONE replay of the step.  A tracing profiler serialises the hardware queues; these stamps do not.
+
+    python tools/lane_timeline.py search|train [--serial]
+
+Prints per pass: every cell with the start / end of its forward and of its backward part (us from the first stamp of the
+pass), the sum of the cells' own durations and the span they cover.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from senas_amd import functional as F  # noqa: E402
+from senas_amd import grid  # noqa: E402
+from senas_amd.loss import SegmentationLosses  # noqa: E402
+
+
+def report(rows, title):
+    cells, order = {}, []
+    for name, f, b in rows:
+        cell, point = name.rsplit('.', 1)
+        if cell not in cells:
+            cells[cell] = {}
+            order.append(cell)
+        cells[cell][point] = (f, b)
+    t0 = min(v for c in cells.values() for p in c.values() for v in p if v)
+    us = lambda t: (t - t0) / 100.0 if t else float('nan')
+    print('\n== %s' % title)
+    print('%-8s %10s %10s %8s | %10s %10s %8s' % ('cell', 'fwd start', 'fwd end', 'us', 'bwd start', 'bwd end', 'us'))
+    fsum = bsum = 0.0
+    last = 0.0
+    for cell in order:
+        c = cells[cell]
+        fs = min(us(c[p][0]) for p in ('in0', 'in1') if p in c)
+        fe = us(c['out'][0])
+        bs = us(c['out'][1])
+        be = max([us(c[p][1]) for p in ('in0', 'in1') if p in c and c[p][1]] or [float('nan')])
+        fsum += fe - fs
+        bsum += (be - bs) if be == be else 0.0
+        last = max(last, fe, be if be == be else 0.0)
+        print('%-8s %10.1f %10.1f %8.1f | %10.1f %10.1f %8.1f' % (cell, fs, fe, fe - fs, bs, be, be - bs))
+    print('cells: forward %.1f us + backward %.1f us = %.1f us of cell time inside a span of %.1f us' % (fsum, bsum, fsum + bsum, last))
+
+
+def split_passes(rows):
+    """The stamps of the two captured passes of a search step (architecture pass first)."""
+    first = rows[0][0]
+    cut = [k for k, r in enumerate(rows) if r[0] == first]
+    return [rows[a:b] for a, b in zip(cut, cut[1:] + [len(rows)])]
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else 'search'
+    grid.Lanes.enabled = '--serial' not in sys.argv
+    dev = torch.device('cuda:0')
+    F.STAMPS = rec = F.StampRecorder(dev)
+    crit = SegmentationLosses('dice_ce')
+    if what == 'search':
+        from senas_amd.senas_search import NAS
+        from senas_amd.step import SearchStep
+        torch.manual_seed(0)
+        net = NAS(1, 32, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False).to(dev).train()
+        opt_w = torch.optim.SGD(net.parameters(), lr=5e-3, weight_decay=3e-4, momentum=0.9)
+        opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
+        xt, yt = bench.synthetic(4, 1, 2, 256, 1, dev)
+        xv, yv = bench.synthetic(4, 1, 2, 256, 101, dev)
+        drv = SearchStep(net, crit, opt_w, opt_a, xt.clone(), yt.clone())
+        step = lambda: drv(xt, yt, xv, yv)
+    else:
+        from senas_amd.step import TrainStep
+        net = bench.build_derived(dev)
+        opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)
+        x, y = bench.synthetic(8, 1, 2, 256, 1, dev)
+        drv = TrainStep(net, crit, opt, x, y)
+        step = drv
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    print('%s step with stamps, lanes=%s: %.3f ms' % (what, grid.Lanes.enabled, e0.elapsed_time(e1) / 10))
+    rec.buf.zero_()
+    torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
+    rows = rec.read()
+    passes = split_passes(rows)
+    titles = ['architecture pass (weights frozen)', 'weight pass'] if what == 'search' else ['train step']
+    for rows_, title in zip(passes, titles):
+        report(rows_, title)
+
+
+if __name__ == '__main__':
+    main()

@@ -60,13 +60,15 @@ def check():
 def timing(steps):
     dev = torch.device('cuda:0')
     args = bench.parse_args(['--steps', str(steps), '--search-steps', str(steps), '--no-cpu-baseline', '--lp-steps', '0'])
-    for lanes in (False, True):
+    only = os.environ.get('LANES_ONLY')
+    modes = (True,) if only else (False, True)
+    for lanes in modes:
         grid.Lanes.enabled = lanes
         s = bench.bench_search(dev, steps, 0, 1)
         print(json.dumps({'lanes': lanes, 'search_ms': s['ms_per_step'], 'nodes': s['roofline'].get('graph_nodes_per_step')}), flush=True)
     from senas_amd.loss import SegmentationLosses
     from senas_amd.step import TrainStep
-    for lanes in (False, True):
+    for lanes in modes:
         grid.Lanes.enabled = lanes
         net = bench.build_derived(dev)
         crit = SegmentationLosses('dice_ce')

@@ -36,7 +36,7 @@ struct Segment {
 
 struct Sched {
     std::vector<Segment> segs;
-    std::vector<hipStream_t> lanes;      // lanes[0] is unused: lane 0 is the caller's stream; the others come from a process-wide pool
+    std::vector<hipStream_t> lanes;      // from a process-wide pool (one lane only: empty, everything runs on the caller's stream)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t start = nullptr;
     int n_nodes = 0, n_lanes = 0, n_cross = 0, n_kernel = 0, n_memset = 0, n_memcpy = 0, n_empty = 0, n_marker = 0, n_captured = 0;
@@ -54,14 +54,65 @@ static void sched_free(Sched* s) {
     delete s;
 }
 
-// Lane streams are shared by every scheduler of a device (the two passes of a search step, successive step drivers): the
-// hardware runs four queues per process by default (GPU_MAX_HW_QUEUES) and the runtime deals streams onto them by load, so
-// every extra stream is another chance of two busy lanes sharing a queue.  Never destroyed (process lifetime).
+// Lane streams are shared by every scheduler of a device (the two passes of a search step, successive step drivers) and are
+// chosen so that no two of them sit on one hardware queue.  The runtime runs GPU_MAX_HW_QUEUES (4) hardware queues per process
+// and deals streams onto them by load; two lanes on one queue run one after the other however independent their work is, and
+// more than four busy queues made every step slower (measured: profiles/r4_lanes_queues.txt).  So the pool is built by
+// measurement: candidate streams are created one by one and a candidate is kept only if a 150 us spin kernel on it overlaps
+// with the same kernel on every stream already kept.  Never destroyed (process lifetime).
+__global__ void lane_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+static bool lanes_overlap(hipStream_t a, hipStream_t b) {
+    // two 150 us spins: ~150 us when the streams run side by side, ~300 us when they share a queue
+    const long long ticks = 15000;                                   // 100 MHz clock
+    double best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+        (void)hipEventRecord(e0, a);
+        hipLaunchKernelGGL(lane_spin_kernel, dim3(1), dim3(1), 0, a, ticks);
+        hipLaunchKernelGGL(lane_spin_kernel, dim3(1), dim3(1), 0, b, ticks);
+        (void)hipEventRecord(eb, b);
+        (void)hipStreamWaitEvent(a, eb, 0);
+        (void)hipEventRecord(e1, a);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = std::min(best, (double)ms);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(eb);
+    }
+    return best < 0.225;
+}
+
 static std::vector<hipStream_t>& lane_pool() {
     static std::vector<hipStream_t> pool[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     return pool[dev & 63];
+}
+
+// grow the pool to `want` streams on distinct hardware queues (fewer if the device does not give that many)
+static void lane_pool_grow(int want) {
+    auto& pool = lane_pool();
+    std::vector<hipStream_t> rejected;
+    for (int tries = 0; (int)pool.size() < want && tries < 16; ++tries) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        bool ok = true;
+        for (hipStream_t kept : pool) ok = ok && lanes_overlap(kept, st);
+        if (ok) pool.push_back(st); else rejected.push_back(st);      // (kept alive until the end: a destroyed stream's queue slot is the next one handed out)
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    (void)hipGetLastError();
 }
 
 #define SCHED_HIP(call, what)                                                   \
@@ -295,18 +346,15 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
     }
     S->lanes.assign(used, nullptr);
     S->lane_done.assign(used, nullptr);
-    {
+    if (used > 1) {
         static std::mutex mu;
         std::lock_guard<std::mutex> lock(mu);
+        lane_pool_grow(used);
         auto& pool = lane_pool();
-        while ((int)pool.size() < used - 1) {
-            hipStream_t st = nullptr;
-            SCHED_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
-            pool.push_back(st);
-        }
-        for (int q = 1; q < used; ++q) S->lanes[q] = pool[q - 1];
+        if (pool.empty()) { set_error_msg("sched_create: no lane stream could be created"); sched_free(S); return SENAS_ELAUNCH; }
+        for (int q = 0; q < used; ++q) S->lanes[q] = pool[q % pool.size()];      // (fewer queues than lanes: lanes share streams)
     }
-    for (int q = 1; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
+    for (int q = 0; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
     SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");
     S->n_nodes = (int)n;
     S->n_lanes = used;
@@ -319,17 +367,19 @@ extern "C" int senas_sched_launch(void* sched, void* stream) {
     Sched* S = reinterpret_cast<Sched*>(sched);
     hipStream_t main = as_stream(stream);
 #define LAUNCH_HIP(call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error(what, e__); return SENAS_ELAUNCH; } } while (0)
-    if (S->n_lanes > 1) {
+    // the caller's stream only forks and joins: the lanes are the pool's streams, one hardware queue each
+    const bool forked = S->n_lanes > 1;
+    if (forked) {
         LAUNCH_HIP(hipEventRecord(S->start, main), "hipEventRecord");
-        for (int q = 1; q < S->n_lanes; ++q) LAUNCH_HIP(hipStreamWaitEvent(S->lanes[q], S->start, 0), "hipStreamWaitEvent");
+        for (int q = 0; q < S->n_lanes; ++q) LAUNCH_HIP(hipStreamWaitEvent(S->lanes[q], S->start, 0), "hipStreamWaitEvent");
     }
     for (auto& sg : S->segs) {
-        hipStream_t s = sg.lane == 0 ? main : S->lanes[sg.lane];
+        hipStream_t s = forked ? S->lanes[sg.lane] : main;
         for (int d : sg.deps) LAUNCH_HIP(hipStreamWaitEvent(s, S->segs[d].done, 0), "hipStreamWaitEvent");
         if (sg.exec) LAUNCH_HIP(hipGraphLaunch(sg.exec, s), "hipGraphLaunch");
         if (sg.signals) LAUNCH_HIP(hipEventRecord(sg.done, s), "hipEventRecord");
     }
-    for (int q = 1; q < S->n_lanes; ++q) {
+    for (int q = 0; forked && q < S->n_lanes; ++q) {
         LAUNCH_HIP(hipEventRecord(S->lane_done[q], S->lanes[q]), "hipEventRecord");
         LAUNCH_HIP(hipStreamWaitEvent(main, S->lane_done[q], 0), "hipStreamWaitEvent");
     }

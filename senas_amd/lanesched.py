@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 
-MAX_LANES = int(os.environ.get('SENAS_MAX_LANES', 5))           # streams per captured pass (lane 0 = the caller's stream)
+MAX_LANES = int(os.environ.get('SENAS_MAX_LANES', 4))           # lanes per captured pass: one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4)
 
 
 class LaneSchedule(object):

@@ -228,6 +228,10 @@ def _oracle_gradient_spread(z, tag, kw, names, trials=3):
     return spread
 
 
+# whole-net fixtures whose gradient counts are recorded, not bounded (see test_whole_net)
+OPEN_WHOLE_NET = ('nas.c8.d5', 'nas.c8.d4.share_dd')
+
+
 @pytest.mark.parametrize('fixture,tag', NET_CASES)
 def test_whole_net(fixture, tag):
     """nets: round-1 cases; nets2: the reference's default flags -- NAS(use_sharing=True, double_down_channel=True)
@@ -266,35 +270,48 @@ def test_whole_net(fixture, tag):
             escaped.append((k, gpu_err, ref_err, vs32))
     # a tensor is held to north_star's 1e-3 against the fp64 reference, or to 2e-4 against the reference's own fp32 run
     # (the parity target proper: ill-conditioned c = 8 fixtures sit 4e-3 from fp64 in BOTH implementations); only the
-    # rest passes on the strength of the reference's fp32-vs-fp64 spread -- bounded in number (the c = 32 fixtures of
-    # test_full_width_net_every_gradient have no escape at all)
+    # rest passes on the strength of the reference's fp32-vs-fp64 spread -- bounded in number for every fixture but the
+    # two OPEN ones below (the c = 32 fixtures of test_full_width_net_every_gradient have no escape at all)
     print('%s: %d of %d full gradients used the conditioning escape: %s' % (tag, len(escaped), len(full64), escaped[:4]))
     worst_full = max((float(np.abs(got[k] - e64).max()) / max(float(np.abs(e64).max()), 1e-3 * top), k) for k, e64 in full64.items())
-    margins = {'full_gradients': len(full64), 'used_conditioning_escape': len(escaped), 'escape_allowed': max(2, len(full64) // 4),
+    # OPEN fixtures: one ReLU flip near the loss moves EVERY tensor of these two by a few 1e-3 -- measured in round 3 when the
+    # fused architecture tables changed the mixing weights by 1e-7 (tools/diag_archmix.py; the oracle moves as far under 1e-6
+    # noise: nets_spread.npz) -- so their counts are recorded, and their per-tensor bound above carries the measured
+    # conditioning.  Everywhere else the counts are pinned at what a run shows (0 escapes, <= 10 norm outliers).  The
+    # depth-5 statement that CAN fail is test_full_width_net_every_gradient[nets4-*] (c = 32, every tensor to 1e-3).
+    open_fixture = tag in OPEN_WHOLE_NET
+    escape_allowed = None if open_fixture else 2
+    if not open_fixture:
+        assert len(escaped) <= escape_allowed, '%s: %d gradient tensors used the conditioning escape (%d allowed): %s' % (
+            tag, len(escaped), escape_allowed, escaped[:4])
+    margins = {'full_gradients': len(full64), 'used_conditioning_escape': len(escaped), 'escape_allowed': escape_allowed,
                'worst_full_gradient_vs_fp64': worst_full[0], 'worst_full_gradient': worst_full[1],
-               'escape_count_is_recorded_not_bounded': True,
+               'escape_count_is_recorded_not_bounded': open_fixture,
                'escaped': [{'tensor': k, 'gpu_vs_fp64': a, 'reference_fp32_vs_fp64': b, 'gpu_vs_reference_fp32': c} for k, a, b, c in escaped],
                'worst_oracle_spread': max(spread.values()) if spread else None,
                'bound': 'max(2e-4, 10 x |ref32 - ref64|, 4 x the oracle\'s own spread under 1e-6 perturbations) of the tensor scale per tensor; '
                         'escape = beyond 1e-3 of fp64 AND beyond 2e-4 of the reference fp32 run'}
-    # (the count is recorded, not bounded: one ReLU flip near the loss moves EVERY tensor of such a fixture by a few 1e-3 -- seen when
-    # the mixing weights changed by 1e-7 in round 3 -- and the per-tensor bound above already knows the fixture's conditioning)
     d32, d64 = gio.digest(z, tag + '/grad/'), gio.digest(z, tag + '/grad64/')
     assert set(d32) == set(got)
     top = max(v[1] for v in d64.values())
     outliers = []
+    norm_bound = 1e-1 if open_fixture else 2e-2
     for k, (_, l2_64) in d64.items():
         scale = max(l2_64, 1e-3 * top)
         ref_err = abs(d32[k][1] - l2_64) / scale
         gpu_err = abs(float(np.sqrt((got[k].astype(np.float64) ** 2).sum())) - l2_64) / scale
-        # (norms move with the same ReLU flips as the full tensors above: 1e-1 catches a lost or doubled contribution, the
-        # outliers beyond the tight bound are recorded in the margins file)
-        assert gpu_err <= max(1e-1, 3 * ref_err), '%s |grad| %s: gpu %.2e, reference fp32 %.2e' % (tag, k, gpu_err, ref_err)
+        # (a lost or doubled contribution is O(1); norms of the open fixtures move with the same ReLU flips as their tensors)
+        assert gpu_err <= max(norm_bound, 3 * ref_err), '%s |grad| %s: gpu %.2e, reference fp32 %.2e' % (tag, k, gpu_err, ref_err)
         if gpu_err > max(5e-4, 10 * ref_err):
             outliers.append((gpu_err, ref_err, k))
-    # batch-norm scale gradients are cancellation residues (sum(ds*z) - mean*sum(ds)); a few of the
-    # tensors amplify summation-order noise past the tight bound -- at most 2% may, none past 2e-2
-    margins.update({'gradient_norms': len(d64), 'norm_outliers': len(outliers), 'norm_outliers_allowed': max(2, len(d64) // 50),
+    # batch-norm scale gradients are cancellation residues (sum(ds*z) - mean*sum(ds)); a few of the tensors amplify
+    # summation-order noise past the tight bound -- at most 2 % may (none beyond 2e-2, asserted above), except in the open fixtures
+    outliers_allowed = None if open_fixture else max(2, len(d64) // 50)
+    if not open_fixture:
+        assert len(outliers) <= outliers_allowed, '%s: %d gradient norms beyond the tight bound (%d allowed): %s' % (
+            tag, len(outliers), outliers_allowed, sorted(outliers)[-3:])
+    margins.update({'gradient_norms': len(d64), 'norm_outliers': len(outliers), 'norm_outliers_allowed': outliers_allowed,
+                    'norm_bound': norm_bound,
                     'worst_norm_outliers': [{'tensor': k, 'gpu': a, 'reference_fp32': b} for a, b, k in sorted(outliers)[-3:]]})
     from conftest import record_margin
     record_margin('test_whole_net[%s-%s]' % (fixture, tag), **margins)

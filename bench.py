@@ -324,6 +324,7 @@ def bench_train_mode(mode, args, dev, rank, world, ref_ms):
                                                                                              a['flops'] / (a['ms'] * 1e-3) / 1e12))
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        lp_traffic, lp_source = pmc_traffic_lp(name) if mode == 'bf16x3' else (None, None)
         peak = BF16_PEAK_TFLOPS / terms                         # fp32-equivalent FLOP/s the pipe can deliver with `terms` MFMAs per product
         res = {'math': mode, 'dtype': {'bf16': 'bf16 operands (RNE), f32 accumulate, f32 storage',
                                        'bf16x3': 'f32 split into 2 bf16 planes, 3 MFMA products, f32 accumulate, f32 storage',
@@ -332,12 +333,27 @@ def bench_train_mode(mode, args, dev, rank, world, ref_ms):
                'steps': args.lp_steps, 'speedup_vs_f32_step': round(ref_ms / ms, 3), 'loss': float(loss.detach()),
                'all_conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / 2, 2),
                'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
-                            'frac': round(tf / peak, 4), 'traffic': None, 'launches': a['launches'],
+                            'frac': round(tf / peak, 4), 'traffic': lp_traffic, 'traffic_source': lp_source, 'launches': a['launches'],
                             'avg_launch_ms': round(a['ms'] / a['launches'], 4),
                             'peak_convention': '2.5 PFLOP/s dense bf16 MFMA / %d MFMA products per fp32 product' % terms}}
         return res
     finally:
         F.set_math(prev)
+
+
+def _schedule_info(*passes):
+    """How the captured passes are replayed: by the lane scheduler (macro-grid columns on their own streams, csrc/sched.hip) --
+    lanes, segments and cross-lane dependencies per pass -- or by the runtime's graph replay on one stream."""
+    info = []
+    for fb in passes:
+        for sched in (getattr(fb, 'sched', None), getattr(fb, 'sched_tail', None)):
+            if sched is not None:
+                info.append(sched.info())
+    if not info:
+        return {'executor': 'one stream (eager or the runtime\'s graph replay)', 'lanes': 1}
+    return {'executor': 'lane scheduler: every column of up cells on a stream of its own, the captured pass replayed as '
+                        'single-branch graph segments with an event per cross-lane dependency (senas_amd/grid.py, csrc/sched.hip)',
+            'lanes': max(i['lanes'] for i in info), 'passes': info}
 
 
 def timed(step, steps, world, dev):
@@ -364,7 +380,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of kernel ``name`` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
     separate runs over this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; aggregated by
     tools/pmc_traffic.py).  Returns (bytes or None, source)."""
-    for fname in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+    for fname in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             pmc = json.load(open(path))
@@ -380,11 +396,28 @@ def pmc_traffic(name):
     return None, None
 
 
+def pmc_traffic_lp(name):
+    """pmc_traffic for the bf16x3 mode's dominant kernel (the committed --profile-math bf16x3 counter passes)."""
+    for fname in ('r4_pmc_traffic_bf16x3.json', 'r3_pmc_traffic_bf16x3.json'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+            rec = pmc['kernels'].get(name)
+            if rec is None:
+                close = [v for k, v in pmc['kernels'].items() if k.split('<')[0] == name.split('<')[0]]
+                rec = max(close, key=lambda v: v['launches']) if close else None
+            if rec:
+                return int((2 * rec['fetch_kb_avg'] + rec['write_kb_avg']) * 1024), \
+                    'profiles/%s (rocprofv3 --pmc passes of bench.py --profile-math bf16x3; not measured in this run)' % fname
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def search_traffic():
     """HBM bytes per search step from the committed rocprofv3 --pmc passes over tools/search_profile.py (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950; tools/pmc_traffic.py --all --steps N), with the time of the
     three heaviest kernel families from the committed steady-state table.  Returns (bytes or None, source, families)."""
-    for fname in ('r3_pmc_traffic_search.json',):
+    for fname in ('r4_pmc_traffic_search.json', 'r3_pmc_traffic_search.json'):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             pmc = json.load(open(path))
@@ -457,10 +490,14 @@ def main():
     # per-kernel HIP-event timing: the same pass run eagerly right after the timed region (events cannot
     # be read back from inside a replayed graph; kernel durations are the same in both modes)
     probe_steps = 2
+    schedule = _schedule_info(step.fb)
     step.fb._collectives = False                                # (no collective inside the probe passes)
     F.TIMER = F.KernelTimer()                                   # (a pair launch is one span: one kernel instance, two problems' flops)
+    from senas_amd import grid
+    lanes_on, grid.Lanes.enabled = grid.Lanes.enabled, False    # (one stream: a span must not see another lane's kernel beside its own)
     for _ in range(probe_steps):
         step.fb._eager()
+    grid.Lanes.enabled = lanes_on
     timer, F.TIMER = F.TIMER, None
     step.fb._collectives = True
     images = args.batch * world * args.steps
@@ -516,7 +553,7 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: SenasModel README genotype (senas_node_4), c=32 depth=5, '
                                '%dx1x%dx%d per GPU, fp32' % (args.batch, args.size, args.size),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'loss': float(loss.detach()),
-                   'hip_graph': bool(step.graphed), 'timed_region_s': round(elapsed, 3),
+                   'hip_graph': bool(step.graphed), 'timed_region_s': round(elapsed, 3), 'schedule': schedule,
                    'allreduce_overlapped_with_backward': bool(step.fb.graph_tail is not None)},
         'roofline': roof,
     }
@@ -638,7 +675,8 @@ def bench_search(dev, steps, rank, world, use_graph=True):
                         'convention': '4 img x 5.690 GB (weight pass, fwd+bwd) + 4 img x 2/3 x 5.690 GB (architecture pass: '
                                       'weights frozen, forward + data gradients only); whole step, not one kernel -- the step is '
                                       'thousands of 3-40 us launches, no single kernel carries more than a few percent',
-                        'graph_nodes_per_step': search.graph_nodes()}}
+                        'graph_nodes_per_step': search.graph_nodes()},
+           'schedule': _schedule_info(search.fb_arch, search.fb)}
     search.close()
     return res
 

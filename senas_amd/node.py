@@ -207,8 +207,23 @@ def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=
     slice of the cell's concatenation buffer (followed by ``zero_pad`` zero channels); with ``dense`` False nothing else is
     written and the slice itself is returned."""
     T = len(terms)
-    if T == 0 or T > _lib.MAX_TERMS:
-        raise SenasHipError('bn_combine: %d terms (supported: 1..%d)' % (T, _lib.MAX_TERMS))
+    if T == 0:
+        raise SenasHipError('bn_combine: no terms')
+    if T > _lib.MAX_TERMS:
+        # more addends than one launch describes (a node with six inputs of a ``--meta_node_num 5`` search cell has 36,
+        # experiments/search_arc.py:38-44): the first SENAS_MAX_TERMS as a partial sum without activation, the rest on top of it
+        # as their residual -- the same sum, one more pass over the partial result
+        head, tail = terms[:_lib.MAX_TERMS], terms[_lib.MAX_TERMS:]
+        if isinstance(mix, F.SharedMix):
+            if mix.count != T:
+                raise SenasHipError('bn_combine: %d shared mixing weights for %d terms' % (mix.count, T))
+            mix_h, mix_t = F.SharedMix(mix.M, mix.off, len(head), mix.dM), F.SharedMix(mix.M, mix.off + len(head), len(tail), mix.dM)
+        elif mix is not None:
+            mix_h, mix_t = mix[:len(head)], mix[len(head):]
+        else:
+            mix_h = mix_t = None
+        part = bn_combine(head, mix=mix_h, residual=residual, relu=False)
+        return bn_combine(tail, mix=mix_t, residual=part, relu=relu, out_stats=out_stats, cat=cat)
     real = [t for t, tm in enumerate(terms) if tm.z is not None]
     se_ids = [t for t, tm in enumerate(terms) if tm.se is not None]
     ref = next((tm.z for tm in terms if tm.z is not None), residual)

@@ -6,7 +6,7 @@ scale and 95 % of the tensors by more than 2.5e-4 -- every one of 7 seeds, at 2x
 (tests/golden/make_golden.py round4-search), so no whole-net fixture of this depth can hold a gradient to
 1e-3.  A single cell is well conditioned.  So the network is checked CELL BY CELL in its own operating regime: the oracle runs
 the whole pass once and hands every cell of the HIP network the inputs the oracle's cell saw and the gradient the oracle's cell
-output received; the cell's output, both input gradients and every parameter gradient must then match the oracle's to 2e-4 of
+output received; the cell's output, both input gradients and every parameter gradient must then match the oracle's to 5e-5 of
 the tensor scale (north_star: 1e-3).  A systematic error of a few 1e-3 in any cell of the depth-5 network -- its 2 x 2 maps at
 the bottom, its 128-channel skip inputs at the top -- fails here; the wiring BETWEEN the cells is what the logits, loss and
 trajectory tests hold (search/senas_search.py:96-107, search/cell.py:92-110, models/senas_model.py:50-64,160-175)."""
@@ -16,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-REL = 2e-4
+REL = 5e-5
 
 
 def dev():

@@ -1690,9 +1690,11 @@ def test_pw_multi_vs_torch(case):
         close(dconvs[t].weight.grad, refs[t].weight.grad.numpy(), 'dw %d' % t, rel=2e-4)
 
 
-@pytest.mark.parametrize('nodes,stacked', [(4, True), (2, True), (3, False)])
+@pytest.mark.parametrize('nodes,stacked', [(4, True), (2, True), (3, False), (5, True)])
 def test_supernet_other_node_counts_vs_oracle(nodes, stacked):
-    """The search cell with 4 nodes (states 0 and 1 feed FOUR edges: the widest stacks and batched launches: 32 -> 32
+    """``--meta_node_num`` (experiments/search_arc.py:38-44): 5 nodes -- the last node has six inputs, 36 addends: more than one
+    node launch describes (SENAS_MAX_TERMS 32), so it runs as a partial sum + the rest on top (node.bn_combine); five edges
+    leave states 0 and 1, beyond the widest stack.  The search cell with 4 nodes (states 0 and 1 feed FOUR edges: the widest stacks and batched launches: 32 -> 32
     stacked candidates, 8 DepSepConv candidates per state, 30 terms on the last node), with 2 nodes, and with the
     state-major execution switched off (every candidate launched on its own): forward + backward + architecture gradients
     against the CPU oracle, c=32, depth 3, 2x1x32x32."""

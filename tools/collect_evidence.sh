@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's evidence set, collected in one gpurun call (see profiles/README.md for what each file is):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh r3'
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh r4'
 # Writes under gpurun_out/<tag>/; copy the summaries into profiles/ by hand (tools/README.md).
 set -e -o pipefail
 tag=${1:-rX}
@@ -33,6 +33,11 @@ python3 tools/pmc_traffic.py $out/pmcFx3 $out/pmcWx3 $out/pmc_traffic_bf16x3.jso
 # (search_profile.py --eager: 2 warm-up + 2 timed steps, all launched eagerly: 4 steps in the counters)
 python3 tools/pmc_traffic.py $out/spF $out/spW $out/pmc_traffic_search.json --all --steps 4 > $out/pmc_traffic_search.txt
 cp $out/stats/*kernel_stats.csv $out/kernel_stats.csv
+# what really overlaps under replay (a tracing profiler serialises the hardware queues): device time stamps per cell
+{ echo "# tools/lane_timeline.py search --serial (every cell on one stream, the runtime's graph replay)"; python3 tools/lane_timeline.py search --serial 2>/dev/null | grep -v amdgpu;
+  echo; echo "# tools/lane_timeline.py search (columns of up cells on lanes, lane scheduler)"; python3 tools/lane_timeline.py search 2>/dev/null | grep -v amdgpu; } > $out/search_by_level.txt
+{ echo "# tools/lane_timeline.py train --serial"; python3 tools/lane_timeline.py train --serial 2>/dev/null | grep -v amdgpu;
+  echo; echo "# tools/lane_timeline.py train (lanes + lane scheduler)"; python3 tools/lane_timeline.py train 2>/dev/null | grep -v amdgpu; } > $out/train_by_level.txt
 # the bench line last: its `traffic` fields are read from the counter aggregates of THIS run
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 cp $out/pmc_traffic_search.json profiles/${tag}_pmc_traffic_search.json

@@ -62,10 +62,15 @@ def timing(steps):
     args = bench.parse_args(['--steps', str(steps), '--search-steps', str(steps), '--no-cpu-baseline', '--lp-steps', '0'])
     only = os.environ.get('LANES_ONLY')
     modes = (True,) if only else (False, True)
-    for lanes in modes:
-        grid.Lanes.enabled = lanes
-        s = bench.bench_search(dev, steps, 0, 1)
-        print(json.dumps({'lanes': lanes, 'search_ms': s['ms_per_step'], 'nodes': s['roofline'].get('graph_nodes_per_step')}), flush=True)
+
+    def search_leg():
+        for lanes in modes:
+            grid.Lanes.enabled = lanes
+            s = bench.bench_search(dev, steps, 0, 1)
+            print(json.dumps({'lanes': lanes, 'search_ms': s['ms_per_step'], 'nodes': s['roofline'].get('graph_nodes_per_step')}), flush=True)
+
+    if not os.environ.get('TRAIN_FIRST'):
+        search_leg()
     from senas_amd.loss import SegmentationLosses
     from senas_amd.step import TrainStep
     for lanes in modes:
@@ -85,6 +90,8 @@ def timing(steps):
         ms = 1e3 * (time.perf_counter() - t0) / steps
         step.close()
         print(json.dumps({'lanes': lanes, 'train_ms': round(ms, 3), 'loss': float(loss)}), flush=True)
+    if os.environ.get('TRAIN_FIRST'):
+        search_leg()
 
 
 if __name__ == '__main__':

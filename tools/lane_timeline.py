@@ -93,6 +93,13 @@ def main():
     step()
     torch.cuda.synchronize()
     rows = rec.read()
+    if '--order' in sys.argv:
+        # every stamp of the replay in time order (name, direction): tools/cell_kernels.py matches them with the stamp kernels of
+        # a rocprofv3 --kernel-trace of this very command to cut the trace into cells
+        import json
+        seq = sorted([(f, n, 'f') for n, f, b in rows if f] + [(b, n, 'b') for n, f, b in rows if b])
+        with open(sys.argv[sys.argv.index('--order') + 1], 'w') as fh:
+            json.dump([[n, d] for _, n, d in seq], fh)
     passes = split_passes(rows)
     titles = ['architecture pass (weights frozen)', 'weight pass'] if what == 'search' else ['train step']
     for rows_, title in zip(passes, titles):

@@ -60,7 +60,7 @@ static void sched_free(Sched* s) {
 // more than four busy queues made every step slower (measured: profiles/r4_lanes_queues.txt).  So the pool is built by
 // measurement: candidate streams are created one by one and a candidate is kept only if a 150 us spin kernel on it overlaps
 // with the same kernel on every stream already kept.  Never destroyed (process lifetime).
-__global__ void lane_spin_kernel(long long ticks) {
+__global__ void lane_probe_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) {}
 }
@@ -77,8 +77,8 @@ static bool lanes_overlap(hipStream_t a, hipStream_t b) {
         (void)hipEventCreate(&e1);
         (void)hipEventCreateWithFlags(&eb, hipEventDisableTiming);
         (void)hipEventRecord(e0, a);
-        hipLaunchKernelGGL(lane_spin_kernel, dim3(1), dim3(1), 0, a, ticks);
-        hipLaunchKernelGGL(lane_spin_kernel, dim3(1), dim3(1), 0, b, ticks);
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(1), 0, a, ticks);
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(1), 0, b, ticks);
         (void)hipEventRecord(eb, b);
         (void)hipStreamWaitEvent(a, eb, 0);
         (void)hipEventRecord(e1, a);

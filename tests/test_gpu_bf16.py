@@ -189,19 +189,30 @@ def test_train_step_graph_in_bf16x3_matches_eager(math_mode):
     x = torch.randn(2, 1, 128, 128, generator=gen).to(dev())
     y = torch.randint(0, 2, (2, 128, 128), generator=gen).to(dev())
     crit = SegmentationLosses('dice_ce')
-    losses = {}
-    for mode in ('f32', 'bf16x3'):
+    losses, weights = {}, {}
+    for mode, graphed in (('f32', True), ('bf16x3', True), ('bf16x3', False)):
         math_mode(mode)
         net = copy.deepcopy(base).to(dev()).train()
         opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.9)
-        step = TrainStep(net, crit, opt, x, y, use_graph=True)
+        step = TrainStep(net, crit, opt, x, y, use_graph=graphed)
         try:
-            assert step.graphed
+            assert step.graphed == graphed
             if mode != 'f32':
                 assert step.fb.packer.n_lp > 0, 'the packer holds no bf16 images'
-            losses[mode] = [float(step()) for _ in range(3)]
+            losses[(mode, graphed)] = [float(step()) for _ in range(3)]
+            torch.cuda.synchronize()
+            weights[(mode, graphed)] = {k: v.detach().clone() for k, v in net.state_dict().items() if v.is_floating_point()}
         finally:
             step.close()
-    for a, b in zip(losses['f32'], losses['bf16x3']):
+    for a, b in zip(losses[('f32', True)], losses[('bf16x3', True)]):
         assert abs(a - b) <= 1e-4 * abs(a), losses
-    assert losses['f32'][2] < losses['f32'][0]
+    assert losses[('f32', True)][2] < losses[('f32', True)][0]
+    # the captured step (packed bf16 images refreshed inside the graph, senas_pack_batched_lp) against the SAME mode launched
+    # eagerly (images repacked per step outside any graph): same kernels on the same images -- losses and weights agree to the
+    # summation order of atomics, step by step; a stale or wrongly laid-out image in the graph would not
+    for a, b in zip(losses[('bf16x3', True)], losses[('bf16x3', False)]):
+        assert abs(a - b) <= 2e-6 * abs(a), losses
+    wg, we = weights[('bf16x3', True)], weights[('bf16x3', False)]
+    for k in wg:
+        scale = float(we[k].abs().max()) + 1e-12
+        assert float((wg[k] - we[k]).abs().max()) <= 1e-6 + 1e-4 * scale, k

@@ -16,6 +16,8 @@
 // stream of its own).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <mutex>
 #include <queue>
@@ -130,6 +132,26 @@ static void lane_pool_grow(int want) {
 // consumer <- producer, the dependency that was meant.
 __global__ void relay_marker_kernel() {}
 
+// A captured 1-D memset as a kernel: count elements of esz bytes (1, 2 or 4) set to the low esz bytes of value; dst is aligned
+// to esz (it is an array of such elements), so every aligned 32-bit word holds whole elements and takes the replicated pattern.
+__global__ void sched_fill_kernel(void* dst, unsigned long long count, unsigned value, int esz) {
+    const unsigned long long bytes = count * (unsigned long long)esz;
+    unsigned pattern = value;
+    if (esz == 1) { pattern &= 0xffu; pattern |= pattern << 8; pattern |= pattern << 16; }
+    else if (esz == 2) { pattern &= 0xffffu; pattern |= pattern << 16; }
+    unsigned char* base = reinterpret_cast<unsigned char*>(dst);
+    unsigned long long head = (4 - (reinterpret_cast<uintptr_t>(base) & 3)) & 3;      // bytes in front of the first aligned word
+    if (head > bytes) head = bytes;
+    const unsigned long long words = (bytes - head) / 4;
+    const unsigned long long tail0 = head + words * 4;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned* w = reinterpret_cast<unsigned*>(base + head);
+    for (unsigned long long i = tid; i < words; i += stride) w[i] = pattern;
+    for (unsigned long long i = tid; i < head; i += stride) base[i] = (unsigned char)(value >> (8 * (i % esz)));
+    for (unsigned long long i = tail0 + tid; i < bytes; i += stride) base[i] = (unsigned char)(value >> (8 * (i % esz)));
+}
+
 using namespace senas;
 
 extern "C" int senas_relay_marker(void* stream) {
@@ -172,11 +194,13 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
                 if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { marker[i] = gone[i] = 1; ++S->n_marker; }
             }
         }
-        for (size_t i = 0; i < n; ++i) {
-            if (!marker[i]) continue;
-            auto& ps = par0[i];
-            for (int p : ps) if (marker[p]) chi0[p].erase(std::remove(chi0[p].begin(), chi0[p].end(), (int)i), chi0[p].end());
-            ps.erase(std::remove_if(ps.begin(), ps.end(), [&](int p) { return marker[p] != 0; }), ps.end());
+        if (getenv("SENAS_SCHED_CUT_MARKERS")) {      // experiment only: UNSAFE (see the note at relay_marker_kernel)
+            for (size_t i = 0; i < n; ++i) {
+                if (!marker[i]) continue;
+                auto& ps = par0[i];
+                for (int p : ps) if (marker[p]) chi0[p].erase(std::remove(chi0[p].begin(), chi0[p].end(), (int)i), chi0[p].end());
+                ps.erase(std::remove_if(ps.begin(), ps.end(), [&](int p) { return marker[p] != 0; }), ps.end());
+            }
         }
         // contract in creation order: a removed node hands its parents to its children
         for (size_t i = 0; i < n; ++i) {
@@ -210,6 +234,11 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         par0.swap(np);
         chi0.swap(nc);
         n = raw.size();
+    }
+    if (getenv("SENAS_SCHED_VERBOSE")) {
+        size_t back = 0, edges = 0;
+        for (size_t i = 0; i < n; ++i) for (int p : par0[i]) { ++edges; if ((size_t)p > i) ++back; }
+        fprintf(stderr, "[sched] %zu nodes, %zu edges, %zu edges point from a later node of hipGraphGetNodes to an earlier one\n", n, edges, back);
     }
     // topological order, ties broken by the runtime's own node order (creation order)
     std::vector<int> indeg(n), topo, pos(n);
@@ -313,7 +342,30 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
                     case hipGraphNodeTypeMemset: {
                         hipMemsetParams p;
                         SCHED_HIP(hipGraphMemsetNodeGetParams(src, &p), "hipGraphMemsetNodeGetParams");
-                        SCHED_HIP(hipGraphAddMemsetNode(&made, sg.graph, deps, nd, &p), "hipGraphAddMemsetNode");
+                        if (getenv("SENAS_SCHED_VERBOSE") && S->n_memset < 4)
+                            fprintf(stderr, "[sched] memset node: dst %p elementSize %u width %zu height %zu pitch %zu value %u\n", p.dst,
+                                    p.elementSize, p.width, p.height, p.pitch, p.value);
+                        // a 1-D fill (what hipMemsetAsync / hipMemsetD32Async capture) is re-issued as a kernel of this library: a
+                        // memset node rebuilt from these parameters did NOT fill its buffer on this runtime (round 4: the zeroed
+                        // scratch of the atomically accumulated weight gradients stayed dirty from the second replay on)
+                        if (p.height <= 1 && (p.elementSize == 1 || p.elementSize == 2 || p.elementSize == 4)) {
+                            void* dst = p.dst;
+                            unsigned long long count = (unsigned long long)p.width;
+                            unsigned value = p.value;
+                            int esz = (int)p.elementSize;
+                            void* args[] = {&dst, &count, &value, &esz};
+                            hipKernelNodeParams kp{};
+                            kp.func = reinterpret_cast<void*>(sched_fill_kernel);
+                            const unsigned long long words = (count * esz + 3) / 4;
+                            kp.gridDim = dim3((unsigned)std::min<unsigned long long>((words + 255) / 256, 4096ull));
+                            kp.blockDim = dim3(256);
+                            kp.sharedMemBytes = 0;
+                            kp.kernelParams = args;
+                            kp.extra = nullptr;
+                            SCHED_HIP(hipGraphAddKernelNode(&made, sg.graph, deps, nd, &kp), "hipGraphAddKernelNode (fill)");
+                        } else {
+                            SCHED_HIP(hipGraphAddMemsetNode(&made, sg.graph, deps, nd, &p), "hipGraphAddMemsetNode");
+                        }
                         ++S->n_memset;
                         break;
                     }

@@ -6,6 +6,7 @@ and the autograd graph only; every pass over an activation tensor is a libsenas_
 
 There is no CPU path: a non-CUDA tensor raises.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -213,7 +214,9 @@ MIX_SLOTS = 32          # rows of a d loss / d M table: one per cell of a kind w
 
 
 def join_lanes():
-    """Make the current stream wait for everything launched so far on the lanes of the running pass."""
+    """Make the current stream wait for everything launched so far on the lanes of the running pass (the queued weight
+    gradients are launched first)."""
+    flush_wgrads()
     if not LANES:
         return
     cur = torch.cuda.current_stream()
@@ -228,6 +231,70 @@ def join_lanes():
                 if not torch.cuda.is_current_stream_capturing():
                     continue
         cur.wait_stream(s)
+
+
+# A stream beside the pass for weight-gradient kernels whose results go straight into the flat gradient buffer (set by a step
+# driver while its pass runs, else None).  Nothing downstream of a convolution's backward pass reads d loss / d w before the end
+# of the pass, but on one stream every weight-gradient launch sits between a data gradient and its consumer: a third of the
+# launches on the backward critical path of a search cell.  They are QUEUED on the host instead and launched on the lane at the
+# end of the cell's backward pass (one stream wait per cell: a wait per kernel costs more than it buys -- measured).
+WLANE = None
+_WQ = []            # (closure, tensors it reads) of the weight-gradient launches waiting for the next flush
+
+
+def run_wgrad(autograd_grads, tensors, fn):
+    """Run ``fn`` (a weight-gradient launch) now, or -- if there is a weight-gradient lane and every destination is a view of
+    the flat gradient buffer (``autograd_grads`` all None: autograd is handed nothing, nobody reads the result before
+    GradSink.finish() has joined the lanes) -- queue it for the lane."""
+    if WLANE is None or any(g is not None for g in autograd_grads):
+        fn()
+    else:
+        _WQ.append((fn, [t for t in tensors if t is not None and t.is_cuda]))
+
+
+def flush_wgrads():
+    """Launch the queued weight gradients on the lane, behind what the current stream holds so far."""
+    if not _WQ:
+        return
+    q = list(_WQ)
+    del _WQ[:]
+    W = WLANE
+    cur = torch.cuda.current_stream()
+    if W is None or W.device != cur.device:
+        for fn, _ in q:
+            fn()
+        return
+    W.wait_stream(cur)
+    LANES.add(W)
+    with torch.cuda.stream(W):
+        for fn, tensors in q:
+            for t in tensors:
+                t.record_stream(W)           # (the caching allocator must not hand the block on while the lane reads it)
+            fn()
+
+
+class _CellIn(torch.autograd.Function):
+    """Identity on a cell's input; on the way back it marks the end of the cell's backward pass: the weight gradients the cell
+    queued are launched on the weight-gradient lane."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_wgrads()
+        return g
+
+
+def cell_in(x):
+    if WLANE is None or not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        return x
+    y = _CellIn.apply(x)
+    st = getattr(x, '_senas_stats', None)
+    if st is not None:
+        y._senas_stats = st
+    return y
 
 
 def wgrad_dest(w):
@@ -317,11 +384,11 @@ def _conv_wgrad(g, x, in_relu, dy, w, dest=None):
     return dw
 
 
-def _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb):
+def _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb, da, db):
     """The weight gradients of the two convolutions of a pair as ONE first-stage launch (senas_conv2d_bwd_weight_pair); where
-    the two share no kernel, the two single calls.  Returns what autograd is handed for wa and wb."""
+    the two share no kernel, the two single calls.  da, db: the destinations (wgrad_dest).  Returns what autograd is handed for
+    wa and wb."""
     L = _lib.lib()
-    da, db = wgrad_dest(wa), wgrad_dest(wb)
     sizes = []
     for g in (ga, gb):
         nbytes, zero = C.c_int64(), C.c_int32()
@@ -395,6 +462,11 @@ class _Conv2d(torch.autograd.Function):
             return (None,) * 10
         dy = nhwc(dy)
         dx = dw = None
+        if ctx.needs_input_grad[1]:                       # (queued for the weight-gradient lane where there is one)
+            dest = wgrad_dest(w)
+            dw = dest[1]
+            in_relu = ctx.in_relu
+            run_wgrad((dw,), (x, dy), lambda: _conv_wgrad(g, x, in_relu, dy, w, dest=dest))
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
             ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
@@ -407,8 +479,6 @@ class _Conv2d(torch.autograd.Function):
                     rc = L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
                                                  x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream())
                 _lib.check(rc, 'senas_conv2d_bwd_data')
-        if ctx.needs_input_grad[1]:
-            dw = _conv_wgrad(g, x, ctx.in_relu, dy, w)
         return dx, dw, None, None, None, None, None, None, None, None
 
 
@@ -469,6 +539,23 @@ class _Conv2dPair(torch.autograd.Function):
         dya = nhwc(dya) if dya is not None else None
         dyb = nhwc(dyb) if dyb is not None else None
         dxa = dxb = None
+        # the weight gradients: queued for the weight-gradient lane where there is one (see _Conv2d.backward)
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and dya is not None and dyb is not None and wa.data_ptr() != wb.data_ptr():
+            da, db = wgrad_dest(wa), wgrad_dest(wb)
+            dwa, dwb = da[1], db[1]
+            in_relu = ctx.in_relu
+            run_wgrad((dwa, dwb), (x, dya, dyb), lambda: _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb, da, db))
+        else:
+            dwa = dwb = None
+            in_relu = ctx.in_relu
+            if ctx.needs_input_grad[2] and dya is not None:
+                da = wgrad_dest(wa)
+                dwa = da[1]
+                run_wgrad((dwa,), (x, dya), lambda: _conv_wgrad(ga, x, in_relu, dya, wa, dest=da))
+            if ctx.needs_input_grad[3] and dyb is not None:
+                db = wgrad_dest(wb)
+                dwb = db[1]
+                run_wgrad((dwb,), (x, dyb), lambda: _conv_wgrad(gb, x, in_relu, dyb, wb, dest=db))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             nb = int(L.senas_conv2d_ws_bytes(C.byref(ga)))
             rc = _lib.UNSUPPORTED
@@ -496,11 +583,6 @@ class _Conv2dPair(torch.autograd.Function):
                 dxa, dxb = outs
             else:
                 _lib.check(rc, 'senas_conv2d_bwd_data_pair')
-        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and dya is not None and dyb is not None and wa.data_ptr() != wb.data_ptr():
-            dwa, dwb = _conv_wgrad_pair(ga, gb, x, ctx.in_relu, dya, dyb, wa, wb)
-        else:
-            dwa = _conv_wgrad(ga, x, ctx.in_relu, dya, wa) if (ctx.needs_input_grad[2] and dya is not None) else None
-            dwb = _conv_wgrad(gb, x, ctx.in_relu, dyb, wb) if (ctx.needs_input_grad[3] and dyb is not None) else None
         return dxa, dxb, dwa, dwb, None, None, None, None, None, None, None
 
 
@@ -1096,23 +1178,27 @@ class _DwMulti(torch.autograd.Function):
         dys = [nhwc(d) if d is not None else torch.zeros((g.n, g.co, g.ho, g.wo), device=x.device).contiguous(memory_format=CL) for d in dys]
         dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
         dx = None
+        dws = [None] * k
+        if any(ctx.needs_input_grad[6:]):                 # (queued for the weight-gradient lane where there is one)
+            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
+            defer = may_defer(*dws)
+
+            def launch():
+                scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=x.device, dtype=torch.uint8)
+                dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
+                items = (_lib.SumItem * k)() if defer else None
+                _lib.check(L.senas_dwconv_pair_bwd_weight(C.byref(ga), ka, gbp, kb, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
+                           'senas_dwconv_pair_bwd_weight')
+                if items is not None:
+                    for t in range(k):
+                        one = _lib.SumItem()
+                        C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
+                        DEFER.append((one, scratch))
+            run_wgrad(dws, [x] + dys, launch)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=CL)
             wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
             _lib.check(L.senas_dwconv_pair_bwd_data(C.byref(ga), ka, gbp, kb, dyp, wp, dx.data_ptr(), _stream()), 'senas_dwconv_pair_bwd_data')
-        dws = [None] * k
-        if any(ctx.needs_input_grad[6:]):
-            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
-            scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=x.device, dtype=torch.uint8)
-            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            items = (_lib.SumItem * k)() if may_defer(*dws) else None
-            _lib.check(L.senas_dwconv_pair_bwd_weight(C.byref(ga), ka, gbp, kb, x.data_ptr(), dyp, dwp, scratch.data_ptr(), items, _stream()),
-                       'senas_dwconv_pair_bwd_weight')
-            if items is not None:
-                for t in range(k):
-                    one = _lib.SumItem()
-                    C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
-                    DEFER.append((one, scratch))
         return (dx, None, None, None, None, None) + tuple(dws)
 
 
@@ -1151,6 +1237,26 @@ class _DwMulti2(torch.autograd.Function):
             return (None,) * (8 + k)
         dev_ = xs[0].device
         dys = [nhwc(d) if d is not None else torch.zeros((g.n, g.co, g.ho, g.wo), device=dev_).contiguous(memory_format=CL) for d in dys]
+        dws = [None] * k
+        if any(ctx.needs_input_grad[8:]):                 # (queued for the weight-gradient lane where there is one)
+            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
+            defer = may_defer(*dws)
+
+            def launch():
+                gbp = C.byref(gb) if kb else None
+                scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=dev_, dtype=torch.uint8)
+                xp = (C.c_void_p * k)(*[xs[src[p]].data_ptr() for p in range(k)])
+                dyq = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
+                dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
+                items = (_lib.SumItem * k)() if defer else None
+                _lib.check(L.senas_dwconv_pair_bwd_weight_xs(C.byref(ga), ka, gbp, kb, None, xp, dyq, dwp, scratch.data_ptr(), items, _stream()),
+                           'senas_dwconv_pair_bwd_weight_xs')
+                if items is not None:
+                    for t in range(k):
+                        one = _lib.SumItem()
+                        C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
+                        DEFER.append((one, scratch))
+            run_wgrad(dws, list(xs) + dys, launch)
         dxs = [None, None]
         for i in range(2):
             if not ctx.needs_input_grad[i]:
@@ -1169,22 +1275,6 @@ class _DwMulti2(torch.autograd.Function):
                 rc = L.senas_dwconv_pair_bwd_data(C.byref(gb), len(pb), None, 0, dyp, wp, dx.data_ptr(), _stream())
             _lib.check(rc, 'senas_dwconv_pair_bwd_data')
             dxs[i] = dx
-        dws = [None] * k
-        if any(ctx.needs_input_grad[8:]):
-            dwt, dws = zip(*[wgrad_dest(w) for w in ws])
-            gbp = C.byref(gb) if kb else None
-            scratch = torch.empty(int(L.senas_dwconv_pair_ws_bytes(C.byref(ga), ka, gbp, kb)), device=dev_, dtype=torch.uint8)
-            xp = (C.c_void_p * k)(*[xs[src[p]].data_ptr() for p in range(k)])
-            dyp = (C.c_void_p * k)(*[d.data_ptr() for d in dys])
-            dwp = (C.c_void_p * k)(*[d.data_ptr() for d in dwt])
-            items = (_lib.SumItem * k)() if may_defer(*dws) else None
-            _lib.check(L.senas_dwconv_pair_bwd_weight_xs(C.byref(ga), ka, gbp, kb, None, xp, dyp, dwp, scratch.data_ptr(), items, _stream()),
-                       'senas_dwconv_pair_bwd_weight_xs')
-            if items is not None:
-                for t in range(k):
-                    one = _lib.SumItem()
-                    C.memmove(C.byref(one), C.byref(items[t]), C.sizeof(one))
-                    DEFER.append((one, scratch))
         return (dxs[0], dxs[1], None, None, None, None, None, None) + tuple(dws)
 
 

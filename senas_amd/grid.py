@@ -241,6 +241,7 @@ class MacroGrid(nn.Module):
         def call(name, module, kind, a, b):
             """run(...), between time stamps when a timeline is being taken (tools/lane_timeline.py)."""
             from . import functional as F
+            a, b = F.cell_in(a), F.cell_in(b)      # (the end of the cell's backward pass: its queued weight gradients go to their lane)
             if F.STAMPS is None:
                 return run(module, kind, a, b)
             return F.stamp(run(module, kind, F.stamp(a, name + '.in0'), F.stamp(b, name + '.in1')), name + '.out')

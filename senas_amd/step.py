@@ -13,6 +13,8 @@ With more than one rank the backward pass is captured as TWO graphs cut at the o
 graph has run -- are all-reduced while the second graph (down cells, stems) still runs; only the second, smaller
 all-reduce is exposed.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -57,7 +59,7 @@ class GraphedForwardBackward(object):
     the rest of backward."""
 
     def __init__(self, model, criterion, x, y, reducer, warmup=2, use_graph=True, packer=None, frozen=(), early=None,
-                 count_nodes=False, refresh=True):
+                 count_nodes=False, refresh=True, max_lanes=None):
         self.model, self.criterion, self.reducer = model, criterion, reducer
         # refresh=False: the caller guarantees that the packed / stacked weight images are current when the pass starts
         # (the weight pass of a search step right after the architecture pass: the weights have not moved in between)
@@ -67,8 +69,16 @@ class GraphedForwardBackward(object):
         self.loss = None
         self.graph = self.graph_tail = None
         self.sched = self.sched_tail = None        # lane schedulers of the captured passes (None: the runtime's own graph replay)
+        self.wlane = None                          # the weight-gradient lane of this driver's passes (functional.WLANE), or None
+        self.max_lanes = max_lanes                 # lanes of the scheduler (None: lanesched.MAX_LANES)
         self.frozen = [p for p in frozen if p.requires_grad]
         self.grid = _macro_grid(model)
+        if (self.grid is not None and Lanes.enabled and self.grid._depth > 2 and not getattr(self.grid, '_supervision', False)
+                and next(model.parameters()).is_cuda):
+            # weight-gradient kernels beside the pass (functional.wgrad_lane).  Not under deep supervision: the shared head
+            # receives several gradients per pass, and the later ones are accumulated by autograd into the view the first one's
+            # kernel writes
+            self.wlane = torch.cuda.Stream()
         if self.grid is not None and any(isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0 for m in model.modules()):
             # torch's graph replay advances the Philox offsets of the captured dropout draws; the lane scheduler replays the
             # captured launches as they are -- a network with dropout keeps the serial schedule and torch's own replay
@@ -95,11 +105,13 @@ class GraphedForwardBackward(object):
         if cut:
             self._cut_src, self._cut_leaf = [], []
             self.grid.cut = self._cut
+        F.WLANE = self.wlane if (self.grid is not None and self.grid.lanes and Lanes.enabled) else None
         try:
             loss = self.criterion(self.model(self.x), self.y)
             loss.backward()
             F.join_lanes()                # the macro grid's columns ran on their own streams (grid.Lanes): the flat gradient buffer is complete after this
         finally:
+            F.WLANE = None
             if cut:
                 self.grid.cut = None
             if not cut:
@@ -122,6 +134,7 @@ class GraphedForwardBackward(object):
     def _tail(self):
         """The rest of backward below the cut."""
         self.reducer.sink.resume()
+        F.WLANE = self.wlane if (self.grid is not None and self.grid.lanes and Lanes.enabled) else None
         try:
             leaves = [l for l in self._cut_leaf if l.requires_grad]
             pairs = [(s, l.grad) for s, l in zip(self._cut_src, leaves) if l.grad is not None]
@@ -129,6 +142,7 @@ class GraphedForwardBackward(object):
                 torch.autograd.backward([s for s, _ in pairs], [g for _, g in pairs])
             F.join_lanes()
         finally:
+            F.WLANE = None
             self._cut_src = self._cut_leaf = None
             for p in self.frozen:
                 p.requires_grad_(True)
@@ -172,17 +186,17 @@ class GraphedForwardBackward(object):
             self.loss = self._head()
         if self.count_nodes:
             self.nodes = _graph_nodes(graph)
-        if lanes:
-            self.sched = LaneSchedule(graph)
+        if lanes and not os.environ.get('SENAS_NO_SCHED'):
+            self.sched = LaneSchedule(graph, self.max_lanes)
         elif keep:
-            graph.instantiate()
+            graph.instantiate()              # (SENAS_NO_SCHED: diagnosis only -- the runtime's own executor on a multi-branch graph)
         if self.early is not None:
             tail = torch.cuda.CUDAGraph(keep_graph=True) if lanes else torch.cuda.CUDAGraph()
             with torch.cuda.graph(tail, pool=graph.pool(), capture_error_mode='thread_local'):
                 self._tail()
             self.graph_tail = tail
-            if lanes:
-                self.sched_tail = LaneSchedule(tail)
+            if lanes and not os.environ.get('SENAS_NO_SCHED'):
+                self.sched_tail = LaneSchedule(tail, self.max_lanes)
         reset_arena()
         self.graph = graph
         with torch.no_grad():
@@ -239,6 +253,9 @@ def _graph_nodes(graph):
         return None
 
 
+SEARCH_LANES = int(os.environ.get('SENAS_SEARCH_LANES', 5))
+
+
 def _model_stacks(model):
     return [sw for m in model.modules() if hasattr(m, 'stacked_weights') for sw in m.stacked_weights()]
 
@@ -270,13 +287,15 @@ class SearchStep(object):
         self.reducer = SinkReducer(self.sink, 0, last, world_size, process_group)
         self.arch_reducer = SinkReducer(self.sink, last, last, world_size, process_group)
         early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and last >= 2) else None
+        # five scheduler lanes on four hardware queues: the supernet's pass has six chains in flight (origin stream, four columns,
+        # weight gradients); measured 28.1 - 28.9 ms against 29.2 - 29.4 with four (profiles/r4_lanes_queues.txt)
         self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, packer=packer,
-                                              frozen=weights, count_nodes=count_nodes)
+                                              frozen=weights, count_nodes=count_nodes, max_lanes=SEARCH_LANES)
         # the weight pass does not repack: either the architecture pass just did, or __call__ does it (before alpha_begin)
         packer.refresh()
         self.packer = packer
         self.fb = GraphedForwardBackward(model, criterion, x, y, self.reducer, use_graph=use_graph, packer=packer, early=early,
-                                         count_nodes=count_nodes and early is None, refresh=False)
+                                         count_nodes=count_nodes and early is None, refresh=False, max_lanes=SEARCH_LANES)
         self.graphed = self.fb.graph is not None
         # static gradient addresses -> clip + SGD in two launches instead of ~110
         self.fused = optim.FusedClipSGD(weight_optimizer, grad_clip) if optim.supported(weight_optimizer) else None

@@ -164,13 +164,45 @@ def test_step_drivers_on_lanes_track_the_serial_eager_step(kind, lanes_switch):
         assert abs(a - b) <= 2e-5 * abs(a), (l0, l1)
     for k in s0:
         if s0[k].is_floating_point():
-            # three steps of lr ~5e-3 on gradients that agree to ~1e-5: to 1e-6 + 2e-4 of the tensor's scale.  The architecture
+            # three steps of lr ~5e-3 on gradients that agree to ~1e-5: to 5e-6 + 2e-4 of the tensor's scale.  The architecture
             # gradients of a c = 8 supernet are conditioned 1e4 worse (1e-7 on the mixing weights moves them
             # by 5e-4): 2e-2 of their scale here -- the tight statement is test_search_step_driver_trajectory against the oracle
             scale = float(s0[k].abs().max()) + 1e-12
             arch = k.startswith(('alphas', 'betas', 'gamma'))
-            bound = 2e-2 * scale if arch else 1e-6 + 2e-4 * scale
+            bound = 2e-2 * scale if arch else 5e-6 + 2e-4 * scale
             assert float((s0[k] - s1[k]).abs().max()) <= bound, (k, float((s0[k] - s1[k]).abs().max()), scale)
+
+
+@pytest.mark.parametrize('c,size', [(8, 64), (32, 64)])
+def test_replays_of_a_lane_scheduled_pass_agree(c, size):
+    """Every replay of the captured passes of a depth-5 search step gives the first replay's gradients (to the order of atomics).
+    A dependency lost between capture and replay does not show in the FIRST replay -- it still finds the warm-up pass's values
+    in memory -- but as garbage from the second on: found in round 4 when the scheduler cut the relay markers' chain and with it
+    the origin stream's own waits (csrc/sched.hip, note at relay_marker_kernel; c = 8: the 2-channel inner edges of the first
+    down cell, whose weight gradients are summed on the origin stream at the end of the pass)."""
+    from senas_amd.loss import SegmentationLosses
+    from senas_amd.senas_search import NAS
+    from senas_amd.step import SearchStep
+    torch.manual_seed(1)
+    net = NAS(1, c, 2, 5, meta_node_num=3, use_sharing=False, double_down_channel=False).to(dev()).train()
+    x, y = _batch(2, size, 5)
+    ow = torch.optim.SGD(net.parameters(), lr=0.0)
+    oa = torch.optim.SGD(net.arch_parameters(), lr=0.0)
+    drv = SearchStep(net, SegmentationLosses('dice_ce'), ow, oa, x.clone(), y.clone(), grad_clip=0.0)
+    assert drv.fb.sched is not None and drv.fb_arch.sched is not None
+    for fb in (drv.fb_arch, drv.fb):
+        runs = []
+        for _ in range(4):
+            fb()
+            torch.cuda.synchronize()
+            runs.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        top = max(float(v.abs().max()) for v in runs[0].values())
+        assert top > 0 and all(bool(torch.isfinite(v).all()) for v in runs[0].values())
+        for r in runs[1:]:
+            for k, v in runs[0].items():
+                scale = max(float(v.abs().max()), 1e-3 * top)
+                assert float((r[k] - v).abs().max()) <= 1e-4 * scale, (k, float((r[k] - v).abs().max()), scale)
+    drv.close()
 
 
 def test_a_network_with_dropout_keeps_the_serial_schedule():

@@ -224,6 +224,10 @@ int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* 
  * senas_relay_marker: an empty kernel launched on the capture's origin stream at every hand-over between two lanes; the
  * scheduler cuts the false marker -> marker chain the capture records and contracts the markers away (csrc/sched.hip).  */
 int senas_relay_marker(void* stream);
+/* A new non-blocking HIP stream of the current device (never destroyed).  The lanes of a captured pass must be streams of their
+ * own: torch hands its streams out of a pool of 32 round-robin, and two "different" torch streams that are one hipStream_t turn the
+ * star topology of the capture into lane-to-lane waits (the runtime then never returns from hipStreamEndCapture: csrc/sched.hip). */
+int senas_stream_create(void** out);
 int senas_sched_create(void* hip_graph, int max_lanes, void** out);
 int senas_sched_launch(void* sched, void* stream);
 int senas_sched_info(void* sched, int32_t* out8);

@@ -9,8 +9,9 @@
 // A linear graph on one stream is the path of that executor that has replayed this package's steps since round 1.
 //
 // So: take the captured hipGraph_t (never instantiated), read its nodes and edges, cover the DAG with at most L chains
-// ("lanes"), cut every chain where a dependency crosses lanes, rebuild every piece as a single-branch graph (kernel / memset
-// / memcpy nodes re-added from their own parameters, each depending on its predecessor only), and at launch time issue the
+// ("lanes"), cut every chain where a dependency crosses lanes, rebuild every piece as a single-branch graph (kernel nodes
+// re-added from their own parameters, 1-D memsets as a fill kernel of this library, a memcpy node as the one survivor of a
+// clone of the captured graph; each node depending on its predecessor only), and at launch time issue the
 // pieces in topological order on L streams with an event per cross-lane dependency.  Dependencies are exactly the captured
 // ones (+ the chain order inside a lane); memory safety is the capture's (torch's caching allocator saw every lane as a
 // stream of its own).
@@ -127,9 +128,12 @@ static void lane_pool_grow(int want) {
 
 // A hand-over between two lanes passes through the capture's origin stream (grid.Lanes: the star topology).  The origin stream
 // records no kernel between two hand-overs, so the runtime's capture bookkeeping makes every hand-over depend on the producers
-// of all earlier ones.  A marker launched on the origin stream at each hand-over gives the chain a node the scheduler can
-// recognise: it drops marker -> marker edges and then contracts the markers (and empty nodes) out of the graph, which leaves
-// consumer <- producer, the dependency that was meant.
+// of all earlier ones.  A marker launched on the origin stream at each hand-over gives that chain nodes the scheduler can
+// recognise and contract away.  CUTTING the chain at the markers (marker -> marker edges dropped, SENAS_SCHED_CUT_MARKERS) would
+// leave consumer <- producer, the dependency that was meant -- but a marker also absorbs every wait the origin stream itself
+// made since its last kernel (autograd's hand-overs TO the origin stream, join_lanes), and the origin's next real kernel
+// reaches those only through the chain: the cut loses them (measured: dirty weight gradients of the first down cell).  So the
+// chain is kept; telling the two kinds of children of a marker apart needs a marker on the consumer side too (not built).
 __global__ void relay_marker_kernel() {}
 
 // A captured 1-D memset as a kernel: count elements of esz bytes (1, 2 or 4) set to the low esz bytes of value; dst is aligned
@@ -153,6 +157,15 @@ __global__ void sched_fill_kernel(void* dst, unsigned long long count, unsigned 
 }
 
 using namespace senas;
+
+extern "C" int senas_stream_create(void** out) {
+    SENAS_REQUIRE(out != nullptr, "stream_create: bad argument");
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error("hipStreamCreateWithFlags", e); return SENAS_ELAUNCH; }
+    *out = st;
+    return SENAS_OK;
+}
 
 extern "C" int senas_relay_marker(void* stream) {
     hipLaunchKernelGGL(relay_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream));

@@ -213,6 +213,24 @@ LANES = set()
 MIX_SLOTS = 32          # rows of a d loss / d M table: one per cell of a kind within a pass (cells of different lanes never share one)
 
 
+_OWN_STREAMS = {}       # (device index, name) -> torch.cuda.ExternalStream over a hipStream_t of this library
+
+
+def own_stream(device, name):
+    """A HIP stream that is nobody else's, by (device, name): made once per process by senas_stream_create and wrapped for torch.
+    torch.cuda.Stream() hands out a pool of 32 streams round-robin -- after a few dozen step drivers a "new" stream IS one of the
+    lanes, and the capture's star topology (grid.Lanes) silently turns into lane-to-lane waits."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, name)
+    st = _OWN_STREAMS.get(key)
+    if st is None:
+        handle = C.c_void_p()
+        with torch.cuda.device(index):
+            _lib.check(_lib.lib().senas_stream_create(C.byref(handle)), 'senas_stream_create')
+        st = _OWN_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=torch.device('cuda', index))
+    return st
+
+
 def join_lanes():
     """Make the current stream wait for everything launched so far on the lanes of the running pass (the queued weight
     gradients are launched first)."""

@@ -90,16 +90,13 @@ class Lanes(object):
     harmless)."""
 
     enabled = True          # class-wide switch (False: every cell on the caller's stream, as the reference's loop)
-    _pool = {}              # device index -> streams
 
     def __init__(self, device, columns):
         from . import functional as F
         self.F = F
         self.main = torch.cuda.current_stream(device)
-        pool = Lanes._pool.setdefault(device.index, [])
-        while len(pool) < columns:
-            pool.append(torch.cuda.Stream(device))
-        self.streams = pool[:columns]
+        # (streams of this library's own, not torch.cuda.Stream(): see functional.own_stream)
+        self.streams = [F.own_stream(device, 'lane%d' % j) for j in range(columns)]
         self.events = {}
         self.used = []
 

@@ -78,7 +78,7 @@ class GraphedForwardBackward(object):
             # weight-gradient kernels beside the pass (functional.wgrad_lane).  Not under deep supervision: the shared head
             # receives several gradients per pass, and the later ones are accumulated by autograd into the view the first one's
             # kernel writes
-            self.wlane = torch.cuda.Stream()
+            self.wlane = F.own_stream(next(model.parameters()).device, 'wgrad')
         if self.grid is not None and any(isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0 for m in model.modules()):
             # torch's graph replay advances the Philox offsets of the captured dropout draws; the lane scheduler replays the
             # captured launches as they are -- a network with dropout keeps the serial schedule and torch's own replay

@@ -222,7 +222,7 @@ def test_a_network_with_dropout_keeps_the_serial_schedule():
     drv.close()
 
 
-@pytest.mark.parametrize('sharing,depth,nodes', [(False, 4, 3), (True, 4, 3), (False, 2, 3), (True, 3, 4), (False, 3, 4)])
+@pytest.mark.parametrize('sharing,depth,nodes', [(False, 4, 3), (True, 4, 3), (False, 2, 3), (True, 3, 4), (False, 3, 4), (False, 3, 5)])
 def test_arch_tables_against_the_torch_path(sharing, depth, nodes):
     """senas_arch_mix_fwd / _bwd (all softmaxes, the overlapping beta windows, both mixing matrices, the seven parameter
     gradients -- search/senas_search.py:252-260, search/cell.py:33-36,100-106) against NAS._mixing_weights + _EdgeMix on the
@@ -232,7 +232,7 @@ def test_arch_tables_against_the_torch_path(sharing, depth, nodes):
     from senas_amd.loss import SegmentationLosses
     from senas_amd.senas_search import NAS
     torch.manual_seed(11)
-    net = NAS(1, 8, 2, depth, meta_node_num=nodes, use_sharing=sharing, double_down_channel=False).to(dev()).train()
+    net = NAS(1, 32 if nodes == 5 else 8, 2, depth, meta_node_num=nodes, use_sharing=sharing, double_down_channel=False).to(dev()).train()
     with torch.no_grad():
         for p in net.arch_parameters():
             p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev()) * 0.5)

@@ -417,7 +417,14 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         lane_pool_grow(used);
         auto& pool = lane_pool();
         if (pool.empty()) { set_error_msg("sched_create: no lane stream could be created"); sched_free(S); return SENAS_ELAUNCH; }
-        for (int q = 0; q < used; ++q) S->lanes[q] = pool[q % pool.size()];      // (fewer queues than lanes: lanes share streams)
+        // fewer hardware queues than lanes: the lanes with the fewest nodes share streams, the heaviest keep theirs to themselves
+        // (rank by node count; rank r < P owns stream r; rank P + i shares with rank P - 1 - (i mod P), the lightest owners first)
+        const int P = (int)pool.size();
+        std::vector<int> weight(used, 0), order(used);
+        for (int v = 0; v < (int)n; ++v) ++weight[lane[v]];
+        for (int q = 0; q < used; ++q) order[q] = q;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
+        for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
     }
     for (int q = 0; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
     SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");

@@ -28,6 +28,11 @@ from .packing import WeightPacker
 from .parallel import SinkReducer
 
 
+def _lib_error():
+    from ._lib import SenasHipError
+    return SenasHipError
+
+
 def _macro_grid(model):
     for m in model.modules():
         if isinstance(m, MacroGrid):
@@ -176,6 +181,25 @@ class GraphedForwardBackward(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._collectives = True
+        try:
+            graph = self._capture_graphs()
+        except _lib_error() as err:
+            # the lane scheduler could not rebuild the captured pass (a node type it does not re-issue, a runtime error): the
+            # pass is captured again on ONE stream and replayed by the runtime -- never a multi-branch graph on its executor
+            if self.grid is None or not self.grid.lanes:
+                raise
+            import sys
+            sys.stderr.write('[senas_amd.step] lane scheduler unavailable (%s): this pass keeps the serial schedule\n' % err)
+            self.grid.lanes = False
+            self.sched = self.sched_tail = self.graph_tail = None
+            graph = self._capture_graphs()
+        reset_arena()
+        self.graph = graph
+        with torch.no_grad():
+            for b, k in zip(buffers, kept):
+                b.copy_(k)
+
+    def _capture_graphs(self):
         reset_arena()
         # a pass that runs on several lanes (grid.Lanes) is captured but never handed to the runtime's graph executor: the
         # captured graph is replayed by the lane scheduler (lanesched.LaneSchedule, csrc/sched.hip)
@@ -197,11 +221,7 @@ class GraphedForwardBackward(object):
             self.graph_tail = tail
             if lanes and not os.environ.get('SENAS_NO_SCHED'):
                 self.sched_tail = LaneSchedule(tail, self.max_lanes)
-        reset_arena()
-        self.graph = graph
-        with torch.no_grad():
-            for b, k in zip(buffers, kept):
-                b.copy_(k)
+        return graph
 
     def __call__(self):
         if self.graph is None:

@@ -289,6 +289,10 @@ def flush_wgrads():
             for t in tensors:
                 t.record_stream(W)           # (the caching allocator must not hand the block on while the lane reads it)
             fn()
+        if DEFER:
+            # the second stage of this batch's two-stage weight gradients right behind them, on the lane: at the end of the
+            # pass the batched sums (0.6 ms per search step) would sit on the critical path
+            flush_deferred(reopen=True)
 
 
 class _CellIn(torch.autograd.Function):

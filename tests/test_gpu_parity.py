@@ -586,24 +586,10 @@ def test_supernet_full_width_vs_oracle():
     close(out[-1], ref.detach().numpy(), 'logits', rel=1e-3)
     assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
     got = grads_of(net)
-    keys = ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'net.stem0.0.weight')
-    # the oracle's own conditioning: the same pass with inputs and weights perturbed by 1e-6 (what another summation order
-    # amounts to) -- the deeper the cell, the further its architecture gradients move (5 nodes: a few 1e-2)
-    g = torch.Generator().manual_seed(77)
-    sd2 = {k: ((v.detach() * (1 + 1e-6 * torch.randn(v.shape, generator=g))).requires_grad_(True)
-               if (v.is_floating_point() and 'running' not in k) else v.detach().clone()) for k, v in sd.items()}
-    gio.share_stem(sd2, 'net.')
-    R.dice_ce_loss(R.nas_forward(sd2, x * (1 + 1e-6 * torch.randn(x.shape, generator=g)), depth=3, nodes=nodes)[-1], y).backward()
-    worst = {}
-    for k in keys:
+    for k in ('alphas_dn', 'alphas_up', 'alphas_dn_nm', 'alphas_up_nm', 'betas_dn', 'betas_up', 'net.stem0.0.weight'):
         e = sd[k].grad.numpy().astype(np.float64)
         err = float(np.sqrt(((got[k] - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
-        spread = float(np.sqrt(((sd2[k].grad.numpy().astype(np.float64) - e) ** 2).sum()) / np.sqrt((e ** 2).sum()))
-        worst[k] = (err, spread)
-        assert err <= max(1e-2, 4 * spread), 'grad %s: L2 rel err %.2e, the oracle itself moves by %.2e under 1e-6 noise' % (k, err, spread)
-    from conftest import record_margin
-    record_margin('test_supernet_other_node_counts_vs_oracle[%d-%s]' % (nodes, stacked),
-                  **{k: {'gpu_vs_oracle': a, 'oracle_spread_under_1e-6': b} for k, (a, b) in worst.items()})
+        assert err <= 1e-2, 'grad %s: L2 rel err %.2e' % (k, err)
     ref_geno = R.derive_genotype(sd, depth=3, nodes=3)
     got_geno = net.genotype()
     assert (list(got_geno.down), list(got_geno.up), list(got_geno.gamma)) == (list(ref_geno.down), list(ref_geno.up), list(ref_geno.gamma))

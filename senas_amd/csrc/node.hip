@@ -186,6 +186,10 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
     int ch_thr = (int)(threadIdx.x % cv) * V;            // (every element of this thread has that channel: 256 % cv == 0)
     const long per_img = hw * cv;
     const size_t img_off = (size_t)n * hw * c;
+    // (latency-bound regime: every thread has at most two elements of its image)
+    const float* safe = nullptr;
+    for (int t = 0; t < nterms && safe == nullptr; ++t) safe = z.p[t];
+    const bool batched = nterms > 4 && safe != nullptr && per_img <= 2L * gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cv) * V;
         const size_t pixel = (size_t)n * hw + (size_t)(i / cv);
@@ -198,11 +202,34 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
 #pragma unroll
             for (int j = 0; j < V; ++j) acc[j] += tmp[j];
         }
-        for (int t = 0; t < nterms; ++t) {
-            if (z.p[t] == nullptr) continue;
-            ldv<V>(z.p[t] + pixel * z.s[t] + ch, tmp);
+        if (batched) {
+            // small maps: a thread has one or two elements, and the walk over 12 - 24 terms is a chain of that many dependent
+            // L2 round trips (13.7 us for a node on a 2 x 2 map).  Eight requests at a time, no control flow between them: an
+            // absent term ('none') loads from the first present one and is multiplied by zero.
+            constexpr int NB = 8;
+            for (int t0 = 0; t0 < nterms; t0 += NB) {
+                float tv[NB][V], cf[NB][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
+                for (int k = 0; k < NB; ++k) {
+                    const int t = t0 + k < nterms ? t0 + k : nterms - 1;
+                    const bool ok = t0 + k < nterms && z.p[t] != nullptr;
+                    const float* src = ok ? z.p[t] + pixel * z.s[t] + ch : safe;
+                    ldv<V>(src, tv[k]);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) cf[k][j] = ok ? lds[t * c + ch + j] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(cf[k][j], cf[k][j] != 0.f ? tv[k][j] : 0.f, acc[j]);
+            }
+        } else {
+            for (int t = 0; t < nterms; ++t) {
+                if (z.p[t] == nullptr) continue;
+                ldv<V>(z.p[t] + pixel * z.s[t] + ch, tmp);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
+            }
         }
         if (V == 4 && mask8 != nullptr) {           // one byte per 16-byte piece: bit j = (y_j > 0), the backward pass's ReLU mask
             const unsigned bits = (acc[0] > 0.f ? 1u : 0u) | (acc[1 % V] > 0.f ? 2u : 0u) | (acc[2 % V] > 0.f ? 4u : 0u) |
@@ -237,16 +264,21 @@ __global__ __launch_bounds__(256) void node_combine_fwd_kernel(long hw, int c, i
                                                                const float* __restrict__ residual, int relu,
                                                                float* __restrict__ y, uint8_t* __restrict__ mask8,
                                                                double* __restrict__ out_stats, float* __restrict__ y2, int y2s, int y2pad) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c]
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // coef[nterms][c], bias[c], shift[nterms][c]
     const int n = blockIdx.y;
     float* bias = lds + nterms * c;
+    float* sh = bias + c;
+    // (every global operand requested at once: summing the shifts term by term from global memory was a chain of nterms
+    // dependent round trips -- 12 of the 13.7 us of a 24-term node on a small map)
     for (int i = threadIdx.x; i < nterms * c; i += 256) {
         const int t = i / c, ch = i % c;
         lds[i] = coef[((size_t)t * nimg + n) * c + ch];
+        sh[i] = shiftc[((size_t)t * nimg + n) * c + ch];
     }
+    __syncthreads();
     for (int ch = threadIdx.x; ch < c; ch += 256) {
         float b = 0.f;
-        for (int t = 0; t < nterms; ++t) b += shiftc[((size_t)t * nimg + n) * c + ch];
+        for (int t = 0; t < nterms; ++t) b += sh[t * c + ch];
         bias[ch] = b;
     }
     __syncthreads();
@@ -931,7 +963,7 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     hipLaunchKernelGGL(node_prepare_fwd_kernel, dim3(d.nterms), dim3(256), lds1, st, d, coefs, gate, coef, shiftc, se_m, se_a1);
     const int V = (d.c % 4 == 0) ? 4 : 1;
     dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
-    const size_t lds2 = ((size_t)d.nterms * d.c + d.c) * sizeof(float);
+    const size_t lds2 = ((size_t)2 * d.nterms * d.c + d.c) * sizeof(float);
     if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr, out_stats, y2, y2s, y2pad);
     else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr, (double*)nullptr, y2, y2s, y2pad);
     return launch_status("node_fwd");

@@ -822,6 +822,9 @@ __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, 
     const int cv = c / V;
     const long per_img = hw * cv;
     const size_t img_off = (size_t)n * hw * c;
+    const float* safe = nullptr;
+    for (int t = 0; t < nterms && safe == nullptr; ++t) safe = z.p[t];
+    const bool batched = nterms > 4 && safe != nullptr && per_img <= 2L * gridDim.x * 256;      // (latency-bound regime)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cv) * V;
         const size_t off = img_off + (size_t)(i / cv) * c + ch;
@@ -839,6 +842,35 @@ __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, 
             }
         }
         if (ds_out != nullptr) stv<V>(ds_out + off, ds);
+        if (batched) {
+            // small maps: one or two elements per thread, and a term-by-term walk is a chain of nterms dependent L2 round trips
+            // (9 - 15 us for a node of a search cell).  Eight terms' operands requested together, then their stores.
+            constexpr int NB = 8;
+            const size_t pix = (size_t)n * hw + (size_t)(i / cv);
+            for (int t0 = 0; t0 < nterms; t0 += NB) {
+                float zb[NB][V], ab[NB][V], bb[NB][V], kb[NB][V];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int t = t0 + k < nterms ? t0 + k : nterms - 1;
+                    const bool ok = t0 + k < nterms && dz.p[t] != nullptr && z.p[t] != nullptr;
+                    const int ko = t * kt + kbase + ch;
+                    ldv<V>(ok ? z.p[t] + pix * z.s[t] + ch : safe, zb[k]);
+                    ldv<V>(A + ko, ab[k]);
+                    ldv<V>(B + ko, bb[k]);
+                    ldv<V>(K + ko, kb[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int t = t0 + k;
+                    if (t < nterms && dz.p[t] != nullptr && z.p[t] != nullptr) {
+#pragma unroll
+                        for (int j = 0; j < V; ++j) zb[k][j] = fmaf(ab[k][j], ds[j], fmaf(bb[k][j], zb[k][j], kb[k][j]));
+                        stv<V>(dz.p[t] + pix * dz.s[t] + ch, zb[k]);
+                    }
+                }
+            }
+            continue;
+        }
         for (int t = 0; t < nterms; ++t) {
             float* out = dz.p[t];
             if (out == nullptr) continue;

@@ -424,7 +424,13 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         for (int v = 0; v < (int)n; ++v) ++weight[lane[v]];
         for (int q = 0; q < used; ++q) order[q] = q;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
-        for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
+        int partner = -1;                                      // experiment: SENAS_SCHED_SHARE=<rank the first extra lane shares with>
+        if (const char* e = getenv("SENAS_SCHED_SHARE")) partner = atoi(e);
+        for (int r = 0; r < used; ++r) {
+            int slot = r < P ? r : P - 1 - ((r - P) % P);
+            if (r == P && partner >= 0 && partner < P) slot = partner;
+            S->lanes[order[r]] = pool[slot];
+        }
     }
     for (int q = 0; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
     SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");

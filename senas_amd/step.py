@@ -111,6 +111,7 @@ class GraphedForwardBackward(object):
             self._cut_src, self._cut_leaf = [], []
             self.grid.cut = self._cut
         F.WLANE = self.wlane if (self.grid is not None and self.grid.lanes and Lanes.enabled) else None
+        del F._WQ[:]                      # (weight gradients a failed pass may have left queued belong to tensors that are gone)
         try:
             loss = self.criterion(self.model(self.x), self.y)
             loss.backward()

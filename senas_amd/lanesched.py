@@ -10,6 +10,9 @@ from . import _lib
 MAX_LANES = int(os.environ.get('SENAS_MAX_LANES', 4))           # lanes per captured pass: one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4)
 
 
+_PENDING = []          # scheduler handles whose destruction had to wait (see LaneSchedule.close)
+
+
 class LaneSchedule(object):
     def __init__(self, graph, max_lanes=None):
         """``graph``: a ``torch.cuda.CUDAGraph(keep_graph=True)`` whose capture has ended; it is kept alive here (it owns the
@@ -32,10 +35,19 @@ class LaneSchedule(object):
         return dict(zip(keys, [int(v) for v in out]))
 
     def close(self):
-        if self.handle:
-            torch.cuda.synchronize()
-            _lib.lib().senas_sched_destroy(self.handle)
-            self.handle = C.c_void_p()
+        """Destroy the scheduler (its segment graphs and events) once the device is idle.  Called from ``__del__`` too, i.e.
+        possibly by the garbage collector in the middle of somebody's stream capture, where a device synchronisation is not
+        allowed (it would invalidate the capture): the handle then waits in ``_PENDING`` for the next close outside a capture."""
+        if not self.handle:
+            return
+        handle, self.handle = self.handle, C.c_void_p()
+        if torch.cuda.is_current_stream_capturing():
+            _PENDING.append(handle)
+            return
+        torch.cuda.synchronize()
+        for h in [handle] + _PENDING:
+            _lib.lib().senas_sched_destroy(h)
+        del _PENDING[:]
 
     def __del__(self):
         try:

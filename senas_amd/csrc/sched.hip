@@ -129,7 +129,7 @@ static void lane_pool_grow(int want) {
 // A hand-over between two lanes passes through the capture's origin stream (grid.Lanes: the star topology).  The origin stream
 // records no kernel between two hand-overs, so the runtime's capture bookkeeping makes every hand-over depend on the producers
 // of all earlier ones.  A marker launched on the origin stream at each hand-over gives that chain nodes the scheduler can
-// recognise and contract away.  CUTTING the chain at the markers (marker -> marker edges dropped, SENAS_SCHED_CUT_MARKERS) would
+// recognise and contract away.  CUTTING the chain at the markers (marker -> marker edges dropped: tried in round 4) would
 // leave consumer <- producer, the dependency that was meant -- but a marker also absorbs every wait the origin stream itself
 // made since its last kernel (autograd's hand-overs TO the origin stream, join_lanes), and the origin's next real kernel
 // reaches those only through the chain: the cut loses them (measured: dirty weight gradients of the first down cell).  So the
@@ -205,14 +205,6 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
                 hipKernelNodeParams p;
                 SCHED_HIP(hipGraphKernelNodeGetParams(raw[i], &p), "hipGraphKernelNodeGetParams");
                 if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { marker[i] = gone[i] = 1; ++S->n_marker; }
-            }
-        }
-        if (getenv("SENAS_SCHED_CUT_MARKERS")) {      // experiment only: UNSAFE (see the note at relay_marker_kernel)
-            for (size_t i = 0; i < n; ++i) {
-                if (!marker[i]) continue;
-                auto& ps = par0[i];
-                for (int p : ps) if (marker[p]) chi0[p].erase(std::remove(chi0[p].begin(), chi0[p].end(), (int)i), chi0[p].end());
-                ps.erase(std::remove_if(ps.begin(), ps.end(), [&](int p) { return marker[p] != 0; }), ps.end());
             }
         }
         // contract in creation order: a removed node hands its parents to its children
@@ -424,13 +416,8 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         for (int v = 0; v < (int)n; ++v) ++weight[lane[v]];
         for (int q = 0; q < used; ++q) order[q] = q;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
-        int partner = -1;                                      // experiment: SENAS_SCHED_SHARE=<rank the first extra lane shares with>
-        if (const char* e = getenv("SENAS_SCHED_SHARE")) partner = atoi(e);
-        for (int r = 0; r < used; ++r) {
-            int slot = r < P ? r : P - 1 - ((r - P) % P);
-            if (r == P && partner >= 0 && partner < P) slot = partner;
-            S->lanes[order[r]] = pool[slot];
-        }
+        // (which owner the fifth lane shares with moves the search step by 0.9 ms: lightest 28.4, heaviest 29.3 -- r4_lanes_queues.txt)
+        for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
     }
     for (int q = 0; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
     SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");

@@ -369,3 +369,100 @@ def test_dropout_keeps_the_reference_child_indices():
     plain = DepSepConv(8, 8, 3)
     assert plain.dw is plain[0] and plain.norm1 is plain[1] and plain.pw is plain[3] and plain.norm2 is plain[4] and plain.drop is None
     assert sorted(k for k in a.state_dict() if k.endswith('weight')) == ['1.weight', '2.weight']
+
+
+# ------------------------------------------------------------------ macro-grid schedule (grid.MacroGrid._walk_grid)
+class _CountingPlan(object):
+    """FanPlan's interface, counting: how often every key is put and got, and in which order the cells are applied."""
+
+    def __init__(self):
+        self.puts, self.gets = {}, {}
+        self.dry = True
+
+    def put(self, key, value=None):
+        self.puts[key] = self.puts.get(key, 0) + 1
+        return key
+
+    def get(self, key):
+        self.gets[key] = self.gets.get(key, 0) + 1
+        return None
+
+
+@pytest.mark.parametrize('kind,depth,supervision', [('search', 2, False), ('search', 3, True), ('search', 5, False), ('search', 6, True),
+                                                   ('derived', 5, False), ('derived', 4, True), ('derived', 3, False)])
+def test_macro_grid_schedule_reads_what_the_references_loop_reads(kind, depth, supervision):
+    """The level-major schedule (down cell j + 1, then at once up cell (1, j); then levels 2, 3, ...) must hand every cell
+    exactly the tensors the reference's loop does (search/senas_search.py:96-107, models/senas_model.py:160-175: j descending, i
+    ascending, overwriting a running list).  Both schedules are run dry over keys: the same cells, each with the same in1 and the
+    same skip list; every tensor read as often in both (a reader count that differs between the dry and the live walk of the
+    FanPlan ends in StopIteration on the GPU)."""
+    from senas_amd.geno_searched import senas_node_4
+    from senas_amd.grid import gamma_index
+    from senas_amd.senas_model import SenasModel
+    from senas_amd.senas_search import SenasSearch
+    if kind == 'search':
+        net = SenasSearch(1, 8, 2, depth, meta_node_num=3, double_down_channel=False, supervision=supervision)
+    else:
+        gamma = [1] * 6 if supervision else list(senas_node_4.gamma)
+        net = SenasModel(2, 1, c=8, depth=depth, genotype=senas_node_4._replace(gamma=gamma), supervision=supervision)
+    # --- this package's schedule, dry
+    plan = _CountingPlan()
+    seen = []
+
+    def skips(plan_, G, i, j, live):
+        if kind == 'search':
+            out = [plan_.get(G[0][j])]
+            for k in range(1, i):
+                plan_.get(G[k - 1][j]); plan_.get(G[k][j])
+                out.append(('blend', k, j))
+            return out
+        return [plan_.get(G[k][j]) or G[k][j] for k in range(i) if G[k][j] is not None]
+
+    orig_put = plan.put
+
+    def put(key, value=None):
+        seen.append(key)
+        return orig_put(key, value)
+    plan.put = put
+    net._walk_grid(plan, None, lambda *a: None, skips)
+    # --- the reference's loop, dry, over the same keys
+    want_gets, cells = {}, []
+
+    def get(key):
+        want_gets[key] = want_gets.get(key, 0) + 1
+        return key
+    s0 = 's0'
+    get(s0)
+    outs = [('o', 0, 0)]
+    for j in range(1, depth):
+        get(s0 if j == 1 else outs[j - 2]); get(outs[j - 1])
+        outs.append(('o', 0, j))
+        cells.append(('o', 0, j))
+    for j in reversed(range(depth - 1)):
+        for i in range(1, depth - j):
+            if net.blocks[i][j] is None:
+                outs[i + j] = None
+                continue
+            if kind == 'search':
+                get(outs[j])
+                for k in range(1, i):
+                    get(outs[j + k - 1]); get(outs[j + k])
+            else:
+                for t in range(j, i + j):
+                    if outs[t] is not None:
+                        get(outs[t])
+            get(outs[i + j])
+            outs[i + j] = ('o', i, j)
+            cells.append(('o', i, j))
+    for o in (outs if supervision else outs[-1:]):
+        get(s0); get(o)
+    assert plan.gets == want_gets
+    assert sorted(k for k in seen if k != 's0' and k != ('o', 0, 0)) == sorted(cells)
+    assert all(v == 1 for v in plan.puts.values())
+    # the order respects the data flow: a cell is applied after the cells it reads
+    pos = {k: n for n, k in enumerate(seen)}
+    for (_, i, j) in cells:
+        if i >= 1:
+            assert pos[('o', i - 1, j + 1)] < pos[('o', i, j)]
+            assert all(pos[('o', k, j)] < pos[('o', i, j)] for k in range(i) if ('o', k, j) in pos)
+    assert gamma_index(2, 1) == 4

@@ -71,10 +71,28 @@ class Evaluator(object):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        reset_arena()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
-            self.logits, self.mask = self._eager()
+        # a forward pass that runs on several lanes (grid.Lanes: the model's own forward, not the folded launch list) is captured
+        # but replayed by the lane scheduler -- the runtime's executor is never given a multi-branch graph (csrc/sched.hip)
+        from .grid import Lanes, MacroGrid
+        from .lanesched import LaneSchedule
+        from ._lib import SenasHipError
+        grid = next((m for m in self.model.modules() if isinstance(m, MacroGrid)), None)
+        lanes = (type(self)._forward is Evaluator._forward and Lanes.enabled and grid is not None and grid.lanes and grid._depth > 2)
+        self.sched = None
+        for attempt in (0, 1):
+            reset_arena()
+            graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes else torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
+                self.logits, self.mask = self._eager()
+            if not lanes:
+                break
+            try:
+                self.sched = LaneSchedule(graph)
+                break
+            except SenasHipError:
+                if attempt:
+                    raise
+                grid.lanes, lanes = False, False         # (this model keeps the serial schedule)
         reset_arena()
         self.graph = graph
         self.reset()
@@ -95,7 +113,10 @@ class Evaluator(object):
         if self.graph is None:
             self.logits, self.mask = self._eager()
         else:
-            self.graph.replay()
+            if getattr(self, 'sched', None) is not None:
+                self.sched.launch()
+            else:
+                self.graph.replay()
             if self.y is not None:
                 self.metric._acc_n += 1             # the replay ran the captured update launch
         self.batches += 1

@@ -31,6 +31,7 @@ extern "C" {
 #define SENAS_EUNSUPPORTED -3
 
 #define SENAS_MAX_TERMS 32
+#define SENAS_SKIP_MAX 8     /* tensors one senas_skipcat_* call stacks (a column of a depth-9 macro grid) */
 
 /* Geometry of one convolution, always stated for the FORWARD op y = op(x):
  *   x: [n][hi][wi][ci]  ->  y: [n][ho][wo][co]
@@ -248,6 +249,19 @@ int senas_relu_bwd(int64_t numel, const float* dy, const float* y, float* dx, vo
 int senas_blend2_fwd(int64_t numel, const float* x1, const float* x2, const float* g, float* y, void* stream);
 int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1, const float* x2, const float* g, float* dx1,
                      float* dx2, double* dg, void* stream);
+
+/* ---- in0 of a supernet up cell in one pass (search/senas_search.py:96-103) -------------------------------------------
+ * The reference concatenates, along channels, the column's down-path output and the gamma-gated blends of neighbouring
+ * outputs below it.  xs: m NHWC tensors [npix][c] (2 <= m <= SENAS_SKIP_MAX, c % 4 == 0, 16-byte aligned); table: DEVICE
+ * float[rows][2] = softmax(gamma); idx[k] (k >= 1; idx[0] is ignored): the row that gates slice k.
+ *     y[npix][m * c]:  slice 0 = xs[0],  slice k = table[idx[k]][0] * xs[k-1] + table[idx[k]][1] * xs[k]
+ * Backward: dy [npix][m * c] -> dxs[k] [npix][c] (NULL: not wanted) = [k == 0] dy_0 + [k >= 1] table[idx[k]][1] dy_k
+ * + [k + 1 < m] table[idx[k+1]][0] dy_{k+1};  acc[idx[k]] += (sum dy_k xs[k-1], sum dy_k xs[k]) -- acc: DEVICE
+ * double[rows][2], zeroed by the caller once per pass (the d loss / d softmax(gamma) table every blend of the pass adds into). */
+int senas_skipcat_fwd(int64_t npix, int c, int m, const float* const* xs, const float* table, int rows, const int32_t* idx,
+                      float* y, void* stream);
+int senas_skipcat_bwd(int64_t npix, int c, int m, const float* dy, const float* const* xs, const float* table, int rows,
+                      const int32_t* idx, float* const* dxs, double* acc, void* stream);
 
 /* ---- the architecture tensors of the supernet, one launch per direction --------------------------------------------------
  * NAS.forward (search/senas_search.py:246-260): row softmax of alphas_dn / alphas_up / alphas_dn_nm / alphas_up_nm ([k][ops]),

@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
-EXPECTED_ABI = 29          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
+EXPECTED_ABI = 30          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
+SKIP_MAX = 8               # SENAS_SKIP_MAX
 MAX_STACK = 4
 
 
@@ -114,6 +115,8 @@ SIGNATURES = {
     'senas_relu_bwd': (_I, [_L, _P, _P, _P, _P]),
     'senas_blend2_fwd': (_I, [_L, _P, _P, _P, _P, _P]),
     'senas_blend2_bwd': (_I, [_L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_skipcat_fwd': (_I, [_L, _I, _I, _PP, _P, _I, _P, _P, _P]),
+    'senas_skipcat_bwd': (_I, [_L, _I, _I, _P, _PP, _P, _I, _P, _PP, _P, _P]),
     'senas_chan_stats': (_I, [_I, _L, _I, _P, _P, _P]),
     'senas_bn_finalize': (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
     'senas_dwconv_multi_fwd': (_I, [_G, _I, _P, _PP, _PP, _PP, _P]),

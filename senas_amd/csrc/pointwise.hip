@@ -307,9 +307,165 @@ __global__ __launch_bounds__(256) void blend2_bwd_kernel(const float4* __restric
     }
 }
 
+// ---- in0 of up cell (i, j) of the supernet in ONE pass (search/senas_search.py:96-103: torch.cat of the column's down-path
+// output and the gamma-gated blends of neighbouring outputs below it): m tensors x_0 .. x_{m-1} of [npix][c] in, one
+// [npix][m * c] tensor out -- slice 0 = x_0, slice k = g_k[0] * x_{k-1} + g_k[1] * x_k (g_k = row idx[k] of the softmax(gamma)
+// table).  Every x_k is read once and every output byte written once (m - 1 blends + a concatenation read x 3m - 2 times and
+// write 2m - 1 slices).
+struct SkipTab {
+    const float* x[SENAS_SKIP_MAX];
+    float* dx[SENAS_SKIP_MAX];
+    int idx[SENAS_SKIP_MAX];
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void skipcat_fwd_kernel(SkipTab t, const float* __restrict__ table, float4* __restrict__ y,
+                                                          long total4, int cq, int m_rt) {
+    const int m = M > 0 ? M : m_rt;
+    float ga[SENAS_SKIP_MAX], gb[SENAS_SKIP_MAX];
+#pragma unroll
+    for (int k = 0; k < SENAS_SKIP_MAX; ++k) {
+        ga[k] = gb[k] = 0.f;
+        if (k >= 1 && k < m) { ga[k] = table[2 * t.idx[k]]; gb[k] = table[2 * t.idx[k] + 1]; }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long pix = i / cq;
+        const int q = (int)(i - pix * cq);
+        float4* o = y + pix * (long)(m * cq) + q;
+        float4 v[SENAS_SKIP_MAX];
+#pragma unroll
+        for (int k = 0; k < (M > 0 ? M : SENAS_SKIP_MAX); ++k)
+            if (k < m) v[k] = reinterpret_cast<const float4*>(t.x[k])[i];
+        o[0] = v[0];
+#pragma unroll
+        for (int k = 1; k < (M > 0 ? M : SENAS_SKIP_MAX); ++k)
+            if (k < m) {
+                const float a = ga[k], b = gb[k];
+                const float4 u = v[k - 1], w = v[k];
+                o[(long)k * cq] = make_float4(fmaf(a, u.x, b * w.x), fmaf(a, u.y, b * w.y), fmaf(a, u.z, b * w.z), fmaf(a, u.w, b * w.w));
+            }
+    }
+}
+
+// its backward pass in one more: d x_k = [k == 0] dy_0 + [k >= 1] g_k[1] dy_k + [k + 1 < m] g_{k+1}[0] dy_{k+1} (NULL: not
+// wanted), acc[idx[k]] += (sum dy_k x_{k-1}, sum dy_k x_k) in fp64 (the caller zeroes the table once per pass)
+template <int M>
+__global__ __launch_bounds__(256) void skipcat_bwd_kernel(SkipTab t, const float* __restrict__ table, const float4* __restrict__ dy,
+                                                          double* __restrict__ acc, long total4, int cq, int m_rt) {
+    constexpr int MM = M > 0 ? M : SENAS_SKIP_MAX;
+    const int m = M > 0 ? M : m_rt;
+    __shared__ double red[2 * SENAS_SKIP_MAX][4];
+    float ga[MM + 1], gb[MM + 1];
+    double s[2 * MM];
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {
+        s[2 * k] = s[2 * k + 1] = 0.0;
+        ga[k] = gb[k] = 0.f;
+        if (k >= 1 && k < m) { ga[k] = table[2 * t.idx[k]]; gb[k] = table[2 * t.idx[k] + 1]; }
+    }
+    ga[MM] = gb[MM] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long pix = i / cq;
+        const int q = (int)(i - pix * cq);
+        const float4* d0 = dy + pix * (long)(m * cq) + q;
+        float4 d[MM + 1], x[MM];
+#pragma unroll
+        for (int k = 0; k < MM; ++k)
+            if (k < m) { d[k] = d0[(long)k * cq]; x[k] = reinterpret_cast<const float4*>(t.x[k])[i]; }
+            else d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        d[MM] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < MM; ++k)
+            if (k < m) {
+                const float b = k == 0 ? 1.f : gb[k];
+                const float a = (k + 1 < m) ? ga[k + 1] : 0.f;
+                const float4 u = d[k], w = d[k + 1];
+                if (t.dx[k] != nullptr)
+                    reinterpret_cast<float4*>(t.dx[k])[i] = make_float4(fmaf(a, w.x, b * u.x), fmaf(a, w.y, b * u.y), fmaf(a, w.z, b * u.z),
+                                                                        fmaf(a, w.w, b * u.w));
+                if (k >= 1) {
+                    const float4 p = x[k - 1], c = x[k];
+                    s[2 * k] += (double)u.x * p.x + (double)u.y * p.y + (double)u.z * p.z + (double)u.w * p.w;
+                    s[2 * k + 1] += (double)u.x * c.x + (double)u.y * c.y + (double)u.z * c.z + (double)u.w * c.w;
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 1; k < MM; ++k)
+        if (k < m) {
+            const double s0 = wave_sum(s[2 * k]), s1 = wave_sum(s[2 * k + 1]);
+            if ((threadIdx.x & 63) == 0) { red[2 * k][threadIdx.x >> 6] = s0; red[2 * k + 1][threadIdx.x >> 6] = s1; }
+        }
+    __syncthreads();
+    if (threadIdx.x >= 2 && threadIdx.x < 2 * m) {
+        const int k = threadIdx.x >> 1, h = threadIdx.x & 1;
+        atomicAdd(acc + 2 * t.idx[k] + h, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+template <int M>
+static void skipcat_fwd_launch(const SkipTab& t, const float* table, float* y, long total4, int cq, int m, hipStream_t s) {
+    hipLaunchKernelGGL(skipcat_fwd_kernel<M>, dim3(stream_grid(total4)), dim3(256), 0, s, t, table, reinterpret_cast<float4*>(y), total4, cq, m);
+}
+template <int M>
+static void skipcat_bwd_launch(const SkipTab& t, const float* table, const float* dy, double* acc, long total4, int cq, int m, hipStream_t s) {
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256) blocks = 256;                                       // (every block ends in 2 (m - 1) fp64 atomics on the same few addresses)
+    hipLaunchKernelGGL(skipcat_bwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, t, table, reinterpret_cast<const float4*>(dy), acc, total4, cq, m);
+}
+
 }  // namespace senas
 
 using namespace senas;
+
+static int skipcat_table(SkipTab& t, int64_t npix, int c, int m, const float* const* xs, const int32_t* idx, int rows) {
+    SENAS_REQUIRE(npix > 0 && c >= 4 && c % 4 == 0 && m >= 2 && m <= SENAS_SKIP_MAX && xs && idx && rows > 0, "skipcat: bad argument (2 <= m <= SENAS_SKIP_MAX, c % 4 == 0)");
+    for (int k = 0; k < m; ++k) {
+        SENAS_REQUIRE(xs[k] && (reinterpret_cast<uintptr_t>(xs[k]) & 15) == 0, "skipcat: null or misaligned source");
+        SENAS_REQUIRE(k == 0 || (idx[k] >= 0 && idx[k] < rows), "skipcat: gamma row out of range");
+        t.x[k] = xs[k];
+        t.idx[k] = k == 0 ? 0 : idx[k];
+    }
+    return SENAS_OK;
+}
+
+extern "C" int senas_skipcat_fwd(int64_t npix, int c, int m, const float* const* xs, const float* table, int rows, const int32_t* idx,
+                                 float* y, void* stream) {
+    SkipTab t{};
+    const int rc = skipcat_table(t, npix, c, m, xs, idx, rows);
+    if (rc != SENAS_OK) return rc;
+    SENAS_REQUIRE(table && y && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "skipcat_fwd: null or misaligned destination");
+    const long total4 = (long)npix * (c / 4);
+    hipStream_t s = as_stream(stream);
+    switch (m) {
+        case 2: skipcat_fwd_launch<2>(t, table, y, total4, c / 4, m, s); break;
+        case 3: skipcat_fwd_launch<3>(t, table, y, total4, c / 4, m, s); break;
+        case 4: skipcat_fwd_launch<4>(t, table, y, total4, c / 4, m, s); break;
+        default: skipcat_fwd_launch<0>(t, table, y, total4, c / 4, m, s); break;
+    }
+    return launch_status("skipcat_fwd");
+}
+
+extern "C" int senas_skipcat_bwd(int64_t npix, int c, int m, const float* dy, const float* const* xs, const float* table, int rows,
+                                 const int32_t* idx, float* const* dxs, double* acc, void* stream) {
+    SkipTab t{};
+    const int rc = skipcat_table(t, npix, c, m, xs, idx, rows);
+    if (rc != SENAS_OK) return rc;
+    SENAS_REQUIRE(table && dy && dxs && acc && (reinterpret_cast<uintptr_t>(dy) & 15) == 0, "skipcat_bwd: null or misaligned argument");
+    for (int k = 0; k < m; ++k) {
+        SENAS_REQUIRE((reinterpret_cast<uintptr_t>(dxs[k]) & 15) == 0, "skipcat_bwd: misaligned gradient");
+        t.dx[k] = dxs[k];
+    }
+    const long total4 = (long)npix * (c / 4);
+    hipStream_t s = as_stream(stream);
+    switch (m) {
+        case 2: skipcat_bwd_launch<2>(t, table, dy, acc, total4, c / 4, m, s); break;
+        case 3: skipcat_bwd_launch<3>(t, table, dy, acc, total4, c / 4, m, s); break;
+        case 4: skipcat_bwd_launch<4>(t, table, dy, acc, total4, c / 4, m, s); break;
+        default: skipcat_bwd_launch<0>(t, table, dy, acc, total4, c / 4, m, s); break;
+    }
+    return launch_status("skipcat_bwd");
+}
 
 extern "C" int senas_blend2_fwd(int64_t numel, const float* x1, const float* x2, const float* g, float* y, void* stream) {
     SENAS_REQUIRE(x1 && x2 && g && y && numel > 0 && numel % 4 == 0, "blend2_fwd: bad argument (numel % 4 == 0)");

@@ -210,6 +210,7 @@ def flush_deferred(reopen=False):
 # on.  Whatever reads a table that kernels of several lanes ADD into (the mixing-weight gradients, the gamma table, the flat
 # gradient buffer at the end of backward) joins them first.
 LANES = set()
+SKIP_MAX = _lib.SKIP_MAX  # tensors one skip_stack launch takes (deeper columns fall back to blends + torch.cat)
 MIX_SLOTS = 32          # rows of a d loss / d M table: one per cell of a kind within a pass (cells of different lanes never share one)
 
 
@@ -861,6 +862,48 @@ class _Blend2Row(torch.autograd.Function):
 def blend2_row(x1, x2, rows, idx):
     """rows.table[idx][0] * x1 + rows.table[idx][1] * x2 (rows: GammaRows)."""
     return _Blend2Row.apply(x1, x2, rows.table, idx, rows.acc)
+
+
+class _SkipStack(torch.autograd.Function):
+    """in0 of a supernet up cell (search/senas_search.py:96-103) in one launch per direction: the channel concatenation of
+    xs[0] and the blends rows[idx[k]][0] * xs[k-1] + rows[idx[k]][1] * xs[k], k = 1 .. m-1 (senas_skipcat_fwd / _bwd) -- every
+    tensor of the column read once, the concatenation written once, and on the way back every gradient written once from
+    the concatenation's own gradient (no slice copies, no blend outputs in between)."""
+
+    @staticmethod
+    def forward(ctx, table, acc, idx, *xs):
+        xs = tuple(nhwc(x) for x in xs)
+        m, ref = len(xs), xs[0]
+        n, c, h, w = ref.shape
+        if not 2 <= m <= _lib.SKIP_MAX or c % 4 != 0 or any(x.shape != ref.shape or x.dtype != torch.float32 for x in xs) \
+                or table.dim() != 2 or table.shape[1] != 2 or len(idx) != m:
+            raise SenasHipError('skip_stack: %d tensors of %s, table %s' % (m, [tuple(x.shape) for x in xs], tuple(table.shape)))
+        y = torch.empty((n, m * c, h, w), device=ref.device, dtype=torch.float32, memory_format=CL)
+        ctx.ptrs = (C.c_void_p * m)(*[x.data_ptr() for x in xs])
+        ctx.idx = (C.c_int32 * m)(*[int(k) for k in idx])
+        _lib.check(_lib.lib().senas_skipcat_fwd(n * h * w, c, m, ctx.ptrs, table.data_ptr(), table.shape[0], ctx.idx, y.data_ptr(),
+                                                _stream()), 'senas_skipcat_fwd')
+        ctx.save_for_backward(table, acc, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        table, acc, *xs = ctx.saved_tensors
+        dy = nhwc(dy)
+        m, ref = len(xs), xs[0]
+        n, c, h, w = ref.shape
+        need = ctx.needs_input_grad[3:]
+        dxs = [torch.empty_like(ref, memory_format=CL) if need[k] else None for k in range(m)]
+        outs = (C.c_void_p * m)(*[_p(d) for d in dxs])
+        _lib.check(_lib.lib().senas_skipcat_bwd(n * h * w, c, m, dy.data_ptr(), ctx.ptrs, table.data_ptr(), table.shape[0], ctx.idx, outs,
+                                                acc.data_ptr(), _stream()), 'senas_skipcat_bwd')
+        return (None, None, None) + tuple(dxs)
+
+
+def skip_stack(xs, rows, idx):
+    """cat([xs[0]] + [rows.table[idx[k]][0] * xs[k-1] + rows.table[idx[k]][1] * xs[k] for k >= 1], dim=1) (rows: GammaRows;
+    idx[0] is ignored)."""
+    return _SkipStack.apply(rows.table, rows.acc, tuple(idx), *xs)
 
 
 class _EdgeMix(torch.autograd.Function):

@@ -10,7 +10,7 @@ import torch.nn.functional as tf
 from . import functional as F
 from .cell import Cell
 from .genotype import GenoParser, Genotype
-from .grid import FanPlan, MacroGrid, NoPlan, gamma_index
+from .grid import FanPlan, Lanes, MacroGrid, NoPlan, gamma_index
 from .operations import DownOps, NormOps, ReLUConv, UpOps
 from .utils import weights_init
 
@@ -63,11 +63,14 @@ class SenasSearch(MacroGrid):
             return module(a, b, *args[kind])
 
         def skips(plan, G, i, j, live):
-            out = [plan.get(G[0][j])]
-            for k in range(1, i):      # gamma-gated blend of neighbouring skip candidates
-                a, b = plan.get(G[k - 1][j]), plan.get(G[k][j])
-                out.append(F.blend2_row(a, b, rows, gamma_index(k, j)) if live else None)
-            return out
+            # the column's down-path output, then the gamma-gated blends of neighbouring skip candidates (:98-102) -- stacked
+            # by one launch that reads every tensor of the column once (functional.skip_stack)
+            col = [plan.get(G[k][j]) for k in range(i)]
+            if not live or i == 1:
+                return col
+            if i > F.SKIP_MAX or col[0].shape[1] % 4 != 0:
+                return [col[0]] + [F.blend2_row(col[k - 1], col[k], rows, gamma_index(k, j)) for k in range(1, i)]
+            return [F.skip_stack([Lanes.take(t) for t in col], rows, [0] + [gamma_index(k, j) for k in range(1, i)])]
 
         return self._walk_grid(plan, x, run, skips)
 

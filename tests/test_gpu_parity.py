@@ -1781,6 +1781,45 @@ def test_blend2_vs_torch():
     close(g.grad, g64.grad.numpy(), 'dgamma', rel=1e-4)
 
 
+@pytest.mark.parametrize('case', [(2, 2, 32, 12, 20), (3, 4, 32, 16, 16), (4, 1, 8, 9, 7), (6, 2, 16, 5, 5), (8, 1, 64, 8, 4), (4, 4, 32, 128, 128)])
+def test_skip_stack_vs_torch(case):
+    """senas_skipcat_fwd / _bwd -- in0 of a supernet up cell: the column's down-path output and the gamma-gated blends of
+    neighbouring outputs, concatenated (search/senas_search.py:96-103) -- against the reference's own composition in float64
+    torch (output, every input gradient, d gamma); bit-equal to the blend + torch.cat composition it replaces in the forward
+    direction; and with one input that wants no gradient."""
+    from senas_amd import functional as F
+    from senas_amd.grid import gamma_index
+    m, n, c, h, w = case
+    gen = torch.Generator().manual_seed(sum(case))
+    xs = [torch.randn(n, c, h, w, generator=gen) for _ in range(m)]
+    wgt = torch.randn(n, m * c, h, w, generator=gen)
+    gam = torch.randn(sum(range(m + 1)), 2, generator=gen)
+    idx = [0] + [gamma_index(k, 1) for k in range(1, m)]
+    xs64 = [x.double().requires_grad_(True) for x in xs]
+    g64 = gam.double().requires_grad_(True)
+    t64 = torch.softmax(g64, -1)
+    y64 = torch.cat([xs64[0]] + [t64[idx[k], 0] * xs64[k - 1] + t64[idx[k], 1] * xs64[k] for k in range(1, m)], dim=1)
+    (y64 * wgt.double()).sum().backward()
+    cl = torch.channels_last
+    for frozen in (None, m - 1):
+        gx = [x.to(dev()).contiguous(memory_format=cl).requires_grad_(k != frozen) for k, x in enumerate(xs)]
+        g = gam.to(dev()).requires_grad_(True)
+        rows = F.GammaRows(torch.softmax(g, -1))
+        y = F.skip_stack(gx, rows, idx)
+        assert y.shape == (n, m * c, h, w) and y.is_contiguous(memory_format=cl)
+        (y * wgt.to(dev())).sum().backward()
+        close(y, y64.detach().numpy(), 'stack', rel=1e-5)
+        for k in range(m):
+            if k == frozen:
+                assert gx[k].grad is None
+            else:
+                close(gx[k].grad, xs64[k].grad.numpy(), 'dx%d' % k, rel=1e-5)
+        close(g.grad, g64.grad.numpy(), 'dgamma', rel=1e-4)
+        with torch.no_grad():
+            old = torch.cat([gx[0]] + [F.blend2_row(gx[k - 1], gx[k], rows, idx[k]) for k in range(1, m)], dim=1)
+        assert torch.equal(old, y)
+
+
 @pytest.mark.parametrize('case', [(3, 2, 32, 8, 12, 20, True, False), (6, 4, 32, 8, 16, 16, True, True), (2, 2, 8, 8, 9, 7, True, False),
                                   (8, 1, 64, 4, 8, 8, True, True), (1, 3, 16, 8, 5, 5, True, False), (4, 2, 32, 8, 8, 12, False, False),
                                   (6, 4, 32, 8, 64, 64, True, False)])

@@ -388,6 +388,28 @@ class _CountingPlan(object):
         return None
 
 
+@pytest.mark.parametrize('depth', [3, 5])
+def test_supernet_dry_walk_reads_every_column_tensor_once_per_up_cell(depth):
+    """SenasSearch's own skip lists (functional.skip_stack: one launch stacks the column's down-path output and the gamma-gated
+    blends of neighbouring outputs, search/senas_search.py:96-103): up cell (i, j) reads every tensor (k, j), k < i, ONCE -- the
+    reference's loop reads the inner ones twice, as the second operand of one blend and the first of the next -- plus its in1."""
+    from senas_amd.senas_search import SenasSearch
+    net = SenasSearch(1, 8, 2, depth, meta_node_num=3, double_down_channel=False, supervision=False)
+    plan = _CountingPlan()
+    net._walk(plan, None, None)
+    want = {'s0': 3}                                         # stem1, down cell 1, the head
+    for j in range(depth):
+        for k in range(depth - j):
+            r = (depth - 1 - j) - k                          # skip input of the up cells above it in its column
+            r += 1 if (j >= 1 and k + 1 <= depth - 1 - (j - 1)) else 0      # in1 of up cell (k + 1, j - 1)
+            if k == 0:
+                r += (1 if j + 1 < depth else 0) + (1 if j + 2 < depth else 0)   # the down cells that read it
+            if (k, j) == (depth - 1, 0):
+                r += 1                                       # the head
+            want[('o', k, j)] = r
+    assert plan.gets == want
+
+
 @pytest.mark.parametrize('kind,depth,supervision', [('search', 2, False), ('search', 3, True), ('search', 5, False), ('search', 6, True),
                                                    ('derived', 5, False), ('derived', 4, True), ('derived', 3, False)])
 def test_macro_grid_schedule_reads_what_the_references_loop_reads(kind, depth, supervision):

@@ -490,15 +490,6 @@ extern "C" int senas_blend2_bwd(int64_t numel, const float* dy, const float* x1,
     return launch_status("blend2_bwd");
 }
 
-// One thread writes the device's constant-rate wall clock (100 MHz) into *slot: a time stamp IN stream order -- under HIP-graph
-// replay across several streams the only timeline that shows what really overlaps (a tracing profiler serialises the queues).
-__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
-
-extern "C" int senas_stamp(uint64_t* slot, void* stream) {
-    SENAS_REQUIRE(slot != nullptr, "stamp: bad argument");
-    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, as_stream(stream), reinterpret_cast<unsigned long long*>(slot));
-    return launch_status("stamp");
-}
 
 extern "C" int senas_relu_fwd(int64_t numel, const float* x, float* y, void* stream) {
     SENAS_REQUIRE(x && y && numel >= 0, "relu_fwd: bad argument");

@@ -167,6 +167,16 @@ extern "C" int senas_stream_create(void** out) {
     return SENAS_OK;
 }
 
+// One thread writes the device's constant-rate wall clock (100 MHz) into *slot: a time stamp IN stream order -- under HIP-graph
+// replay across several streams the only timeline that shows what really overlaps (a tracing profiler serialises the queues).
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int senas_stamp(uint64_t* slot, void* stream) {
+    SENAS_REQUIRE(slot != nullptr, "stamp: bad argument");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, as_stream(stream), reinterpret_cast<unsigned long long*>(slot));
+    return launch_status("stamp");
+}
+
 extern "C" int senas_relay_marker(void* stream) {
     hipLaunchKernelGGL(relay_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream));
     return launch_status("relay_marker");
@@ -418,6 +428,30 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
         // (which owner the fifth lane shares with moves the search step by 0.9 ms: lightest 28.4, heaviest 29.3 -- r4_lanes_queues.txt)
         for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
+    }
+    if (const char* path = getenv("SENAS_SCHED_DUMP")) {
+        // tools/lane_timeline.py --segments: which segment, lane and stream every time stamp of the pass (i.e. every cell boundary) sits
+        // on, and which segments each one waits for
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "sched nodes %zu lanes %d segments %zu\n", n, used, S->segs.size());
+            auto& pool = lane_pool();
+            for (size_t k = 0; k < S->segs.size(); ++k) {
+                const Segment& sg = S->segs[k];
+                int stream = -1;
+                for (size_t r = 0; r < pool.size(); ++r) if (used > 1 && pool[r] == S->lanes[sg.lane]) stream = (int)r;
+                fprintf(f, "seg %zu lane %d stream %d nodes %zu first %d last %d deps", k, sg.lane, stream, sg.nodes.size(), sg.nodes.front(), sg.nodes.back());
+                for (int d : sg.deps) fprintf(f, " %d", d);
+                fprintf(f, " stamps");
+                for (int v : sg.nodes) {
+                    if (type[v] != hipGraphNodeTypeKernel) continue;
+                    hipKernelNodeParams p;
+                    if (hipGraphKernelNodeGetParams(raw[topo[v]], &p) != hipSuccess || p.func != reinterpret_cast<void*>(stamp_kernel) || !p.kernelParams) continue;
+                    fprintf(f, " %llu", (unsigned long long)(uintptr_t)*reinterpret_cast<unsigned long long**>(p.kernelParams[0]));
+                }
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
     }
     for (int q = 0; q < used; ++q) SCHED_HIP(hipEventCreateWithFlags(&S->lane_done[q], hipEventDisableTiming), "hipEventCreateWithFlags");
     SCHED_HIP(hipEventCreateWithFlags(&S->start, hipEventDisableTiming), "hipEventCreateWithFlags");

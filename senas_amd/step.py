@@ -274,7 +274,9 @@ def _graph_nodes(graph):
         return None
 
 
-SEARCH_LANES = int(os.environ.get('SENAS_SEARCH_LANES', 5))
+# chains the lane scheduler covers a pass of the search step with (on 4 hardware queues; 5: +0.15 ms, 7: +1.0 ms, 4: +0.7 ms --
+# profiles/r4_wlane_modes.txt)
+SEARCH_LANES = int(os.environ.get('SENAS_SEARCH_LANES', 6))
 
 
 def _model_stacks(model):

@@ -34,10 +34,10 @@ python3 tools/pmc_traffic.py $out/pmcFx3 $out/pmcWx3 $out/pmc_traffic_bf16x3.jso
 python3 tools/pmc_traffic.py $out/spF $out/spW $out/pmc_traffic_search.json --all --steps 4 > $out/pmc_traffic_search.txt
 cp $out/stats/*kernel_stats.csv $out/kernel_stats.csv
 # what really overlaps under replay (a tracing profiler serialises the hardware queues): device time stamps per cell
-{ echo "# tools/lane_timeline.py search --serial (every cell on one stream, the runtime's graph replay)"; python3 tools/lane_timeline.py search --serial 2>/dev/null | grep -v amdgpu;
-  echo; echo "# tools/lane_timeline.py search (columns of up cells on lanes, lane scheduler)"; python3 tools/lane_timeline.py search 2>/dev/null | grep -v amdgpu; } > $out/search_by_level.txt
-{ echo "# tools/lane_timeline.py train --serial"; python3 tools/lane_timeline.py train --serial 2>/dev/null | grep -v amdgpu;
-  echo; echo "# tools/lane_timeline.py train (lanes + lane scheduler)"; python3 tools/lane_timeline.py train 2>/dev/null | grep -v amdgpu; } > $out/train_by_level.txt
+{ echo "# tools/lane_timeline.py search --serial (every cell on one stream, the runtime's graph replay)"; python3 tools/lane_timeline.py search --serial --steady 2>/dev/null | grep -v amdgpu;
+  echo; echo "# tools/lane_timeline.py search (columns of up cells on lanes, lane scheduler)"; python3 tools/lane_timeline.py search --steady --segments 2>/dev/null | grep -v amdgpu; } > $out/search_by_level.txt
+{ echo "# tools/lane_timeline.py train --serial"; python3 tools/lane_timeline.py train --serial --steady 2>/dev/null | grep -v amdgpu;
+  echo; echo "# tools/lane_timeline.py train (lanes + lane scheduler)"; python3 tools/lane_timeline.py train --steady --segments 2>/dev/null | grep -v amdgpu; } > $out/train_by_level.txt
 # the bench line last: its `traffic` fields are read from the counter aggregates of THIS run
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 cp $out/pmc_traffic_search.json profiles/${tag}_pmc_traffic_search.json

@@ -3,7 +3,12 @@
 time stamps in stream order at the boundaries of every cell, forward and backward (senas_stamp; functional.stamp), read
 after ONE replay of the step.  A tracing profiler serialises the hardware queues; these stamps do not.
 
-    python tools/lane_timeline.py search|train [--serial]
+    python tools/lane_timeline.py search|train [--serial] [--steady] [--segments]
+
+--steady: the stamps of the LAST of six back-to-back replays (the host has run ahead of the device, as in a training loop)
+instead of those of one replay launched on an idle device (whose first cells also wait for the host to issue their segments).
+--segments: also the lane scheduler's plan (SENAS_SCHED_DUMP): every segment with its lane, its stream of the pool, the segments
+it waits for and the cell boundaries (stamps) it holds, with the time each stamp showed.
 
 Prints per pass: every cell with the start / end of its forward and of its backward part (us from the first stamp of the
 pass), the sum of the cells' own durations and the span they cover.
@@ -54,8 +59,39 @@ def split_passes(rows):
     return [rows[a:b] for a, b in zip(cut, cut[1:] + [len(rows)])]
 
 
+def segments(path, rec):
+    """The scheduler's dump against the stamps: per captured pass, every segment with its lane, stream, the segments it waits for
+    and the stamps it holds (name:direction@us from the pass's first stamp)."""
+    base = rec.buf.data_ptr()
+    v = rec.buf.cpu().tolist()
+    passes, cur = [], None
+    for line in open(path):
+        w = line.split()
+        if w[0] == 'sched':
+            cur = []
+            passes.append((line.strip(), cur))
+        elif w[0] == 'seg':
+            d, st = w.index('deps'), w.index('stamps')
+            marks = [(int(ptr) - base) // 8 for ptr in w[st + 1:]]
+            marks = [k for k in marks if 0 <= k // 2 < len(rec.names) and v[k]]
+            cur.append(dict(k=int(w[1]), lane=int(w[3]), stream=int(w[5]), nodes=int(w[7]), deps=[int(x) for x in w[d + 1:st]], marks=marks))
+    for head, segs in passes:
+        if not any(sg['marks'] for sg in segs):
+            continue
+        print('\n== ' + head)
+        z = min(v[k] for sg in segs for k in sg['marks'])
+        for sg in segs:
+            ms = ' '.join('%s:%s@%.0f' % (rec.names[k // 2], 'fb'[k % 2], (v[k] - z) / 100.0) for k in sg['marks'])
+            print('seg %3d lane %d stream %d nodes %4d waits %-14s %s' % (sg['k'], sg['lane'], sg['stream'], sg['nodes'],
+                                                                          ','.join(map(str, sg['deps'])) or '-', ms))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else 'search'
+    dump = None
+    if '--segments' in sys.argv:
+        dump = '/tmp/senas_sched_dump_%d.txt' % os.getpid()
+        os.environ['SENAS_SCHED_DUMP'] = dump
     grid.Lanes.enabled = '--serial' not in sys.argv
     dev = torch.device('cuda:0')
     F.STAMPS = rec = F.StampRecorder(dev)
@@ -90,7 +126,8 @@ def main():
     print('%s step with stamps, lanes=%s: %.3f ms' % (what, grid.Lanes.enabled, e0.elapsed_time(e1) / 10))
     rec.buf.zero_()
     torch.cuda.synchronize()
-    step()
+    for _ in range(6 if '--steady' in sys.argv else 1):
+        step()
     torch.cuda.synchronize()
     rows = rec.read()
     if '--order' in sys.argv:
@@ -100,6 +137,8 @@ def main():
         seq = sorted([(f, n, 'f') for n, f, b in rows if f] + [(b, n, 'b') for n, f, b in rows if b])
         with open(sys.argv[sys.argv.index('--order') + 1], 'w') as fh:
             json.dump([[n, d] for _, n, d in seq], fh)
+    if dump is not None and os.path.exists(dump):
+        segments(dump, rec)
     passes = split_passes(rows)
     titles = ['architecture pass (weights frozen)', 'weight pass'] if what == 'search' else ['train step']
     for rows_, title in zip(passes, titles):

@@ -274,8 +274,8 @@ def _graph_nodes(graph):
         return None
 
 
-# chains the lane scheduler covers a pass of the search step with (on 4 hardware queues; 5: +0.15 ms, 7: +1.0 ms, 4: +0.7 ms --
-# profiles/r4_wlane_modes.txt)
+# chains the lane scheduler covers a pass of the search step with (on 4 hardware queues; 5 and 6 are within the run-to-run spread of
+# +-0.3 ms, 4 and 7 lose 0.7 - 1.0 ms -- profiles/r4_wlane_modes.txt)
 SEARCH_LANES = int(os.environ.get('SENAS_SEARCH_LANES', 6))
 
 

@@ -191,17 +191,21 @@ def cpu_baseline_train(batch, size, reps=3):
     y = torch.randint(0, 2, (batch, size, size), generator=g)
     geno = R.Genotype(*senas_node_4)
     times = []
+    step0 = None
     for i in range(reps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = R.dice_ce_loss(R.derived_forward(sd, x, geno)[-1], y)
+        logits = R.derived_forward(sd, x, geno)[-1]
+        loss = R.dice_ce_loss(logits, y)
+        if i == 0:
+            step0 = (logits.detach().clone(), float(loss.detach()), y)        # the parity gate's reference (bench: gate_compare)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 5)
         opt.step()
         log('cpu baseline (train) step %d: %.2f s' % (i, time.perf_counter() - t0))
         if i > 0:
             times.append(time.perf_counter() - t0)
-    return batch / min(times)
+    return batch / min(times), step0
 
 
 def cpu_baseline_search(batch, size, reps=2):
@@ -219,6 +223,9 @@ def cpu_baseline_search(batch, size, reps=2):
     g = torch.Generator().manual_seed(1)
     xt, yt = torch.randn(batch, 1, size, size, generator=g), torch.randint(0, 2, (batch, size, size), generator=g)
     xv, yv = torch.randn(batch, 1, size, size, generator=g), torch.randint(0, 2, (batch, size, size), generator=g)
+    with torch.no_grad():                                                     # the parity gate's reference: step 0's forward on the train batch
+        logits0 = R.nas_forward(sd, xt)[-1]
+        step0 = (logits0.clone(), float(R.dice_ce_loss(logits0, yt)), yt)
     times = []
     for i in range(reps + 1):
         t0 = time.perf_counter()
@@ -232,7 +239,91 @@ def cpu_baseline_search(batch, size, reps=2):
         log('cpu baseline (search) step %d: %.2f s' % (i, time.perf_counter() - t0))
         if i > 0:
             times.append(time.perf_counter() - t0)
-    return batch / min(times)
+    return batch / min(times), step0
+
+
+# ---- parity gates in the same invocation ---------------------------------------
+GATE_LOGITS = 1e-3          # north_star: outputs / loss within 1e-3 rel fp32 of the reference's CPU path
+GATE_SCHEDULE = 5e-5        # the captured pass on lanes + lane scheduler against the same pass eagerly on one stream
+_PENDING_GATES = {}         # GPU-side step-0 results waiting for the oracle's (the CPU baseline runs last)
+
+
+def gate_forward(net, crit, x, y):
+    """Step 0 of the TIMED network on the GPU, before any optimizer step: logits, loss, arg-max mask counts and Dice (the device
+    metric kernels) of the freshly initialised network on the timed batch."""
+    import torch
+    from senas_amd.metrics import SegmentationMetric
+    with torch.no_grad():
+        logits = net(x)[-1]
+        loss = float(crit([logits], y))
+        metric = SegmentationMetric(logits.shape[1])
+        metric.update(y, logits)
+        pix, miou, dice = metric.get()
+    return {'logits': logits.detach().float().cpu(), 'loss': loss, 'dice': dice, 'miou': miou}
+
+
+def gate_compare(gpu, ref_logits, ref_loss, y):
+    """The GPU's step 0 against the oracle's on the same seed-0 weights and seed-1 batch: logits and loss to 1e-3, the arg-max
+    mask bit for bit wherever the oracle's top-2 margin exceeds the logits' own error bound (the pixels inside the margin are
+    counted, not compared), Dice equal when the masks are."""
+    import numpy as np
+    import torch
+    from oracle import senas_ref as R                 # checker only
+    ref = ref_logits.detach().float()
+    got = gpu['logits']
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    loss_err = abs(gpu['loss'] - ref_loss) / abs(ref_loss)
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    decided = margin > 2.0 * GATE_LOGITS * scale      # (an error of 1e-3 of the scale on each of two logits cannot flip these)
+    m_got, m_ref = got.argmax(1), ref.argmax(1)
+    mismatch = int(((m_got != m_ref) & decided).sum())
+    tp, fp, fn = R.hard_counts(ref, y.cpu())
+    ref_dice = R.dice_from_counts(tp, fp, fn)
+    same_mask = bool((m_got == m_ref).all())
+    dice_ok = (abs(gpu['dice'] - ref_dice) <= 1e-3) if same_mask else (abs(gpu['dice'] - ref_dice) <= 0.5)
+    ok = err <= GATE_LOGITS and loss_err <= GATE_LOGITS and mismatch == 0 and dice_ok
+    return {'pass': bool(ok), 'logits_max_rel_err': err, 'loss': gpu['loss'], 'oracle_loss': ref_loss, 'loss_rel_err': loss_err,
+            'bound': GATE_LOGITS,
+            'argmax_mask': {'pixels': int(decided.numel()), 'compared_bit_exact': int(decided.sum()), 'mismatches': mismatch,
+                            'inside_top2_margin_not_compared': int((~decided).sum()),
+                            'disagreeing_inside_margin': int(((m_got != m_ref) & ~decided).sum())},
+            'dice': {'gpu': gpu['dice'], 'oracle': ref_dice, 'masks_identical': same_mask}}
+
+
+def gate_schedule(fb):
+    """Every parameter gradient of ONE captured pass as the timed loop runs it (lanes + lane scheduler + weight-gradient lane,
+    HIP-graph replay) against the same pass launched eagerly on one stream, at the bench's own size: 5e-5 of the tensor scale
+    (what differs is the order of atomics)."""
+    import torch
+    from senas_amd import grid
+    if fb.graph is None:
+        return None
+    params = [p for p in fb.reducer.sink.params if p.requires_grad]
+    frozen = set(id(p) for p in fb.frozen)
+    params = [p for p in params if id(p) not in frozen]
+    collect, fb._collectives = fb._collectives, False
+    try:
+        fb()                                            # the replay
+        torch.cuda.synchronize()
+        got = [p.grad.detach().clone() for p in params]
+        on, grid.Lanes.enabled = grid.Lanes.enabled, False
+        try:
+            fb._eager()
+        finally:
+            grid.Lanes.enabled = on
+        torch.cuda.synchronize()
+        want = [p.grad.detach().clone() for p in params]
+    finally:
+        fb._collectives = collect
+    top = max(float(v.abs().max()) for v in want)
+    worst = 0.0
+    for g, w in zip(got, want):
+        scale = max(float(w.abs().max()), 1e-3 * top)
+        worst = max(worst, float((g - w).abs().max()) / scale)
+    return {'pass': bool(worst <= GATE_SCHEDULE and top > 0), 'tensors': len(params), 'worst_rel_err': worst, 'bound': GATE_SCHEDULE,
+            'replayed_by': 'lane scheduler' if fb.sched is not None else 'runtime graph replay (one stream)'}
 
 
 BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
@@ -474,9 +565,12 @@ def main():
     opt = torch.optim.SGD(net.parameters(), lr=6e-3, weight_decay=5e-4, momentum=0.9)     # senas_promise12.yml training block
     x, y = synthetic(args.batch, 1, 2, args.size, 1 + rank, dev)
     from senas_amd.step import TrainStep
+    want_gate = rank == 0 and world == 1 and not args.no_cpu_baseline and args.profile_math == 'f32'
+    gate_gpu = gate_forward(net, crit, x, y) if want_gate else None
     log('model on %s, %d params; %s forward+backward' % (dev, sum(p.numel() for p in net.parameters()),
                                                           'eager' if args.no_graph else 'capturing HIP graph of'))
     step = TrainStep(net, crit, opt, x, y, world_size=world, grad_clip=5.0, use_graph=not args.no_graph)
+    gate_sched = gate_schedule(step.fb) if args.profile_math == 'f32' else None          # (before any optimizer step)
     log('warm-up x%d' % args.warmup)
     for _ in range(args.warmup):
         step()
@@ -557,6 +651,8 @@ def main():
                    'allreduce_overlapped_with_backward': bool(step.fb.graph_tail is not None)},
         'roofline': roof,
     }
+    if gate_sched is not None:
+        out['parity_gate'] = {'schedule_vs_serial_eager': gate_sched}
     log('train step: %.2f ms/step, %.2f images/s' % (ms_per_step, value))
     step.close()
     del step, net, opt
@@ -575,7 +671,8 @@ def main():
                 out['train_step_' + mode]['max_error_vs_oracle'] = acc[mode]
 
     if args.search_steps > 0:
-        out['search_step'] = bench_search(dev, args.search_steps, rank, world, use_graph=not args.no_graph)
+        out['search_step'] = bench_search(dev, args.search_steps, rank, world, use_graph=not args.no_graph,
+                                          gate=args.profile_math == 'f32' and not args.no_cpu_baseline)
         if rank == 0:
             log('search step: %s' % json.dumps(out['search_step']))
         if args.lp_steps > 0:
@@ -598,12 +695,22 @@ def main():
         log('cpu baseline on %d threads (cpu_count %s)' % (torch.get_num_threads(), os.cpu_count()))
         common = {'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model_name(),
                   'thread_cap': 'min(cores this process may run on, 16 = the GPU box\'s per-GPU CPU share); host reports %s CPUs' % os.cpu_count()}
-        v = cpu_baseline_train(args.batch, args.size, reps=3)
+        v, step0 = cpu_baseline_train(args.batch, args.size, reps=3)
+        if gate_gpu is not None:
+            g = gate_compare(gate_gpu, *step0)
+            g['what'] = ('step 0 of the timed network (seed-0 weights, the timed seed-1 batch, %dx1x%dx%d) on the GPU against the '
+                         'oracle\'s step 0 in cpu_baseline_train' % (args.batch, args.size, args.size))
+            out.setdefault('parity_gate', {})['step0_vs_oracle'] = g
         out['cpu_baseline'] = dict(common, value=round(v, 3),
                                    sample='same train step (oracle/senas_ref.py, torch-CPU fp32) on %dx1x%dx%d, best of 3 after 1 warm-up'
                                           % (args.batch, args.size, args.size))
         if 'search_step' in out:
-            v = cpu_baseline_search(4, 256, reps=2)
+            v, step0 = cpu_baseline_search(4, 256, reps=2)
+            gs = _PENDING_GATES.pop('search', None)
+            if gs is not None:
+                g = gate_compare(gs, *step0)
+                g['what'] = 'step 0 forward of the timed supernet (seed-0 weights, the timed 4x1x256x256 train batch) against the oracle\'s'
+                out['search_step'].setdefault('parity_gate', {})['step0_vs_oracle'] = g
             out['search_step']['cpu_baseline'] = dict(common, value=round(v, 3),
                                                       sample='same search step (arch pass + Adam, weight pass + clip + SGD) on 4+4 images '
                                                              '1x256x256, best of 2 after 1 warm-up; train images per second')
@@ -611,17 +718,24 @@ def main():
             # BASELINE.md section 3 literally: torch.set_num_threads(os.cpu_count()) -- on the GPU box that is the whole
             # 256-CPU host, of which this job owns a 16-CPU share, so the figure is reported beside the capped one, once
             torch.set_num_threads(os.cpu_count() or threads)
-            v = cpu_baseline_train(args.batch, args.size, reps=2)
+            v, _ = cpu_baseline_train(args.batch, args.size, reps=2)
             out['cpu_baseline']['uncapped'] = {'value': round(v, 3), 'threads': torch.get_num_threads(),
                                                'note': 'torch.set_num_threads(os.cpu_count()); cores this process may run on: %d'
                                                        % len(os.sched_getaffinity(0))}
+    gates = [g for blk in (out.get('parity_gate', {}), out.get('search_step', {}).get('parity_gate', {})) for g in blk.values() if g]
+    failed = [g for g in gates if not g['pass']]
+    if 'parity_gate' in out:
+        out['parity_gate']['pass'] = not failed
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        log('PARITY GATE FAILED: %s' % json.dumps(failed))
+        sys.exit(6)
 
 
-def bench_search(dev, steps, rank, world, use_graph=True):
+def bench_search(dev, steps, rank, world, use_graph=True, gate=False):
     """Supernet search step (BASELINE configs[2]; configs[3] with N ranks): arch step on 4 validation images (Adam) +
     weight step on 4 train images (SGD, clip 5) per GPU -- experiments/search_arc.py:252-299.  images/sec counts train
     images, whole job."""
@@ -639,6 +753,7 @@ def bench_search(dev, steps, rank, world, use_graph=True):
     opt_a = torch.optim.Adam(net.arch_parameters(), lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-3)
     xt, yt = synthetic(4, 1, 2, 256, 1 + rank, dev)
     xv, yv = synthetic(4, 1, 2, 256, 101 + rank, dev)
+    gate_gpu = gate_forward(net, crit, xt, yt) if (gate and rank == 0 and world == 1) else None
     log('search: supernet built, capturing forward+backward')
     search = SearchStep(net, crit, opt_w, opt_a, xt.clone(), yt.clone(), world_size=world, grad_clip=5.0, use_graph=use_graph,
                         count_nodes=use_graph and world == 1)
@@ -646,6 +761,16 @@ def bench_search(dev, steps, rank, world, use_graph=True):
     def step():
         return search(xt, yt, xv, yv)
 
+    gates = {}
+    if gate:
+        # both captured passes as the timed loop replays them against the same passes eagerly on one stream (before any optimizer step)
+        search.fb.x.copy_(xv)
+        search.fb.y.copy_(yv)
+        gates['architecture_pass_schedule_vs_serial_eager'] = gate_schedule(search.fb_arch)
+        search.fb.x.copy_(xt)
+        search.fb.y.copy_(yt)
+        gates['weight_pass_schedule_vs_serial_eager'] = gate_schedule(search.fb)
+        gates = {k: v for k, v in gates.items() if v is not None}
     log('search: warm-up steps')
     for _ in range(2):
         step()
@@ -677,6 +802,10 @@ def bench_search(dev, steps, rank, world, use_graph=True):
                                       'thousands of 3-40 us launches, no single kernel carries more than a few percent',
                         'graph_nodes_per_step': search.graph_nodes()},
            'schedule': _schedule_info(search.fb_arch, search.fb)}
+    if gates:
+        res['parity_gate'] = gates
+    if gate_gpu is not None:
+        _PENDING_GATES['search'] = gate_gpu         # (main compares it with the oracle's step 0 once the CPU baseline has run)
     search.close()
     return res
 

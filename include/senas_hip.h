@@ -222,9 +222,21 @@ int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* 
  * successive launches on one stream are ordered like ordinary graph launches.  Not thread-safe per scheduler.
  * senas_sched_info: out8 = {nodes run, lanes used, segments, cross-lane dependencies, kernel, memset, memcpy nodes, nodes
  * contracted away (empty nodes and relay markers)}.
- * senas_relay_marker: an empty kernel launched on the capture's origin stream at every hand-over between two lanes; the
- * scheduler cuts the false marker -> marker chain the capture records and contracts the markers away (csrc/sched.hip).  */
+ * A 2-D memset node is refused with SENAS_EUNSUPPORTED as well (the caller then captures the pass on one stream).  With
+ * GPU_MAX_HW_QUEUES overridden to anything but the runtime's default of 4, or fewer distinct hardware queues than the lanes
+ * need, the scheduler keeps everything on the caller's stream (one line on stderr; SENAS_SCHED_TRUST_QUEUES=1 skips the guard).
+ * senas_relay_marker: an empty kernel launched on the capture's origin stream at every hand-over between two lanes: it gives
+ * the chain of hand-overs the capture records on that stream nodes the scheduler recognises and CONTRACTS out of the graph
+ * (their parents become their children's parents; the chain itself is kept -- csrc/sched.hip says why).
+ * senas_sched_plan: the scheduler's plan alone, host arithmetic (no device, no graph): nodes 0..n-1 numbered topologically,
+ * edges from[e] -> to[e] (from < to), solo[v] != 0 (or solo NULL) for a node that must be a segment of its own.  Outputs:
+ * node_lane[n], node_segment[n]; *n_segments; seg_lane[n]; the segments segment k waits for are
+ * seg_deps[seg_dep_begin[k] .. seg_dep_begin[k+1]) (seg_dep_begin: n + 1 entries, seg_deps: max(m, 1)).  Segment indices are
+ * the issue order.  tests/test_host_logic.py checks the plan's invariants with it.  */
 int senas_relay_marker(void* stream);
+int senas_sched_plan(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const uint8_t* solo, int32_t max_lanes,
+                     int32_t* node_lane, int32_t* node_segment, int32_t* n_segments, int32_t* seg_lane,
+                     int32_t* seg_dep_begin, int32_t* seg_deps);
 /* A new non-blocking HIP stream of the current device (never destroyed).  The lanes of a captured pass must be streams of their
  * own: torch hands its streams out of a pool of 32 round-robin, and two "different" torch streams that are one hipStream_t turn the
  * star topology of the capture into lane-to-lane waits (the runtime then never returns from hipStreamEndCapture: csrc/sched.hip). */

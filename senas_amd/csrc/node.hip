@@ -996,6 +996,7 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
     const int V = (d.c % 4 == 0) ? 4 : 1;
     dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
     const size_t lds2 = ((size_t)2 * d.nterms * d.c + d.c) * sizeof(float);
+    SENAS_REQUIRE(lds2 <= 64 * 1024, "node_fwd: terms x channels too large for the combine kernel's coefficient stage (split the node: 2*T*c + c <= 16384)");
     if (V == 4) hipLaunchKernelGGL((node_combine_fwd_kernel<4>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, d.relu ? mask8 : nullptr, out_stats, y2, y2s, y2pad);
     else hipLaunchKernelGGL((node_combine_fwd_kernel<1>), grid, dim3(256), lds2, st, d.hw, d.c, d.nterms, d.n, zt, coef, shiftc, residual, d.relu, y, (uint8_t*)nullptr, (double*)nullptr, y2, y2s, y2pad);
     return launch_status("node_fwd");

@@ -118,6 +118,106 @@ static void lane_pool_grow(int want) {
     (void)hipGetLastError();
 }
 
+// ---- the plan: host arithmetic only (senas_sched_plan exposes it to the CPU tests) -----------------------------------------
+// Nodes are numbered in a topological order (every parent before its children).  Chain cover with at most L chains ("lanes"):
+// a node continues the lane of the latest parent that still ends its lane, else takes an unused lane, else the lane whose tail has
+// nothing left to feed and has idled longest, else the lane idle longest.  Lane 0 is the lane of node 0.  Segments: cut before a
+// node with a parent on another lane and after a node with a child on another lane; a `solo` node is a segment of its own.  A
+// segment waits for the LATEST segment of every other lane that holds a parent of its first node (stream order covers the earlier
+// ones).  Segment indices are the issue order and a topological order of the segments.
+struct PlanSeg {
+    int lane = 0;
+    std::vector<int> nodes, deps;
+    bool signals = false;
+};
+
+static void plan_schedule(int n, const std::vector<std::vector<int>>& par, const std::vector<std::vector<int>>& chi, const std::vector<char>& solo,
+                          int L, std::vector<int>& lane, std::vector<int>& seg_of, std::vector<PlanSeg>& segs, int& used, int& n_cross) {
+    lane.assign(n, -1);
+    std::vector<int> tail(L, -1), placed_children(n, 0), last_use(L, -1);
+    for (int v = 0; v < n; ++v) {
+        int best = -1;
+        for (int p : par[v])                                   // continue the lane of a parent that still ends its lane
+            if (tail[lane[p]] == p && (best < 0 || p > best)) best = p;
+        int l;
+        if (best >= 0) {
+            l = lane[best];
+        } else {
+            l = -1;
+            for (int q = 0; q < L && l < 0; ++q) if (tail[q] < 0) l = q;                       // an unused lane
+            if (l < 0) {                                                                       // a lane whose tail has nothing left to feed, idle longest
+                for (int q = 0; q < L; ++q) {
+                    const bool dead = placed_children[tail[q]] == (int)chi[tail[q]].size();
+                    if (dead && (l < 0 || last_use[q] < last_use[l])) l = q;
+                }
+            }
+            if (l < 0) { l = 0; for (int q = 1; q < L; ++q) if (last_use[q] < last_use[l]) l = q; }
+        }
+        lane[v] = l;
+        tail[l] = v;
+        last_use[l] = v;
+        for (int p : par[v]) ++placed_children[p];
+    }
+    // lane 0 = the lane of the first node (the caller's stream carries what the capture's origin stream started with)
+    if (n > 0 && lane[0] != 0) { const int a = lane[0]; for (auto& x : lane) x = (x == a ? 0 : (x == 0 ? a : x)); }
+    used = 0;
+    for (int v = 0; v < n; ++v) used = std::max(used, lane[v] + 1);
+    seg_of.assign(n, -1);
+    segs.clear();
+    std::vector<int> open(used, -1);
+    for (int v = 0; v < n; ++v) {
+        const int l = lane[v];
+        bool waits = false, feeds = false;
+        for (int p : par[v]) waits |= lane[p] != l;
+        for (int c : chi[v]) feeds |= lane[c] != l;
+        if (waits || solo[v] || open[l] < 0) {
+            segs.emplace_back();
+            segs.back().lane = l;
+            open[l] = (int)segs.size() - 1;
+        }
+        PlanSeg& sg = segs[open[l]];
+        sg.nodes.push_back(v);
+        seg_of[v] = open[l];
+        if (feeds) sg.signals = true;
+        if (feeds || solo[v]) open[l] = -1;
+    }
+    n_cross = 0;
+    for (auto& sg : segs) {
+        std::vector<int> latest(used, -1);                     // per source lane only the latest segment matters
+        for (int p : par[sg.nodes[0]])
+            if (lane[p] != sg.lane) { latest[lane[p]] = std::max(latest[lane[p]], seg_of[p]); ++n_cross; }
+        for (int q = 0; q < used; ++q) if (latest[q] >= 0) sg.deps.push_back(latest[q]);
+    }
+}
+
+// How many lanes a captured pass may be spread over.  The schedule is tuned to the runtime's default of FOUR hardware queues per
+// process: with GPU_MAX_HW_QUEUES = 5 / 6 / 8 the same step ran 1.4 - 2x SLOWER than on one stream, and with fewer than four
+// distinct queues the lanes share them (profiles/r4_lanes_queues.txt, r5_queue_guard.txt).  So: an override of that variable to
+// anything but 4, or a device that does not give `want` streams on distinct queues, keeps the serial schedule -- one line on
+// stderr, never a slower step.  SENAS_SCHED_TRUST_QUEUES=1 skips the guard (measurement).
+static int lanes_allowed(int want) {
+    if (want <= 1) return want;
+    if (const char* t = getenv("SENAS_SCHED_TRUST_QUEUES")) if (t[0] == '1') return want;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    static int warned = 0;
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES")) {
+        const int v = atoi(q);
+        if (v != 4) {
+            if (!warned++) fprintf(stderr, "[senas sched] GPU_MAX_HW_QUEUES=%d (the lane schedule is tuned to the default of 4): captured passes keep the serial schedule\n", v);
+            return 1;
+        }
+    }
+    const int need = std::min(want, 4);
+    lane_pool_grow(need);
+    const int have = (int)lane_pool().size();
+    if (have < need) {
+        if (!warned++) fprintf(stderr, "[senas sched] %d distinct hardware queue(s) where the lane schedule needs %d: captured passes keep the serial schedule\n", have, need);
+        return 1;
+    }
+    return want;
+}
+
 #define SCHED_HIP(call, what)                                                   \
     do {                                                                        \
         hipError_t e__ = (call);                                                \
@@ -204,9 +304,10 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         par0[b->second].push_back(a->second);
         chi0[a->second].push_back(b->second);
     }
-    // ---- markers and empty nodes: drop marker -> marker edges, then contract both kinds out of the graph
+    // ---- relay markers and empty nodes: contracted out of the graph (a removed node hands its parents to its children; the
+    // marker -> marker chain itself is kept: see the note at relay_marker_kernel)
     {
-        std::vector<char> marker(n, 0), gone(n, 0);
+        std::vector<char> gone(n, 0);
         for (size_t i = 0; i < n; ++i) {
             hipGraphNodeType t;
             SCHED_HIP(hipGraphNodeGetType(raw[i], &t), "hipGraphNodeGetType");
@@ -214,7 +315,7 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
             if (t == hipGraphNodeTypeKernel) {
                 hipKernelNodeParams p;
                 SCHED_HIP(hipGraphKernelNodeGetParams(raw[i], &p), "hipGraphKernelNodeGetParams");
-                if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { marker[i] = gone[i] = 1; ++S->n_marker; }
+                if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { gone[i] = 1; ++S->n_marker; }
             }
         }
         // contract in creation order: a removed node hands its parents to its children
@@ -277,64 +378,20 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
     std::vector<hipGraphNodeType> type(n);
     for (size_t v = 0; v < n; ++v) SCHED_HIP(hipGraphNodeGetType(raw[topo[v]], &type[v]), "hipGraphNodeGetType");
 
-    // ---- chain cover with at most max_lanes chains
-    const int L = max_lanes;
-    std::vector<int> lane(n, -1), tail(L, -1), placed_children(n, 0), last_use(L, -1);
-    for (int v = 0; v < (int)n; ++v) {
-        int best = -1;
-        for (int p : par[v])                                   // continue the lane of a parent that still ends its lane
-            if (tail[lane[p]] == p && (best < 0 || p > best)) best = p;
-        int l;
-        if (best >= 0) {
-            l = lane[best];
-        } else {
-            l = -1;
-            for (int q = 0; q < L && l < 0; ++q) if (tail[q] < 0) l = q;                       // an unused lane
-            if (l < 0) {                                                                       // a lane whose tail has nothing left to feed, idle longest
-                for (int q = 0; q < L; ++q) {
-                    const bool dead = placed_children[tail[q]] == (int)chi[tail[q]].size();
-                    if (dead && (l < 0 || last_use[q] < last_use[l])) l = q;
-                }
-            }
-            if (l < 0) { l = 0; for (int q = 1; q < L; ++q) if (last_use[q] < last_use[l]) l = q; }
-        }
-        lane[v] = l;
-        tail[l] = v;
-        last_use[l] = v;
-        for (int p : par[v]) ++placed_children[p];
-    }
-    // lane 0 = the lane of the first node (the caller's stream carries what the capture's origin stream started with)
-    if (lane[0] != 0) { const int a = lane[0]; for (auto& x : lane) x = (x == a ? 0 : (x == 0 ? a : x)); }
+    // ---- chain cover, segment cut, cross-lane dependencies (host arithmetic: plan_schedule above)
+    std::vector<char> solo(n, 0);
+    for (size_t v = 0; v < n; ++v) solo[v] = type[v] == hipGraphNodeTypeMemcpy;      // (not rebuilt from parameters: a segment of its own)
+    int L = lanes_allowed(max_lanes);
+    std::vector<int> lane, seg_of;
+    std::vector<PlanSeg> planned;
     int used = 0;
-    for (int v = 0; v < (int)n; ++v) used = std::max(used, lane[v] + 1);
-
-    // ---- segments: cut before a node with a parent on another lane, cut after a node with a child on another lane
-    std::vector<int> seg_of(n, -1), open(used, -1);
-    for (int v = 0; v < (int)n; ++v) {
-        const int l = lane[v];
-        // a memcpy node is a segment of its own: it is not rebuilt from parameters (the runtime's 1-D copy nodes do not hand
-        // theirs out) but kept as the one survivor of a clone of the captured graph
-        const bool solo = type[v] == hipGraphNodeTypeMemcpy;
-        bool waits = false, feeds = false;
-        for (int p : par[v]) waits |= lane[p] != l;
-        for (int c : chi[v]) feeds |= lane[c] != l;
-        if (waits || solo || open[l] < 0) {
-            S->segs.emplace_back();
-            S->segs.back().lane = l;
-            open[l] = (int)S->segs.size() - 1;
-        }
-        Segment& sg = S->segs[open[l]];
-        sg.nodes.push_back(v);
-        seg_of[v] = open[l];
-        if (feeds) sg.signals = true;
-        if (feeds || solo) open[l] = -1;
-    }
-    for (size_t k = 0; k < S->segs.size(); ++k) {
-        Segment& sg = S->segs[k];
-        std::vector<int> latest(used, -1);                     // per source lane only the latest segment matters
-        for (int p : par[sg.nodes[0]])
-            if (lane[p] != sg.lane) { latest[lane[p]] = std::max(latest[lane[p]], seg_of[p]); ++S->n_cross; }
-        for (int q = 0; q < used; ++q) if (latest[q] >= 0) sg.deps.push_back(latest[q]);
+    plan_schedule((int)n, par, chi, solo, L, lane, seg_of, planned, used, S->n_cross);
+    S->segs.resize(planned.size());
+    for (size_t k = 0; k < planned.size(); ++k) {
+        S->segs[k].lane = planned[k].lane;
+        S->segs[k].nodes.swap(planned[k].nodes);
+        S->segs[k].deps.swap(planned[k].deps);
+        S->segs[k].signals = planned[k].signals;
     }
 
     // ---- every segment as a single-branch graph
@@ -379,7 +436,11 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
                             kp.extra = nullptr;
                             SCHED_HIP(hipGraphAddKernelNode(&made, sg.graph, deps, nd, &kp), "hipGraphAddKernelNode (fill)");
                         } else {
-                            SCHED_HIP(hipGraphAddMemsetNode(&made, sg.graph, deps, nd, &p), "hipGraphAddMemsetNode");
+                            // a 2-D fill (or an element size the fill kernel does not write): the runtime's own memset node is the
+                            // path that did not fill its buffer -- refuse; the step driver then captures the pass on one stream
+                            set_error_msg("sched_create: the captured graph holds a 2-D memset node, which the lane scheduler does not re-issue");
+                            sched_free(S);
+                            return SENAS_EUNSUPPORTED;
                         }
                         ++S->n_memset;
                         break;
@@ -458,6 +519,35 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
     S->n_nodes = (int)n;
     S->n_lanes = used;
     *out = S;
+    return SENAS_OK;
+}
+
+extern "C" int senas_sched_plan(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const uint8_t* solo, int32_t max_lanes,
+                                int32_t* node_lane, int32_t* node_segment, int32_t* n_segments, int32_t* seg_lane,
+                                int32_t* seg_dep_begin, int32_t* seg_deps) {
+    SENAS_REQUIRE(n >= 1 && m >= 0 && (m == 0 || (from && to)) && max_lanes >= 1 && max_lanes <= 16 && node_lane && node_segment &&
+                  n_segments && seg_lane && seg_dep_begin && seg_deps, "sched_plan: bad argument");
+    std::vector<std::vector<int>> par(n), chi(n);
+    for (int e = 0; e < m; ++e) {
+        SENAS_REQUIRE(from[e] >= 0 && to[e] < n && from[e] < to[e], "sched_plan: nodes must be numbered topologically (from < to)");
+        par[to[e]].push_back(from[e]);
+        chi[from[e]].push_back(to[e]);
+    }
+    std::vector<char> so(n, 0);
+    if (solo) for (int v = 0; v < n; ++v) so[v] = solo[v] != 0;
+    std::vector<int> lane, seg_of;
+    std::vector<PlanSeg> segs;
+    int used = 0, cross = 0;
+    plan_schedule(n, par, chi, so, max_lanes, lane, seg_of, segs, used, cross);
+    for (int v = 0; v < n; ++v) { node_lane[v] = lane[v]; node_segment[v] = seg_of[v]; }
+    *n_segments = (int)segs.size();
+    int off = 0;
+    for (size_t k = 0; k < segs.size(); ++k) {
+        seg_lane[k] = segs[k].lane;
+        seg_dep_begin[k] = off;
+        for (int d : segs[k].deps) seg_deps[off++] = d;            // (at most one per other lane and never more than the edges: <= m)
+    }
+    seg_dep_begin[segs.size()] = off;
     return SENAS_OK;
 }
 

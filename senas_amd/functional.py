@@ -271,15 +271,16 @@ def run_wgrad(autograd_grads, tensors, fn):
         _WQ.append((fn, [t for t in tensors if t is not None and t.is_cuda]))
 
 
-def flush_wgrads():
-    """Launch the queued weight gradients on the lane, behind what the current stream holds so far."""
+def flush_wgrads(inline=False):
+    """Launch the queued weight gradients on the lane, behind what the current stream holds so far.  ``inline``: on the
+    current stream itself (whatever it launches next is then ordered behind them)."""
     if not _WQ:
         return
     q = list(_WQ)
     del _WQ[:]
     W = WLANE
     cur = torch.cuda.current_stream()
-    if W is None or W.device != cur.device:
+    if inline or W is None or W.device != cur.device:
         for fn, _ in q:
             fn()
         return
@@ -327,11 +328,16 @@ def wgrad_dest(w):
         v = SINK.dest(w)
         if v is not None:
             return v, None
-        if DEFER and SINK.pending(w):
-            # a further gradient of a parameter whose first one still has its sum deferred (a module applied twice, e.g.
-            # the shared head under deep supervision): that sum OVERWRITES the view, so it must run before autograd
-            # accumulates this one into the view
-            flush_deferred(reopen=True)
+        if SINK.pending(w):
+            # a further gradient of a parameter within one pass (a module applied twice, e.g. the shared head under deep
+            # supervision): autograd ADDS this one into the view, the first one's kernel OVERWRITES it -- so the first one must
+            # have run by then.  It may still sit in the weight-gradient lane's queue (the queue is then launched on the CURRENT
+            # stream: a lane that waited for the weight-gradient lane, which waits for the lanes, would close a cycle of waits
+            # between two non-origin streams of a capture -- grid.Lanes) or have its second stage deferred (that sum runs now).
+            if _WQ:
+                flush_wgrads(inline=True)
+            if DEFER:
+                flush_deferred(reopen=True)
     t = torch.empty_like(w)
     return t, t
 
@@ -1177,8 +1183,9 @@ class _Hop(torch.autograd.Function):
 
 
 def relay_marker():
-    """An empty kernel on the current (origin) stream while a pass is being captured: the lane scheduler recognises it, cuts the
-    false dependency chain between successive hand-overs and contracts it away (csrc/sched.hip)."""
+    """An empty kernel on the current (origin) stream while a pass is being captured: it gives the chain of hand-overs the
+    capture records on that stream nodes the lane scheduler recognises and contracts out of the graph (the chain itself is
+    kept: cutting it lost the origin stream's own waits -- csrc/sched.hip, note at relay_marker_kernel)."""
     if torch.cuda.is_current_stream_capturing():
         _lib.check(_lib.lib().senas_relay_marker(_stream()), 'senas_relay_marker')
 

@@ -90,6 +90,24 @@ class Lanes(object):
     harmless)."""
 
     enabled = True          # class-wide switch (False: every cell on the caller's stream, as the reference's loop)
+    # Inside a stream capture the columns only fork when whoever captures has said that the captured graph goes to the lane
+    # scheduler (``with Lanes.scheduled():`` -- the step drivers and the Evaluator): anybody else's ``torch.cuda.graph`` would
+    # instantiate the multi-branch graph on the runtime's own executor (SIGSEGV in hip::Graph::UpdateStreams,
+    # profiles/r4_graph_executor.txt) -- their capture gets the serial schedule.
+    _scheduled = 0
+
+    @staticmethod
+    @contextlib.contextmanager
+    def scheduled():
+        Lanes._scheduled += 1
+        try:
+            yield
+        finally:
+            Lanes._scheduled -= 1
+
+    @staticmethod
+    def allowed():
+        return Lanes.enabled and (Lanes._scheduled > 0 or not torch.cuda.is_current_stream_capturing())
 
     def __init__(self, device, columns):
         from . import functional as F
@@ -231,7 +249,7 @@ class MacroGrid(nn.Module):
         j + 1 is launched after that of up cell (1, j) and before that of (1, j - 1), and waits for exactly what it needs."""
         live = x is not None
         depth = self._depth
-        lanes = Lanes(x.device, depth - 1) if (live and Lanes.enabled and self.lanes and x.is_cuda and depth > 2) else None
+        lanes = Lanes(x.device, depth - 1) if (live and self.lanes and x.is_cuda and depth > 2 and Lanes.allowed()) else None
         cut = self.cut if live else None
         G = [[None] * (depth - i) for i in range(depth)]
 

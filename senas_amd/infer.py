@@ -82,7 +82,7 @@ class Evaluator(object):
         for attempt in (0, 1):
             reset_arena()
             graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'), Lanes.scheduled():   # (other threads -- the RCCL watchdog -- may touch the runtime)
                 self.logits, self.mask = self._eager()
             if not lanes:
                 break

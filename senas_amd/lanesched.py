@@ -7,7 +7,8 @@ import torch
 
 from . import _lib
 
-MAX_LANES = int(os.environ.get('SENAS_MAX_LANES', 4))           # lanes per captured pass: one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4)
+# lanes per captured pass: one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4); the scheduler takes 1 .. 16
+MAX_LANES = min(16, max(1, int(os.environ.get('SENAS_MAX_LANES', 4))))
 
 
 _PENDING = []          # scheduler handles whose destruction had to wait (see LaneSchedule.close)
@@ -19,14 +20,19 @@ class LaneSchedule(object):
         captured hipGraph_t and the memory pool the pass lives in)."""
         self.graph = graph
         self.handle = C.c_void_p()
-        _lib.check(_lib.lib().senas_sched_create(C.c_void_p(graph.raw_cuda_graph()), int(max_lanes or MAX_LANES), C.byref(self.handle)),
-                   'senas_sched_create')
+        # the device the pass was captured on: the scheduler's lane pool is per device and its segments are launched on that
+        # device's streams, whatever the current device is when launch() / close() are called
+        self.device = torch.cuda.current_device()
+        lanes = min(16, max(1, int(max_lanes or MAX_LANES)))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().senas_sched_create(C.c_void_p(graph.raw_cuda_graph()), lanes, C.byref(self.handle)), 'senas_sched_create')
         if os.environ.get('SENAS_SCHED_VERBOSE'):
             import sys
             sys.stderr.write('[lanesched] %s\n' % self.info())
 
     def launch(self):
-        _lib.check(_lib.lib().senas_sched_launch(self.handle, torch.cuda.current_stream().cuda_stream), 'senas_sched_launch')
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().senas_sched_launch(self.handle, torch.cuda.current_stream().cuda_stream), 'senas_sched_launch')
 
     def info(self):
         out = (C.c_int32 * 8)()
@@ -44,7 +50,7 @@ class LaneSchedule(object):
         if torch.cuda.is_current_stream_capturing():
             _PENDING.append(handle)
             return
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         for h in [handle] + _PENDING:
             _lib.lib().senas_sched_destroy(h)
         del _PENDING[:]

@@ -198,6 +198,12 @@ class _Node(torch.autograd.Function):
         return (None, dmix, ds_out) + tuple(grads)
 
 
+def max_terms(c):
+    """Addends one node launch takes at ``c`` channels: SENAS_MAX_TERMS, or fewer where the combine kernel's LDS stage of
+    coefficients and shifts (2 * T * c + c floats, csrc/node.hip senas_node_fwd) would pass 64 KiB (c = 256: 31)."""
+    return max(1, min(_lib.MAX_TERMS, (16384 - c) // (2 * c)))
+
+
 def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=None):
     """Normalise every term with its own BatchNorm2d (train or eval mode as the module says), apply
     SE gates, mix with ``mix`` (1-d tensor, one weight per term; None = all ones), add ``residual``
@@ -209,11 +215,13 @@ def bn_combine(terms, mix=None, residual=None, relu=False, out_stats=False, cat=
     T = len(terms)
     if T == 0:
         raise SenasHipError('bn_combine: no terms')
-    if T > _lib.MAX_TERMS:
+    width = next((tm.z.shape[1] for tm in terms if tm.z is not None), residual.shape[1] if residual is not None else 1)
+    cap = max_terms(width)
+    if T > cap:
         # more addends than one launch describes (a node with six inputs of a ``--meta_node_num 5`` search cell has 36,
-        # experiments/search_arc.py:38-44): the first SENAS_MAX_TERMS as a partial sum without activation, the rest on top of it
+        # experiments/search_arc.py:38-44): the first ``cap`` as a partial sum without activation, the rest on top of it
         # as their residual -- the same sum, one more pass over the partial result
-        head, tail = terms[:_lib.MAX_TERMS], terms[_lib.MAX_TERMS:]
+        head, tail = terms[:cap], terms[cap:]
         if isinstance(mix, F.SharedMix):
             if mix.count != T:
                 raise SenasHipError('bn_combine: %d shared mixing weights for %d terms' % (mix.count, T))

@@ -204,23 +204,27 @@ class GraphedForwardBackward(object):
         reset_arena()
         # a pass that runs on several lanes (grid.Lanes) is captured but never handed to the runtime's graph executor: the
         # captured graph is replayed by the lane scheduler (lanesched.LaneSchedule, csrc/sched.hip)
+        if os.environ.get('SENAS_NO_SCHED') and self.grid is not None:
+            # without the lane scheduler the pass is captured on ONE stream: a multi-branch capture is never handed to the
+            # runtime's own graph executor (SIGSEGV in hip::Graph::UpdateStreams: profiles/r4_graph_executor.txt)
+            self.grid.lanes = False
         lanes = Lanes.enabled and self.grid is not None and self.grid.lanes and self.grid._depth > 2
         keep = lanes or self.count_nodes
         graph = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # other threads (the RCCL watchdog) may touch the runtime
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'), Lanes.scheduled():   # (other threads -- the RCCL watchdog -- may touch the runtime)
             self.loss = self._head()
         if self.count_nodes:
             self.nodes = _graph_nodes(graph)
-        if lanes and not os.environ.get('SENAS_NO_SCHED'):
+        if lanes:
             self.sched = LaneSchedule(graph, self.max_lanes)
         elif keep:
-            graph.instantiate()              # (SENAS_NO_SCHED: diagnosis only -- the runtime's own executor on a multi-branch graph)
+            graph.instantiate()              # (a single-stream capture kept for its node count)
         if self.early is not None:
             tail = torch.cuda.CUDAGraph(keep_graph=True) if lanes else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tail, pool=graph.pool(), capture_error_mode='thread_local'):
+            with torch.cuda.graph(tail, pool=graph.pool(), capture_error_mode='thread_local'), Lanes.scheduled():
                 self._tail()
             self.graph_tail = tail
-            if lanes and not os.environ.get('SENAS_NO_SCHED'):
+            if lanes:
                 self.sched_tail = LaneSchedule(tail, self.max_lanes)
         return graph
 
@@ -310,8 +314,9 @@ class SearchStep(object):
         self.reducer = SinkReducer(self.sink, 0, last, world_size, process_group)
         self.arch_reducer = SinkReducer(self.sink, last, last, world_size, process_group)
         early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and last >= 2) else None
-        # five scheduler lanes on four hardware queues: the supernet's pass has six chains in flight (origin stream, four columns,
-        # weight gradients); measured 28.1 - 28.9 ms against 29.2 - 29.4 with four (profiles/r4_lanes_queues.txt)
+        # SEARCH_LANES (six) scheduler chains on four hardware queues: the supernet's pass has six chains in flight (origin stream,
+        # four columns, weight gradients); five and six are within the run-to-run spread, four lose 0.7 - 1.0 ms
+        # (profiles/r4_lanes_queues.txt, r4_wlane_modes.txt)
         self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, packer=packer,
                                               frozen=weights, count_nodes=count_nodes, max_lanes=SEARCH_LANES)
         # the weight pass does not repack: either the architecture pass just did, or __call__ does it (before alpha_begin)

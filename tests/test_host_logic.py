@@ -488,3 +488,99 @@ def test_macro_grid_schedule_reads_what_the_references_loop_reads(kind, depth, s
             assert pos[('o', i - 1, j + 1)] < pos[('o', i, j)]
             assert all(pos[('o', k, j)] < pos[('o', i, j)] for k in range(i) if ('o', k, j) in pos)
     assert gamma_index(2, 1) == 4
+
+
+def _plan(n, edges, max_lanes, solo=None):
+    """senas_sched_plan (csrc/sched.hip: the lane scheduler's plan, host arithmetic only) on a DAG numbered topologically."""
+    import ctypes as C
+    from senas_amd import _lib
+    m = len(edges)
+    I = C.c_int32
+    frm, to = (I * max(m, 1))(*[a for a, _ in edges]), (I * max(m, 1))(*[b for _, b in edges])
+    so = (C.c_uint8 * n)(*(solo or [0] * n))
+    node_lane, node_seg, seg_lane, dep_begin, deps = (I * n)(), (I * n)(), (I * n)(), (I * (n + 1))(), (I * max(m, 1))()
+    nseg = I(0)
+    _lib.check(_lib.lib().senas_sched_plan(n, m, frm, to, so, max_lanes, node_lane, node_seg, C.byref(nseg), seg_lane, dep_begin, deps),
+               'senas_sched_plan')
+    k = nseg.value
+    return list(node_lane), list(node_seg), [seg_lane[s] for s in range(k)], [[deps[i] for i in range(dep_begin[s], dep_begin[s + 1])] for s in range(k)]
+
+
+def _check_plan(n, edges, max_lanes, solo=None):
+    """The invariants every policy of the lane scheduler must keep (a policy change is then testable without a GPU):
+    every node in exactly one segment, a segment on one lane, nodes of a segment consecutive in issue order on their lane; segment
+    indices = issue order, every wait points to an EARLIER segment of another lane; and every edge of the DAG is enforced -- by
+    stream order (same lane, the parent's segment not later) or by a wait: some segment of the child's lane, issued no later than
+    the child's, waits for a segment of the parent's lane issued no earlier than the parent's."""
+    lane, seg, seg_lane, deps = _plan(n, edges, max_lanes, solo)
+    k = len(seg_lane)
+    assert all(0 <= l < max_lanes for l in lane) and lane[0] == 0
+    assert all(0 <= s < k for s in seg) and sorted(set(seg)) == list(range(k))
+    first = {}
+    for v in range(n):
+        assert seg_lane[seg[v]] == lane[v]
+        first.setdefault(seg[v], v)
+    assert [first[s] for s in range(k)] == sorted(first.values())            # segments are numbered by their first node: the issue order
+    for s in range(k):                                                        # a segment's nodes are consecutive among its lane's nodes
+        mine = [v for v in range(n) if seg[v] == s]
+        on_lane = [v for v in range(n) if lane[v] == seg_lane[s]]
+        i = on_lane.index(mine[0])
+        assert on_lane[i:i + len(mine)] == mine
+        for d in deps[s]:
+            assert 0 <= d < s and seg_lane[d] != seg_lane[s]
+    for s, flag in enumerate(solo or []):
+        if flag:
+            assert sum(1 for v in range(n) if seg[v] == seg[s]) == 1
+    for a, b in edges:
+        if lane[a] == lane[b]:
+            assert seg[a] <= seg[b]
+            continue
+        ok = any(seg_lane[d] == lane[a] and d >= seg[a]
+                 for s in range(seg[b] + 1) if seg_lane[s] == lane[b] for d in deps[s])
+        assert ok, ('edge %d -> %d is not enforced' % (a, b), lane[a], lane[b], seg[a], seg[b])
+    return lane, seg, seg_lane, deps
+
+
+def test_lane_scheduler_plan_on_synthetic_dags():
+    """csrc/sched.hip's chain cover + segment cut through senas_sched_plan (no device): dependencies preserved, issue order
+    topological, for a chain, a fork / join diamond, the macro grid's shape (a spine with columns hanging off it and handing
+    over to each other through it) and seeded random DAGs, at 1 .. 6 lanes."""
+    import numpy as np
+    # a chain: one lane, one segment
+    lane, seg, seg_lane, deps = _check_plan(6, [(i, i + 1) for i in range(5)], 4)
+    assert set(lane) == {0} and len(seg_lane) == 1 and deps == [[]]
+    # a diamond with three-node arms
+    edges = [(0, 1), (1, 2), (2, 3), (0, 4), (4, 5), (5, 6), (3, 7), (6, 7)]
+    lane, seg, seg_lane, deps = _check_plan(8, edges, 4)
+    assert len(set(lane)) == 2 and lane[1] == lane[2] == lane[3] and lane[4] == lane[5] == lane[6] != lane[1]
+    assert len(set(_check_plan(8, edges, 1)[0])) == 1                        # one lane: everything in issue order on it
+    # a solo node splits its chain
+    lane, seg, seg_lane, deps = _check_plan(5, [(i, i + 1) for i in range(4)], 2, solo=[0, 0, 1, 0, 0])
+    assert len(seg_lane) == 3
+    # the macro grid's shape: spine nodes s_0..s_4 in a chain; column j forks off s_j, runs 3 nodes, joins the spine's tail
+    n, edges = 0, []
+    spine = list(range(5))
+    n = 5
+    edges += [(i, i + 1) for i in range(4)]
+    tails = []
+    for j in range(4):
+        col = list(range(n, n + 3))
+        n += 3
+        edges += [(spine[j], col[0]), (col[0], col[1]), (col[1], col[2])]
+        tails.append(col[2])
+    edges += [(t, n) for t in tails] + [(spine[-1], n)]
+    n += 1
+    order = sorted(range(n))                                                  # (already topological: every edge goes up)
+    assert all(a < b for a, b in edges)
+    for L in (1, 2, 3, 4, 6):
+        _check_plan(n, edges, L)
+    # random DAGs
+    rng = np.random.RandomState(5)
+    for trial in range(40):
+        n = int(rng.randint(2, 60))
+        edges = set()
+        for b in range(1, n):
+            for a in rng.choice(b, size=min(b, int(rng.randint(0, 4))), replace=False):
+                edges.add((int(a), b))
+        solo = [int(rng.rand() < 0.05) for _ in range(n)]
+        _check_plan(n, sorted(edges), int(rng.randint(1, 7)), solo)

@@ -2,7 +2,7 @@
 """Kernel time per cell: cut a rocprofv3 --kernel-trace of `tools/lane_timeline.py <search|train> --serial --order order.json` into
 cells with the stamp kernels (senas_stamp) that bracket every cell's forward and backward part.
 
-    python tools/cell_kernels.py <trace dir> order.json [cell ...] > table.txt
+    python tools/cell_kernels.py <trace dir> order.json [--ordered] [cell ...] > table.txt
 
 The LAST replay of the run is the one whose stamps order.json lists (in time order); the last len(order) stamp kernels of the
 trace are matched with it one to one.  Prints, per requested cell (default: all, summary only) and direction, the kernels between
@@ -25,7 +25,8 @@ def short(name):
 def main():
     files = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)
     order = json.load(open(sys.argv[2]))
-    want = sys.argv[3:]
+    ordered = '--ordered' in sys.argv
+    want = [a for a in sys.argv[3:] if a != '--ordered']
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -51,6 +52,14 @@ def main():
         ks = [r for r in rows[lo + 1:hi] if 'stamp_kernel' not in r[2]]
         tot = sum(r[1] - r[0] for r in ks) / 1e3
         print('%-10s %-4s %5d %9d %9.1f' % (cell, 'fwd' if d == 'f' else 'bwd', k, len(ks), tot))
+        if cell in want and ordered:
+            # every launch in issue order: start offset from the cell's first kernel, duration, idle gap in front of it
+            print('\n== %s %s (pass %d), in order: %d launches, %.1f us of kernel time, %.1f us first start to last end' % (
+                cell, 'forward' if d == 'f' else 'backward', k, len(ks), tot, (ks[-1][1] - ks[0][0]) / 1e3 if ks else 0.0))
+            prev = None
+            for s, e, n, g in ks:
+                print('   %8.1f  %7.1f us  gap %6.1f  %s/%d' % ((s - ks[0][0]) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0, short(n)[:60], g))
+                prev = e
         if cell in want:
             fam = collections.defaultdict(lambda: [0, 0.0])
             for s, e, n, g in ks:

@@ -223,8 +223,9 @@ int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* 
  * senas_sched_info: out8 = {nodes run, lanes used, segments, cross-lane dependencies, kernel, memset, memcpy nodes, nodes
  * contracted away (empty nodes and relay markers)}.
  * A 2-D memset node is refused with SENAS_EUNSUPPORTED as well (the caller then captures the pass on one stream).  With
- * GPU_MAX_HW_QUEUES overridden to anything but the runtime's default of 4, or fewer distinct hardware queues than the lanes
- * need, the scheduler keeps everything on the caller's stream (one line on stderr; SENAS_SCHED_TRUST_QUEUES=1 skips the guard).
+ * GPU_MAX_HW_QUEUES overridden to more than the runtime's default of 4 (measured: slower than one stream), or no second
+ * hardware queue at all, the scheduler keeps everything on the caller's stream (one line on stderr;
+ * SENAS_SCHED_TRUST_QUEUES=1 skips the guard).
  * senas_relay_marker: an empty kernel launched on the capture's origin stream at every hand-over between two lanes: it gives
  * the chain of hand-overs the capture records on that stream nodes the scheduler recognises and CONTRACTS out of the graph
  * (their parents become their children's parents; the chain itself is kept -- csrc/sched.hip says why).
@@ -234,6 +235,22 @@ int senas_unstack_fwd(int n, int64_t hw, int c, int k, const float* src, float* 
  * seg_deps[seg_dep_begin[k] .. seg_dep_begin[k+1]) (seg_dep_begin: n + 1 entries, seg_deps: max(m, 1)).  Segment indices are
  * the issue order.  tests/test_host_logic.py checks the plan's invariants with it.  */
 int senas_relay_marker(void* stream);
+/* The typed markers of a hand-over between two lanes of a captured pass (senas_amd/grid.py Lanes.hand; csrc/sched.hip):
+ * kind 0 RELAY (what senas_relay_marker launches: on the capture's origin stream), 1 PRODUCER (on the lane that made the tensor,
+ * in front of the event the origin stream waits for), 2 CONSUMER (on the lane that reads it, behind its wait for the origin
+ * stream).  All are empty kernels the scheduler contracts out of the graph; a CONSUMER behind a RELAY takes as its
+ * dependencies what the relay's PRODUCER parents stand for and nothing else of the origin stream's history.
+ * senas_sched_contract: that contraction alone, host arithmetic: nodes numbered topologically, kind[v] = -1 for a node that runs,
+ * 0 / 1 / 2 for the marker kinds, 3 for an empty node; the surviving edges come back in out_from / out_to (cap entries).
+ * senas_sched_plan2: the "critical" policy's plan alone (path cover, segments, list scheduling on `streams` streams with the
+ * per-node durations node_us, NULL = 1 each): node_segment[n]; *n_segments; seg_stream[k]; seg_issue = the segments in launch
+ * order; dependencies as in senas_sched_plan.  tests/test_host_logic.py checks their invariants.  */
+int senas_marker(int kind, void* stream);
+int senas_sched_contract(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const int32_t* kind, int32_t* out_m,
+                         int32_t* out_from, int32_t* out_to, int32_t cap);
+int senas_sched_plan2(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const uint8_t* solo, const double* node_us,
+                      int32_t streams, int32_t* node_segment, int32_t* n_segments, int32_t* seg_stream, int32_t* seg_issue,
+                      int32_t* seg_dep_begin, int32_t* seg_deps);
 int senas_sched_plan(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const uint8_t* solo, int32_t max_lanes,
                      int32_t* node_lane, int32_t* node_segment, int32_t* n_segments, int32_t* seg_lane,
                      int32_t* seg_dep_begin, int32_t* seg_deps);

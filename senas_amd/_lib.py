@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
-EXPECTED_ABI = 31          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
+EXPECTED_ABI = 32          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
 SKIP_MAX = 8               # SENAS_SKIP_MAX
 MAX_STACK = 4
@@ -106,6 +106,9 @@ SIGNATURES = {
     'senas_unstack_fwd': (_I, [_I, _L, _I, _I, _P, _PP, _PP, _P]),
     'senas_stamp': (_I, [_P, _P]),
     'senas_relay_marker': (_I, [_P]),
+    'senas_marker': (_I, [_I, _P]),
+    'senas_sched_contract': (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _I]),
+    'senas_sched_plan2': (_I, [_I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'senas_stream_create': (_I, [C.POINTER(C.c_void_p)]),
     'senas_sched_create': (_I, [_P, _I, C.POINTER(C.c_void_p)]),
     'senas_sched_plan': (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

@@ -8,13 +8,24 @@
 // stream table out of bounds for some fork / join shapes (SIGSEGV inside hipGraphLaunch: profiles/r4_graph_executor.txt).
 // A linear graph on one stream is the path of that executor that has replayed this package's steps since round 1.
 //
-// So: take the captured hipGraph_t (never instantiated), read its nodes and edges, cover the DAG with at most L chains
-// ("lanes"), cut every chain where a dependency crosses lanes, rebuild every piece as a single-branch graph (kernel nodes
-// re-added from their own parameters, 1-D memsets as a fill kernel of this library, a memcpy node as the one survivor of a
-// clone of the captured graph; each node depending on its predecessor only), and at launch time issue the
-// pieces in topological order on L streams with an event per cross-lane dependency.  Dependencies are exactly the captured
-// ones (+ the chain order inside a lane); memory safety is the capture's (torch's caching allocator saw every lane as a
-// stream of its own).
+// So: take the captured hipGraph_t (never instantiated), read its nodes and edges, cut it into linear pieces ("segments"),
+// rebuild every piece as a single-branch graph (kernel nodes re-added from their own parameters, 1-D memsets as a fill kernel
+// of this library, a memcpy node as the one survivor of a clone of the captured graph; each node depending on its predecessor
+// only), and at launch time issue the pieces in a topological order on a few streams (one hardware queue each) with an event
+// per dependency that crosses streams.  Memory safety is the capture's (torch's caching allocator saw every lane as a stream
+// of its own).
+//
+// Two policies decide which piece runs where (SENAS_SCHED_POLICY):
+//   "critical" (default, round 5): the pieces are the maximal linear runs of a path cover of the DAG; every piece is TIMED once
+//       (a serial replay inside senas_sched_create), and a list scheduler deals them to the streams in the order a simulation of
+//       the streams starts them -- whenever a stream falls idle it takes, among the pieces whose dependencies have finished, the
+//       one with the longest remaining path to the end of the pass.  The pass's critical path (head -> column 0 -> first down
+//       cell) is then never queued behind a weight-gradient batch or a small cell that happens to share its stream.
+//   "chain" (round 4): cover the DAG with at most L chains ("lanes") greedily at node level, cut the chains where a dependency
+//       crosses lanes, lanes pinned to streams by node count.
+// Dependencies are the captured ones, with one exception that is the point of the typed markers (below): a reader behind a
+// CONSUMER marker depends on the PRODUCER-marked parents of the RELAY marker it waited for, not on the rest of the origin stream's
+// history.
 #include "common.h"
 
 #include <stdlib.h>
@@ -28,10 +39,11 @@
 namespace senas {
 
 struct Segment {
-    int lane = 0;
+    int lane = 0;                // the stream (index into Sched::lanes) this piece is launched on
     std::vector<int> nodes;      // indices into Sched::node (topological positions)
-    std::vector<int> deps;       // segments whose `done` event this one waits for
-    bool signals = false;        // somebody waits for it
+    std::vector<int> deps;       // segments whose `done` event this one waits for (those on its own stream need no event)
+    bool signals = false;        // somebody on another stream waits for it
+    float dur_us = 0.f;          // measured by the serial timing replay of senas_sched_create ("critical" policy)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipEvent_t done = nullptr;
@@ -39,6 +51,8 @@ struct Segment {
 
 struct Sched {
     std::vector<Segment> segs;
+    std::vector<int> issue;              // the order the segments are launched in (a topological order of the segments)
+    int policy = 1;                      // 1 critical, 0 chain
     std::vector<hipStream_t> lanes;      // from a process-wide pool (one lane only: empty, everything runs on the caller's stream)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t start = nullptr;
@@ -190,11 +204,130 @@ static void plan_schedule(int n, const std::vector<std::vector<int>>& par, const
     }
 }
 
+// ---- typed contraction (host arithmetic; senas_sched_contract exposes it to the CPU tests) -----------------------------------
+// kind[v]: -1 a node that runs; 0 RELAY, 1 PRODUCER, 2 CONSUMER marker; 3 an empty node.  Nodes numbered topologically.  On
+// return par[] of the surviving nodes holds surviving nodes only (chi[] is rebuilt from it); the others have par[] cleared.
+static void contract_markers(int n, std::vector<std::vector<int>>& par, std::vector<std::vector<int>>& chi, const std::vector<int>& kind) {
+    std::vector<std::vector<int>> via(n);                    // via[v]: the parents v inherited through a PRODUCER marker
+    auto add = [](std::vector<int>& to, int x) { if (std::find(to.begin(), to.end(), x) == to.end()) to.push_back(x); };
+    for (int i = 0; i < n; ++i) {
+        if (kind[i] < 0) continue;
+        // (topological order: every parent of i that was a marker is gone already, so par[i] holds running nodes only)
+        for (int c : chi[i]) {
+            auto& cp = par[c];
+            cp.erase(std::remove(cp.begin(), cp.end(), i), cp.end());
+            const bool narrow = kind[i] == 0 && kind[c] == 2 && !via[i].empty();      // RELAY -> CONSUMER: the hand-over's source only
+            for (int p : (narrow ? via[i] : par[i])) add(cp, p);
+            if (kind[i] == 1) for (int p : par[i]) add(via[c], p);
+        }
+        par[i].clear();
+    }
+    for (int v = 0; v < n; ++v) chi[v].clear();
+    for (int v = 0; v < n; ++v) for (int p : par[v]) chi[p].push_back(v);
+}
+
+// ---- the "critical" plan (host arithmetic; senas_sched_plan2 exposes it to the CPU tests) ----------------------------------
+// 1. Path cover: in topological order a node becomes the heir of its latest parent that has no heir yet.  2. Segments: the
+// maximal runs of a path in which no node but the first has a parent outside the run and no node but the last a child that is not
+// its heir (a `solo` node is a run of its own) -- so every parent of a segment's first node is the LAST node of its segment and
+// "wait for that segment" is exact.  Segments are numbered by their first node: the numbering is a topological order.
+struct Piece {
+    std::vector<int> nodes, deps, kids;
+};
+
+static void cut_pieces(int n, const std::vector<std::vector<int>>& par, const std::vector<std::vector<int>>& chi, const std::vector<char>& solo,
+                       std::vector<int>& seg_of, std::vector<Piece>& segs) {
+    std::vector<int> pred(n, -1), heir(n, -1);
+    for (int v = 0; v < n; ++v) {
+        if (solo[v]) continue;
+        int best = -1;
+        for (int p : par[v]) if (heir[p] < 0 && !solo[p] && p > best) best = p;
+        if (best >= 0) { pred[v] = best; heir[best] = v; }
+    }
+    seg_of.assign(n, -1);
+    segs.clear();
+    for (int v = 0; v < n; ++v) {
+        bool fresh = pred[v] < 0;
+        if (!fresh) {
+            const int p = pred[v];
+            for (int c : chi[p]) fresh |= c != v;                                   // the predecessor feeds somebody else too: it ends its segment
+            for (int q : par[v]) fresh |= q != p && seg_of[q] != seg_of[p];        // a parent outside the open segment: a wait in front of v
+        }
+        if (fresh) {
+            segs.emplace_back();
+            seg_of[v] = (int)segs.size() - 1;
+            for (int q : par[v]) {
+                auto& d = segs.back().deps;
+                if (std::find(d.begin(), d.end(), seg_of[q]) == d.end()) d.push_back(seg_of[q]);
+            }
+        } else {
+            seg_of[v] = seg_of[pred[v]];
+        }
+        segs[seg_of[v]].nodes.push_back(v);
+    }
+    for (size_t k = 0; k < segs.size(); ++k) for (int d : segs[k].deps) segs[d].kids.push_back((int)k);
+}
+
+// 3. List scheduling on S streams with the measured durations: a simulation in which, whenever a stream is idle, it takes --
+// among the segments whose dependencies have FINISHED -- the one with the longest remaining path (its own duration + the longest
+// chain of dependants); an idle stream that ran one of the segment's dependencies is preferred (no event, no cross-queue
+// latency).  `stream[k]`, and `issue` = the segments in the order the simulation starts them (topological; per stream it is the
+// stream's FIFO order).
+static void list_schedule(const std::vector<Piece>& segs, const std::vector<double>& dur, int S, std::vector<int>& stream, std::vector<int>& issue) {
+    const int K = (int)segs.size();
+    std::vector<double> bottom(K, 0.0), finish(K, 0.0);
+    for (int k = K - 1; k >= 0; --k) {
+        double b = 0.0;
+        for (int c : segs[k].kids) b = std::max(b, bottom[c]);
+        bottom[k] = b + std::max(dur[k], 1e-3);
+    }
+    std::vector<int> waiting(K), state(K, 0);                  // state: 0 not ready, 1 ready, 2 started
+    for (int k = 0; k < K; ++k) { waiting[k] = (int)segs[k].deps.size(); if (!waiting[k]) state[k] = 1; }
+    std::vector<double> free_at(S, 0.0);
+    std::vector<int> running(S, -1);
+    stream.assign(K, 0);
+    issue.clear();
+    double t = 0.0;
+    int started = 0;
+    while (started < K) {
+        // retire what has finished by t
+        for (int q = 0; q < S; ++q)
+            if (running[q] >= 0 && free_at[q] <= t) {
+                for (int c : segs[running[q]].kids) if (--waiting[c] == 0) state[c] = 1;
+                running[q] = -1;
+            }
+        for (;;) {
+            int best = -1;
+            for (int k = 0; k < K; ++k) if (state[k] == 1 && (best < 0 || bottom[k] > bottom[best])) best = k;
+            if (best < 0) break;
+            int q = -1;
+            double latest = -1.0;
+            for (int d : segs[best].deps)                      // an idle stream that ran a dependency (the one that finished last)
+                if (running[stream[d]] < 0 && finish[d] > latest) { latest = finish[d]; q = stream[d]; }
+            for (int r = 0; r < S && q < 0; ++r) if (running[r] < 0) q = r;
+            if (q < 0) break;                                  // every stream is busy
+            stream[best] = q;
+            running[q] = best;
+            state[best] = 2;
+            finish[best] = free_at[q] = t + std::max(dur[best], 1e-3);
+            issue.push_back(best);
+            ++started;
+        }
+        double next = 1e300;
+        for (int q = 0; q < S; ++q) if (running[q] >= 0) next = std::min(next, free_at[q]);
+        if (next < 1e300) { t = next; continue; }
+        // nothing runs and nothing is ready although segments remain: only a malformed dependency list gets here -- issue the
+        // rest in their numbering (a topological order) on stream 0 rather than spin
+        for (int k = 0; k < K; ++k) if (state[k] != 2) { state[k] = 2; stream[k] = 0; issue.push_back(k); ++started; }
+    }
+}
+
 // How many lanes a captured pass may be spread over.  The schedule is tuned to the runtime's default of FOUR hardware queues per
-// process: with GPU_MAX_HW_QUEUES = 5 / 6 / 8 the same step ran 1.4 - 2x SLOWER than on one stream, and with fewer than four
-// distinct queues the lanes share them (profiles/r4_lanes_queues.txt, r5_queue_guard.txt).  So: an override of that variable to
-// anything but 4, or a device that does not give `want` streams on distinct queues, keeps the serial schedule -- one line on
-// stderr, never a slower step.  SENAS_SCHED_TRUST_QUEUES=1 skips the guard (measurement).
+// process.  Measured (profiles/r5_queue_guard.txt; search step, ms): default 28.5; GPU_MAX_HW_QUEUES=6 with lanes 43.7, =8 54.7
+// (round 4) against 34.9 on one stream -- MORE queues than four make the step slower than no lanes at all; =3 with lanes 28.8, =2
+// 31.3 -- FEWER queues still beat one stream (the lanes share the queues there are).  So: an override above 4 keeps the serial
+// schedule, one line on stderr, never a slower step; below 4 the lanes run on what the probe finds.  No distinct second queue at
+// all: serial.  SENAS_SCHED_TRUST_QUEUES=1 skips the guard (measurement).
 static int lanes_allowed(int want) {
     if (want <= 1) return want;
     if (const char* t = getenv("SENAS_SCHED_TRUST_QUEUES")) if (t[0] == '1') return want;
@@ -203,16 +336,15 @@ static int lanes_allowed(int want) {
     static int warned = 0;
     if (const char* q = getenv("GPU_MAX_HW_QUEUES")) {
         const int v = atoi(q);
-        if (v != 4) {
-            if (!warned++) fprintf(stderr, "[senas sched] GPU_MAX_HW_QUEUES=%d (the lane schedule is tuned to the default of 4): captured passes keep the serial schedule\n", v);
+        if (v > 4) {
+            if (!warned++) fprintf(stderr, "[senas sched] GPU_MAX_HW_QUEUES=%d (more hardware queues than the default 4 make the lane schedule slower than one stream): captured passes keep the serial schedule\n", v);
             return 1;
         }
     }
-    const int need = std::min(want, 4);
-    lane_pool_grow(need);
+    lane_pool_grow(2);
     const int have = (int)lane_pool().size();
-    if (have < need) {
-        if (!warned++) fprintf(stderr, "[senas sched] %d distinct hardware queue(s) where the lane schedule needs %d: captured passes keep the serial schedule\n", have, need);
+    if (have < 2) {
+        if (!warned++) fprintf(stderr, "[senas sched] no second hardware queue: captured passes keep the serial schedule\n");
         return 1;
     }
     return want;
@@ -234,7 +366,13 @@ static int lanes_allowed(int want) {
 // made since its last kernel (autograd's hand-overs TO the origin stream, join_lanes), and the origin's next real kernel
 // reaches those only through the chain: the cut loses them (measured: dirty weight gradients of the first down cell).  So the
 // chain is kept; telling the two kinds of children of a marker apart needs a marker on the consumer side too (not built).
-__global__ void relay_marker_kernel() {}
+// Kinds (senas_marker): 0 RELAY -- on the capture's origin stream at a hand-over; 1 PRODUCER -- on the lane that made the tensor
+// (the gradient, on the way back), in front of the event the origin stream waits for; 2 CONSUMER -- on the lane that reads it,
+// behind its wait for the origin stream.  A RELAY marker R has parents {origin stream's previous node and whatever else that
+// stream had waited for, PRODUCER markers}; its children are CONSUMER markers (the readers) and the origin stream's next node.
+// Contraction: a CONSUMER child inherits only what R's PRODUCER parents stand for; any other child inherits everything (the
+// origin stream's own chain keeps every wait it ever made -- the cut that lost some of them in round 4 is not made).
+__global__ void relay_marker_kernel(int kind) {}
 
 // A captured 1-D memset as a kernel: count elements of esz bytes (1, 2 or 4) set to the low esz bytes of value; dst is aligned
 // to esz (it is an array of such elements), so every aligned 32-bit word holds whole elements and takes the replicated pattern.
@@ -277,10 +415,13 @@ extern "C" int senas_stamp(uint64_t* slot, void* stream) {
     return launch_status("stamp");
 }
 
-extern "C" int senas_relay_marker(void* stream) {
-    hipLaunchKernelGGL(relay_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream));
-    return launch_status("relay_marker");
+extern "C" int senas_marker(int kind, void* stream) {
+    SENAS_REQUIRE(kind >= 0 && kind <= 2, "marker: kind must be 0 (relay), 1 (producer) or 2 (consumer)");
+    hipLaunchKernelGGL(relay_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream), kind);
+    return launch_status("marker");
 }
+
+extern "C" int senas_relay_marker(void* stream) { return senas_marker(0, stream); }
 
 extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
     SENAS_REQUIRE(hip_graph && out && max_lanes >= 1 && max_lanes <= 16, "sched_create: bad argument");
@@ -304,94 +445,101 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
         par0[b->second].push_back(a->second);
         chi0[a->second].push_back(b->second);
     }
-    // ---- relay markers and empty nodes: contracted out of the graph (a removed node hands its parents to its children; the
-    // marker -> marker chain itself is kept: see the note at relay_marker_kernel)
+    // ---- topological order of everything captured, ties broken by the runtime's own node order (creation order)
+    std::vector<int> topo, pos(n);
     {
-        std::vector<char> gone(n, 0);
+        std::vector<int> indeg(n);
+        for (size_t i = 0; i < n; ++i) indeg[i] = (int)par0[i].size();
+        std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+        for (size_t i = 0; i < n; ++i) if (!indeg[i]) ready.push((int)i);
+        while (!ready.empty()) {
+            const int v = ready.top();
+            ready.pop();
+            pos[v] = (int)topo.size();
+            topo.push_back(v);
+            for (int c : chi0[v]) if (--indeg[c] == 0) ready.push(c);
+        }
+        if (topo.size() != n) { set_error_msg("sched_create: the captured graph has a cycle"); sched_free(S); return SENAS_EINVAL; }
+    }
+    // ---- markers and empty nodes: contracted out of the graph (contract_markers: a removed node hands its parents to its
+    // children; a CONSUMER marker behind a RELAY marker only takes what the relay's PRODUCER markers stand for)
+    {
+        std::vector<std::vector<int>> par(n), chi(n);
+        std::vector<int> kind(n, -1);
         for (size_t i = 0; i < n; ++i) {
+            for (int p : par0[i]) par[pos[i]].push_back(pos[p]);
+            for (int c : chi0[i]) chi[pos[i]].push_back(pos[c]);
             hipGraphNodeType t;
             SCHED_HIP(hipGraphNodeGetType(raw[i], &t), "hipGraphNodeGetType");
-            if (t == hipGraphNodeTypeEmpty) { gone[i] = 1; ++S->n_empty; }
+            if (t == hipGraphNodeTypeEmpty) { kind[pos[i]] = 3; ++S->n_empty; }
             if (t == hipGraphNodeTypeKernel) {
                 hipKernelNodeParams p;
                 SCHED_HIP(hipGraphKernelNodeGetParams(raw[i], &p), "hipGraphKernelNodeGetParams");
-                if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) { gone[i] = 1; ++S->n_marker; }
+                if (p.func == reinterpret_cast<void*>(relay_marker_kernel)) {
+                    int k = 0;
+                    if (p.kernelParams && p.kernelParams[0]) k = *reinterpret_cast<int*>(p.kernelParams[0]);
+                    kind[pos[i]] = (k >= 0 && k <= 2) ? k : 0;
+                    ++S->n_marker;
+                }
             }
         }
-        // contract in creation order: a removed node hands its parents to its children
-        for (size_t i = 0; i < n; ++i) {
-            if (!gone[i]) continue;
-            for (int c : chi0[i]) {
-                auto& cp = par0[c];
-                cp.erase(std::remove(cp.begin(), cp.end(), (int)i), cp.end());
-                for (int p : par0[i]) if (std::find(cp.begin(), cp.end(), p) == cp.end()) cp.push_back(p);
-            }
-            for (int p : par0[i]) {
-                auto& pc = chi0[p];
-                pc.erase(std::remove(pc.begin(), pc.end(), (int)i), pc.end());
-                for (int c : chi0[i]) if (std::find(pc.begin(), pc.end(), c) == pc.end()) pc.push_back(c);
-            }
-            par0[i].clear();
-            chi0[i].clear();
-        }
-        // compact: only the surviving nodes take part from here on
+        size_t edges_before = 0, edges_after = 0;
+        for (size_t v = 0; v < n; ++v) edges_before += par[v].size();
+        contract_markers((int)n, par, chi, kind);
+        // compact: only the surviving nodes take part from here on, numbered in the same topological order
         std::vector<int> newidx(n, -1);
         std::vector<hipGraphNode_t> kept;
-        for (size_t i = 0; i < n; ++i) if (!gone[i]) { newidx[i] = (int)kept.size(); kept.push_back(raw[i]); }
+        for (size_t v = 0; v < n; ++v) if (kind[v] < 0) { newidx[v] = (int)kept.size(); kept.push_back(raw[topo[v]]); }
         if (kept.empty()) { set_error_msg("sched_create: the graph has no nodes to run"); sched_free(S); return SENAS_EINVAL; }
-        std::vector<std::vector<int>> np(kept.size()), nc(kept.size());
-        for (size_t i = 0; i < n; ++i) {
-            if (gone[i]) continue;
-            for (int p : par0[i]) np[newidx[i]].push_back(newidx[p]);
-            for (int c : chi0[i]) nc[newidx[i]].push_back(newidx[c]);
+        par0.assign(kept.size(), {});
+        chi0.assign(kept.size(), {});
+        for (size_t v = 0; v < n; ++v) {
+            if (kind[v] >= 0) continue;
+            for (int p : par[v]) { par0[newidx[v]].push_back(newidx[p]); chi0[newidx[p]].push_back(newidx[v]); ++edges_after; }
         }
+        if (getenv("SENAS_SCHED_VERBOSE"))
+            fprintf(stderr, "[sched] %zu captured nodes, %zu edges; %d markers and %d empty nodes contracted: %zu nodes, %zu edges\n", n, edges_before,
+                    S->n_marker, S->n_empty, kept.size(), edges_after);
         S->n_captured = (int)n;
         raw.swap(kept);
-        par0.swap(np);
-        chi0.swap(nc);
         n = raw.size();
     }
-    if (getenv("SENAS_SCHED_VERBOSE")) {
-        size_t back = 0, edges = 0;
-        for (size_t i = 0; i < n; ++i) for (int p : par0[i]) { ++edges; if ((size_t)p > i) ++back; }
-        fprintf(stderr, "[sched] %zu nodes, %zu edges, %zu edges point from a later node of hipGraphGetNodes to an earlier one\n", n, edges, back);
-    }
-    // topological order, ties broken by the runtime's own node order (creation order)
-    std::vector<int> indeg(n), topo, pos(n);
-    for (size_t i = 0; i < n; ++i) indeg[i] = (int)par0[i].size();
-    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
-    for (size_t i = 0; i < n; ++i) if (!indeg[i]) ready.push((int)i);
-    while (!ready.empty()) {
-        const int v = ready.top();
-        ready.pop();
-        pos[v] = (int)topo.size();
-        topo.push_back(v);
-        for (int c : chi0[v]) if (--indeg[c] == 0) ready.push(c);
-    }
-    if (topo.size() != n) { set_error_msg("sched_create: the captured graph has a cycle"); sched_free(S); return SENAS_EINVAL; }
-    // from here on a node is its topological position
-    std::vector<std::vector<int>> par(n), chi(n);
-    for (size_t i = 0; i < n; ++i) {
-        for (int p : par0[i]) par[pos[i]].push_back(pos[p]);
-        for (int c : chi0[i]) chi[pos[i]].push_back(pos[c]);
-    }
+    // from here on a node is its (compacted) topological position; raw[v] is its captured node
+    std::vector<std::vector<int>>& par = par0;
+    std::vector<std::vector<int>>& chi = chi0;
     std::vector<hipGraphNodeType> type(n);
-    for (size_t v = 0; v < n; ++v) SCHED_HIP(hipGraphNodeGetType(raw[topo[v]], &type[v]), "hipGraphNodeGetType");
+    for (size_t v = 0; v < n; ++v) SCHED_HIP(hipGraphNodeGetType(raw[v], &type[v]), "hipGraphNodeGetType");
 
-    // ---- chain cover, segment cut, cross-lane dependencies (host arithmetic: plan_schedule above)
+    // ---- the plan (host arithmetic: plan_schedule / cut_pieces + list_schedule above)
     std::vector<char> solo(n, 0);
     for (size_t v = 0; v < n; ++v) solo[v] = type[v] == hipGraphNodeTypeMemcpy;      // (not rebuilt from parameters: a segment of its own)
-    int L = lanes_allowed(max_lanes);
-    std::vector<int> lane, seg_of;
-    std::vector<PlanSeg> planned;
+    const int L = lanes_allowed(max_lanes);
+    int policy = 1;
+    if (const char* pol = getenv("SENAS_SCHED_POLICY")) policy = (pol[0] == 'c' && pol[1] == 'h') ? 0 : 1;      // "chain" | "critical"
+    S->policy = policy;
     int used = 0;
-    plan_schedule((int)n, par, chi, solo, L, lane, seg_of, planned, used, S->n_cross);
-    S->segs.resize(planned.size());
-    for (size_t k = 0; k < planned.size(); ++k) {
-        S->segs[k].lane = planned[k].lane;
-        S->segs[k].nodes.swap(planned[k].nodes);
-        S->segs[k].deps.swap(planned[k].deps);
-        S->segs[k].signals = planned[k].signals;
+    std::vector<Piece> pieces;
+    if (policy == 0 || L <= 1) {
+        std::vector<int> lane, seg_of;
+        std::vector<PlanSeg> planned;
+        plan_schedule((int)n, par, chi, solo, L, lane, seg_of, planned, used, S->n_cross);
+        S->segs.resize(planned.size());
+        for (size_t k = 0; k < planned.size(); ++k) {
+            S->segs[k].lane = planned[k].lane;
+            S->segs[k].nodes.swap(planned[k].nodes);
+            S->segs[k].deps.swap(planned[k].deps);
+            S->segs[k].signals = planned[k].signals;
+            S->issue.push_back((int)k);
+        }
+        S->policy = 0;
+    } else {
+        std::vector<int> seg_of;
+        cut_pieces((int)n, par, chi, solo, seg_of, pieces);
+        S->segs.resize(pieces.size());
+        for (size_t k = 0; k < pieces.size(); ++k) {
+            S->segs[k].nodes = pieces[k].nodes;
+            S->segs[k].deps = pieces[k].deps;
+        }
     }
 
     // ---- every segment as a single-branch graph
@@ -400,7 +548,7 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
             SCHED_HIP(hipGraphCreate(&sg.graph, 0), "hipGraphCreate");
             hipGraphNode_t prev = nullptr;
             for (int v : sg.nodes) {
-                hipGraphNode_t src = raw[topo[v]], made = nullptr;
+                hipGraphNode_t src = raw[v], made = nullptr;
                 const hipGraphNode_t* deps = prev ? &prev : nullptr;
                 const size_t nd = prev ? 1 : 0;
                 switch (type[v]) {
@@ -470,43 +618,89 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
             }
             SCHED_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0), "hipGraphInstantiate");
         }
-        if (sg.signals) SCHED_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming), "hipEventCreateWithFlags");
     }
-    S->lanes.assign(used, nullptr);
-    S->lane_done.assign(used, nullptr);
-    if (used > 1) {
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lock(mu);
-        lane_pool_grow(used);
-        auto& pool = lane_pool();
+    auto& pool = lane_pool();
+    if (S->policy == 0) {
+        // ---- "chain": lanes pinned to streams by node count
+        S->lanes.assign(used, nullptr);
+        if (used > 1) {
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lock(mu);
+            lane_pool_grow(used);
+            if (pool.empty()) { set_error_msg("sched_create: no lane stream could be created"); sched_free(S); return SENAS_ELAUNCH; }
+            // fewer hardware queues than lanes: the lanes with the fewest nodes share streams, the heaviest keep theirs to themselves
+            // (rank by node count; rank r < P owns stream r; rank P + i shares with rank P - 1 - (i mod P), the lightest owners first)
+            const int P = (int)pool.size();
+            std::vector<int> weight(used, 0), order(used);
+            for (auto& sg : S->segs) weight[sg.lane] += (int)sg.nodes.size();
+            for (int q = 0; q < used; ++q) order[q] = q;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
+            // (which owner the fifth lane shares with moves the search step by 0.9 ms: lightest 28.4, heaviest 29.3 -- r4_lanes_queues.txt)
+            for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
+        }
+    } else {
+        // ---- "critical": time every segment once (a serial replay on one stream: the segments' numbering is a topological order, and
+        // the pass is self-contained -- it zeroes what it accumulates into), then deal them to the streams there are
+        {
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lock(mu);
+            lane_pool_grow(std::min(L, 4));
+        }
         if (pool.empty()) { set_error_msg("sched_create: no lane stream could be created"); sched_free(S); return SENAS_ELAUNCH; }
-        // fewer hardware queues than lanes: the lanes with the fewest nodes share streams, the heaviest keep theirs to themselves
-        // (rank by node count; rank r < P owns stream r; rank P + i shares with rank P - 1 - (i mod P), the lightest owners first)
-        const int P = (int)pool.size();
-        std::vector<int> weight(used, 0), order(used);
-        for (int v = 0; v < (int)n; ++v) ++weight[lane[v]];
-        for (int q = 0; q < used; ++q) order[q] = q;
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] != weight[b] ? weight[a] > weight[b] : a < b; });
-        // (which owner the fifth lane shares with moves the search step by 0.9 ms: lightest 28.4, heaviest 29.3 -- r4_lanes_queues.txt)
-        for (int r = 0; r < used; ++r) S->lanes[order[r]] = pool[r < P ? r : P - 1 - ((r - P) % P)];
+        const int P = std::min((int)pool.size(), L);
+        const int K = (int)S->segs.size();
+        std::vector<double> dur(K, 1.0);
+        if (const char* t = getenv("SENAS_SCHED_NO_TIMING"); t && t[0] == '1') {
+            for (int k = 0; k < K; ++k) dur[k] = (double)S->segs[k].nodes.size();      // (measurement: node counts instead of times)
+        } else {
+            std::vector<hipEvent_t> ev(K + 1, nullptr);
+            hipStream_t st = pool[0];
+            bool ok = hipDeviceSynchronize() == hipSuccess;
+            for (int k = 0; k <= K && ok; ++k) ok = hipEventCreate(&ev[k]) == hipSuccess;
+            for (int rep = 0; rep < 2 && ok; ++rep) {
+                for (int k = 0; k < K && ok; ++k) {
+                    ok = hipEventRecord(ev[k], st) == hipSuccess;
+                    if (ok && S->segs[k].exec) ok = hipGraphLaunch(S->segs[k].exec, st) == hipSuccess;
+                }
+                ok = ok && hipEventRecord(ev[K], st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            }
+            for (int k = 0; k < K && ok; ++k) {
+                float ms = 0.f;
+                ok = hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess;
+                dur[k] = 1e3 * (double)ms;
+            }
+            for (auto e : ev) if (e) (void)hipEventDestroy(e);
+            if (!ok) { set_error("sched_create: the timing replay", hipGetLastError()); sched_free(S); return SENAS_ELAUNCH; }
+        }
+        std::vector<int> stream;
+        list_schedule(pieces, dur, P, stream, S->issue);
+        used = 0;
+        for (int k = 0; k < K; ++k) { S->segs[k].lane = stream[k]; S->segs[k].dur_us = (float)dur[k]; used = std::max(used, stream[k] + 1); }
+        for (int k = 0; k < K; ++k)
+            for (int d : S->segs[k].deps) if (stream[d] != stream[k]) { S->segs[d].signals = true; ++S->n_cross; }
+        S->lanes.assign(used, nullptr);
+        for (int q = 0; q < used; ++q) S->lanes[q] = pool[q];
     }
+    S->lane_done.assign(used, nullptr);
+    for (auto& sg : S->segs)
+        if (sg.signals) SCHED_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming), "hipEventCreateWithFlags");
     if (const char* path = getenv("SENAS_SCHED_DUMP")) {
-        // tools/lane_timeline.py --segments: which segment, lane and stream every time stamp of the pass (i.e. every cell boundary) sits
-        // on, and which segments each one waits for
+        // tools/lane_timeline.py --segments: which segment and stream every time stamp of the pass (i.e. every cell boundary) sits on,
+        // which segments each one waits for, its measured duration; in issue order
         if (FILE* f = fopen(path, "a")) {
-            fprintf(f, "sched nodes %zu lanes %d segments %zu\n", n, used, S->segs.size());
-            auto& pool = lane_pool();
-            for (size_t k = 0; k < S->segs.size(); ++k) {
+            fprintf(f, "sched nodes %zu lanes %d segments %zu policy %s\n", n, used, S->segs.size(), S->policy ? "critical" : "chain");
+            for (int k : S->issue) {
                 const Segment& sg = S->segs[k];
                 int stream = -1;
                 for (size_t r = 0; r < pool.size(); ++r) if (used > 1 && pool[r] == S->lanes[sg.lane]) stream = (int)r;
-                fprintf(f, "seg %zu lane %d stream %d nodes %zu first %d last %d deps", k, sg.lane, stream, sg.nodes.size(), sg.nodes.front(), sg.nodes.back());
+                fprintf(f, "seg %d lane %d stream %d nodes %zu first %d last %d dur_us %.1f deps", k, sg.lane, stream, sg.nodes.size(), sg.nodes.front(),
+                        sg.nodes.back(), sg.dur_us);
                 for (int d : sg.deps) fprintf(f, " %d", d);
                 fprintf(f, " stamps");
                 for (int v : sg.nodes) {
                     if (type[v] != hipGraphNodeTypeKernel) continue;
                     hipKernelNodeParams p;
-                    if (hipGraphKernelNodeGetParams(raw[topo[v]], &p) != hipSuccess || p.func != reinterpret_cast<void*>(stamp_kernel) || !p.kernelParams) continue;
+                    if (hipGraphKernelNodeGetParams(raw[v], &p) != hipSuccess || p.func != reinterpret_cast<void*>(stamp_kernel) || !p.kernelParams) continue;
                     fprintf(f, " %llu", (unsigned long long)(uintptr_t)*reinterpret_cast<unsigned long long**>(p.kernelParams[0]));
                 }
                 fprintf(f, "\n");
@@ -551,6 +745,60 @@ extern "C" int senas_sched_plan(int32_t n, int32_t m, const int32_t* from, const
     return SENAS_OK;
 }
 
+extern "C" int senas_sched_contract(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const int32_t* kind, int32_t* out_m,
+                                    int32_t* out_from, int32_t* out_to, int32_t cap) {
+    SENAS_REQUIRE(n >= 1 && m >= 0 && (m == 0 || (from && to)) && kind && out_m && out_from && out_to && cap >= 0, "sched_contract: bad argument");
+    std::vector<std::vector<int>> par(n), chi(n);
+    for (int e = 0; e < m; ++e) {
+        SENAS_REQUIRE(from[e] >= 0 && to[e] < n && from[e] < to[e], "sched_contract: nodes must be numbered topologically (from < to)");
+        par[to[e]].push_back(from[e]);
+        chi[from[e]].push_back(to[e]);
+    }
+    std::vector<int> k(kind, kind + n);
+    contract_markers(n, par, chi, k);
+    int cnt = 0;
+    for (int v = 0; v < n; ++v)
+        for (int p : par[v]) {
+            SENAS_REQUIRE(cnt < cap, "sched_contract: the output arrays are too small");
+            out_from[cnt] = p;
+            out_to[cnt++] = v;
+        }
+    *out_m = cnt;
+    return SENAS_OK;
+}
+
+extern "C" int senas_sched_plan2(int32_t n, int32_t m, const int32_t* from, const int32_t* to, const uint8_t* solo, const double* node_us,
+                                 int32_t streams, int32_t* node_segment, int32_t* n_segments, int32_t* seg_stream, int32_t* seg_issue,
+                                 int32_t* seg_dep_begin, int32_t* seg_deps) {
+    SENAS_REQUIRE(n >= 1 && m >= 0 && (m == 0 || (from && to)) && streams >= 1 && streams <= 16 && node_segment && n_segments && seg_stream &&
+                  seg_issue && seg_dep_begin && seg_deps, "sched_plan2: bad argument");
+    std::vector<std::vector<int>> par(n), chi(n);
+    for (int e = 0; e < m; ++e) {
+        SENAS_REQUIRE(from[e] >= 0 && to[e] < n && from[e] < to[e], "sched_plan2: nodes must be numbered topologically (from < to)");
+        par[to[e]].push_back(from[e]);
+        chi[from[e]].push_back(to[e]);
+    }
+    std::vector<char> so(n, 0);
+    if (solo) for (int v = 0; v < n; ++v) so[v] = solo[v] != 0;
+    std::vector<int> seg_of, stream, issue;
+    std::vector<Piece> segs;
+    cut_pieces(n, par, chi, so, seg_of, segs);
+    std::vector<double> dur(segs.size(), 0.0);
+    for (size_t k = 0; k < segs.size(); ++k) for (int v : segs[k].nodes) dur[k] += node_us ? node_us[v] : 1.0;
+    list_schedule(segs, dur, streams, stream, issue);
+    for (int v = 0; v < n; ++v) node_segment[v] = seg_of[v];
+    *n_segments = (int)segs.size();
+    int off = 0;
+    for (size_t k = 0; k < segs.size(); ++k) {
+        seg_stream[k] = stream[k];
+        seg_issue[k] = issue[k];
+        seg_dep_begin[k] = off;
+        for (int d : segs[k].deps) seg_deps[off++] = d;            // (one per parent segment of the first node: <= m)
+    }
+    seg_dep_begin[segs.size()] = off;
+    return SENAS_OK;
+}
+
 extern "C" int senas_sched_launch(void* sched, void* stream) {
     SENAS_REQUIRE(sched != nullptr, "sched_launch: bad argument");
     Sched* S = reinterpret_cast<Sched*>(sched);
@@ -562,11 +810,13 @@ extern "C" int senas_sched_launch(void* sched, void* stream) {
         LAUNCH_HIP(hipEventRecord(S->start, main), "hipEventRecord");
         for (int q = 0; q < S->n_lanes; ++q) LAUNCH_HIP(hipStreamWaitEvent(S->lanes[q], S->start, 0), "hipStreamWaitEvent");
     }
-    for (auto& sg : S->segs) {
+    for (int k : S->issue) {
+        Segment& sg = S->segs[k];
         hipStream_t s = forked ? S->lanes[sg.lane] : main;
-        for (int d : sg.deps) LAUNCH_HIP(hipStreamWaitEvent(s, S->segs[d].done, 0), "hipStreamWaitEvent");
+        for (int d : sg.deps)                                   // (a dependency on the segment's own stream is the stream's order)
+            if (forked && S->segs[d].lane != sg.lane) LAUNCH_HIP(hipStreamWaitEvent(s, S->segs[d].done, 0), "hipStreamWaitEvent");
         if (sg.exec) LAUNCH_HIP(hipGraphLaunch(sg.exec, s), "hipGraphLaunch");
-        if (sg.signals) LAUNCH_HIP(hipEventRecord(sg.done, s), "hipEventRecord");
+        if (forked && sg.signals) LAUNCH_HIP(hipEventRecord(sg.done, s), "hipEventRecord");
     }
     for (int q = 0; forked && q < S->n_lanes; ++q) {
         LAUNCH_HIP(hipEventRecord(S->lane_done[q], S->lanes[q]), "hipEventRecord");

@@ -1164,6 +1164,32 @@ def stamp(x, name):
     return y
 
 
+# Marker kinds (empty kernels the lane scheduler reads and contracts out of the captured graph: csrc/sched.hip)
+MARK_RELAY, MARK_PRODUCER, MARK_CONSUMER = 0, 1, 2
+
+
+def marker(kind):
+    """An empty kernel of the given kind on the current stream while a pass is being captured (nothing outside a capture)."""
+    if torch.cuda.is_current_stream_capturing():
+        _lib.check(_lib.lib().senas_marker(int(kind), _stream()), 'senas_marker')
+
+
+def relay_marker():
+    """A RELAY marker on the current (origin) stream: it gives the chain of hand-overs the capture records on that stream nodes
+    the lane scheduler recognises.  A reader that sits behind a CONSUMER marker gets the relay's PRODUCER-marked parents as its
+    dependencies and nothing else of the origin stream's history; the origin stream's own next node keeps all of them
+    (csrc/sched.hip, note at relay_marker_kernel)."""
+    marker(MARK_RELAY)
+
+
+def _ride(x, y):
+    """Producer-side statistics riding on x ride on its alias y too."""
+    st = getattr(x, '_senas_stats', None)
+    if st is not None:
+        y._senas_stats = st
+    return y
+
+
 class _Hop(torch.autograd.Function):
     """An alias of x behind an autograd node of the CURRENT stream.  Autograd replays a node on the stream its forward pass
     ran on and makes that stream wait for the producer of every gradient it receives: a tensor that goes from one lane of
@@ -1182,24 +1208,56 @@ class _Hop(torch.autograd.Function):
         return g
 
 
-def relay_marker():
-    """An empty kernel on the current (origin) stream while a pass is being captured: it gives the chain of hand-overs the
-    capture records on that stream nodes the lane scheduler recognises and contracts out of the graph (the chain itself is
-    kept: cutting it lost the origin stream's own waits -- csrc/sched.hip, note at relay_marker_kernel)."""
-    if torch.cuda.is_current_stream_capturing():
-        _lib.check(_lib.lib().senas_relay_marker(_stream()), 'senas_relay_marker')
-
-
 def hop(x):
     if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
         if torch.is_tensor(x) and x.is_cuda:
             relay_marker()
         return x
-    y = _Hop.apply(x)
-    st = getattr(x, '_senas_stats', None)
-    if st is not None:
-        y._senas_stats = st
-    return y
+    return _ride(x, _Hop.apply(x))
+
+
+class _LaneOut(torch.autograd.Function):
+    """The producer's end of a hand-over, made on the PRODUCER's lane (grid.Lanes.hand): nothing forward (the PRODUCER marker
+    sits in front of the event the reader waits for, grid.Lanes.mark); on the way back the gradient arrives here from the origin
+    stream: a CONSUMER marker."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        marker(MARK_CONSUMER)
+        return g
+
+
+class _LaneIn(torch.autograd.Function):
+    """The reader's end of a hand-over, made on the READER's lane: a CONSUMER marker forward; on the way back the gradient leaves
+    this lane for the origin stream: a PRODUCER marker."""
+
+    @staticmethod
+    def forward(ctx, x):
+        marker(MARK_CONSUMER)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        marker(MARK_PRODUCER)
+        return g
+
+
+def lane_out(x):
+    if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        return x
+    return _ride(x, _LaneOut.apply(x))
+
+
+def lane_in(x):
+    if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        if torch.is_tensor(x) and x.is_cuda:
+            marker(MARK_CONSUMER)
+        return x
+    return _ride(x, _LaneIn.apply(x))
 
 
 def fan_out(x, n):

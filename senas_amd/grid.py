@@ -90,6 +90,7 @@ class Lanes(object):
     harmless)."""
 
     enabled = True          # class-wide switch (False: every cell on the caller's stream, as the reference's loop)
+    down_lane = True        # the down cells on a lane of their own (False: on the caller's stream, round 4's schedule)
     # Inside a stream capture the columns only fork when whoever captures has said that the captured graph goes to the lane
     # scheduler (``with Lanes.scheduled():`` -- the step drivers and the Evaluator): anybody else's ``torch.cuda.graph`` would
     # instantiate the multi-branch graph on the runtime's own executor (SIGSEGV in hip::Graph::UpdateStreams,
@@ -115,15 +116,41 @@ class Lanes(object):
         self.main = torch.cuda.current_stream(device)
         # (streams of this library's own, not torch.cuda.Stream(): see functional.own_stream)
         self.streams = [F.own_stream(device, 'lane%d' % j) for j in range(columns)]
+        # The down cells on a lane of their own (``down_lane``): on the caller's stream their backward passes sit behind every
+        # hand-over the host issued before them -- the chain of relay markers on that stream carries all of those waits on --
+        # and ran as a serial tail of the pass (2.5 ms of the search step's weight pass: profiles/r4_search_by_level.txt, down4
+        # waiting for cells of column 0 it has nothing to do with).  On a lane a down cell waits for exactly the hand-overs it
+        # takes part in (csrc/sched.hip: the typed markers).
+        self.down = F.own_stream(device, 'lane_down') if Lanes.down_lane else None
         self.events = {}
         self.used = []
 
     def mark(self, key):
-        """``key`` is produced by what the current stream holds so far."""
+        """``key`` is produced by what the current stream holds so far.  On a lane the event sits behind a PRODUCER marker: the
+        lane scheduler then knows which parent of a relay marker on the origin stream is the hand-over's source."""
         s = torch.cuda.current_stream()
+        if s != self.main:
+            self.F.marker(self.F.MARK_PRODUCER)
         ev = torch.cuda.Event()
         ev.record(s)
         self.events[key] = (ev, s)
+
+    def down_stream(self):
+        """The stream the down cells run on: their own lane, or the caller's stream."""
+        if self.down is None:
+            return self.main
+        if self.down not in self.used:
+            self.used.append(self.down)
+            self.F.LANES.add(self.down)
+        return self.down
+
+    def after_down(self, keys):
+        """The down lane waits for the producers of ``keys`` that ran on the caller's stream (stems)."""
+        s = self.down_stream()
+        for key in keys:
+            ev, src = self.events[key]
+            if src == self.main and s != self.main:
+                s.wait_event(ev)
 
     def lane(self, j):
         s = self.streams[j]
@@ -143,17 +170,29 @@ class Lanes(object):
                 raise RuntimeError('lane %d may not wait for another lane directly (grid.Lanes)' % j)
 
     def hand(self, t, key, j):
-        """Tensor ``t``, produced under ``key`` on another lane, for a reader on lane j: through main (see the class text)."""
+        """Tensor ``t``, produced under ``key`` on another stream, for a reader on lane j (``'down'``: the down lane): through
+        main (see the class text).  Three identity nodes mark the hand-over for the lane scheduler, forward and backward: one made
+        on the producer's lane (backward: a CONSUMER marker there -- the gradient arrives), the hop on main (a RELAY marker both
+        ways), one on the reader's lane (forward: a CONSUMER marker; backward: a PRODUCER marker -- the gradient leaves).  With
+        them the scheduler gives the reader exactly the producer as its dependency instead of everything main had waited for
+        before (csrc/sched.hip)."""
         ev, src = self.events[key]
-        s = self.lane(j)
+        s = self.down_stream() if j == 'down' else self.lane(j)
         if src == s:
             return t
         if src != self.main:
+            with torch.cuda.stream(src):
+                t = self.F.lane_out(t)
             self.main.wait_event(ev)
             with torch.cuda.stream(self.main):
                 t = self.F.hop(t)
             ev = torch.cuda.Event()
             ev.record(self.main)
+            s.wait_event(ev)
+            if s != self.main:
+                with torch.cuda.stream(s):
+                    t = self.F.lane_in(t)
+            return t
         s.wait_event(ev)
         return t
 
@@ -273,35 +312,56 @@ class MacroGrid(nn.Module):
                 y = call('up%d%d' % (i, j), cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), in1) if live else None
                 G[i][j] = plan.put(('o', i, j), y)
                 return
-            lanes.after(j, [(0, j)])
             in1 = lanes.hand(in1, (i - 1, j + 1), j)
+
+            def fetch(k, t):
+                # a tensor of the column as lane j reads it: the cells (k, j), k >= 1, ran on this lane; the column's down-path
+                # output comes from the down lane (a hand-over) or from the caller's stream (a wait)
+                return Lanes.take(lanes.hand(t, (k, j), j))
+
             with lanes.on(j):
-                ins = [Lanes.take(t) for t in skips(plan, G, i, j, live)]
+                ins = skips(plan, G, i, j, live, fetch)
                 y = call('up%d%d' % (i, j), cell, 'up', ins[0] if len(ins) == 1 else torch.cat(ins, dim=1), Lanes.take(in1))
                 G[i][j] = plan.put(('o', i, j), y)
                 lanes.mark((i, j))
 
-        def cut_here(t):
+        def cut_here(t, key=None):
             # the two-part backward of a multi-rank step (senas_amd.step) re-leafs the down-path outputs: what the up path
             # reads is the leaf, behind an identity node made on THIS stream (the leaf's gradient is then accumulated here,
-            # whichever lanes its readers run on)
+            # whichever lanes its readers run on).  A tensor the down lane made is waited for here and from then on counts as
+            # made on this stream (its readers wait for this stream, no hand-over)
             if cut is None:
                 return t
             from . import functional as F
-            return F.hop(cut(t))
+            if lanes is not None and key is not None and lanes.events[key][1] != lanes.main:
+                lanes.main.wait_event(lanes.events[key][0])
+                Lanes.take(t)
+            out = F.hop(cut(t))
+            if lanes is not None and key is not None:
+                lanes.mark(key)
+            return out
 
         s0 = plan.put('s0', self.stem0(x) if live else None)
         first = plan.get(s0)
         D = [plan.put(('o', 0, 0), self.stem1(first) if live else None)]             # the down path as the down path reads it
-        G[0][0] = cut_here(D[0])
         if lanes is not None:
             lanes.mark((0, 0))
+        G[0][0] = cut_here(D[0], (0, 0))
+        # the down cells run on the down lane (grid.Lanes.down): it waits for the stems once, and its tensors reach the columns
+        # of up cells through hand-overs
+        on_down = (lambda: torch.cuda.stream(lanes.down_stream())) if lanes is not None else contextlib.nullcontext
+        if lanes is not None:
+            lanes.after_down([(0, 0)])
         for j in range(1, depth):
-            a, b = plan.get(s0 if j == 1 else D[j - 2]), plan.get(D[j - 1])
-            D.append(plan.put(('o', 0, j), call('down%d' % j, self.blocks[0][j], 'down', a, b) if live else None))
-            G[0][j] = cut_here(D[j])
-            if lanes is not None:
-                lanes.mark((0, j))
+            with on_down():
+                a, b = plan.get(s0 if j == 1 else D[j - 2]), plan.get(D[j - 1])
+                if lanes is not None and j <= 2:                 # (what the stems made is read on the down lane)
+                    a = Lanes.take(a)
+                    b = Lanes.take(b) if j == 1 else b
+                D.append(plan.put(('o', 0, j), call('down%d' % j, self.blocks[0][j], 'down', a, b) if live else None))
+                if lanes is not None:
+                    lanes.mark((0, j))
+            G[0][j] = cut_here(D[j], (0, j))
             up_cell(1, j - 1)
         s0 = cut_here(s0)
         for i in range(2, depth):

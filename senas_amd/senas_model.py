@@ -155,7 +155,8 @@ class SenasModel(MacroGrid):
         def run(module, kind, a, b):
             return module(a, b)
 
-        def skips(plan, G, i, j, live):
-            return [plan.get(G[k][j]) for k in range(i) if G[k][j] is not None]
+        def skips(plan, G, i, j, live, fetch=None):
+            col = [(k, plan.get(G[k][j])) for k in range(i) if G[k][j] is not None]
+            return [fetch(k, t) if (live and fetch is not None) else t for k, t in col]
 
         return self._walk_grid(plan, x, run, skips)

@@ -62,15 +62,18 @@ class SenasSearch(MacroGrid):
         def run(module, kind, a, b):
             return module(a, b, *args[kind])
 
-        def skips(plan, G, i, j, live):
+        def skips(plan, G, i, j, live, fetch=None):
             # the column's down-path output, then the gamma-gated blends of neighbouring skip candidates (:98-102) -- stacked
-            # by one launch that reads every tensor of the column once (functional.skip_stack)
+            # by one launch that reads every tensor of the column once (functional.skip_stack).  ``fetch(k, t)``: tensor k of
+            # the column as the CURRENT stream may read it (grid.MacroGrid._walk_grid: the hand-over between lanes)
             col = [plan.get(G[k][j]) for k in range(i)]
+            if live and fetch is not None:
+                col = [fetch(k, t) for k, t in enumerate(col)]
             if not live or i == 1:
                 return col
             if i > F.SKIP_MAX or col[0].shape[1] % 4 != 0:
                 return [col[0]] + [F.blend2_row(col[k - 1], col[k], rows, gamma_index(k, j)) for k in range(1, i)]
-            return [F.skip_stack([Lanes.take(t) for t in col], rows, [0] + [gamma_index(k, j) for k in range(1, i)])]
+            return [F.skip_stack(col, rows, [0] + [gamma_index(k, j) for k in range(1, i)])]
 
         return self._walk_grid(plan, x, run, skips)
 

@@ -175,12 +175,12 @@ def test_step_drivers_on_lanes_track_the_serial_eager_step(kind, lanes_switch):
     upd1 = {k: s1[k] - b1[k] for k in s1 if k in params}
     top = max(float(v.abs().max()) for v in upd0.values())
     assert top > 0 and len(upd0) > 100
-    worst = (0.0, None)
+    worst = (0.0, '')
     for k, u in upd0.items():
         assert bool(torch.equal(b0[k], b1[k])), k                        # (same start)
         scale = max(float(u.abs().max()), 1e-3 * top)
         err = float((u - upd1[k]).abs().max()) / scale
-        worst = max(worst, (err, k))
+        worst = (err, k) if err > worst[0] else worst
         assert err <= 1e-4, (k, err, scale)
     for k in s0:
         if k not in params and s0[k].is_floating_point():               # running statistics of every BatchNorm2d

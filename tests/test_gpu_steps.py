@@ -187,6 +187,18 @@ def test_bench_line_contract():
     search = out['search_step']
     assert search['value'] > 0 and search['roofline']['bound'] == 'hbm' and search['roofline']['peak'] == 8000.0
     assert search['cpu_baseline']['value'] > 0
+    # the parity gates of the same invocation: step 0 of the timed networks against the oracle, and the captured
+    # passes as the timed loop replays them against the same passes eagerly on one stream -- all at the bench's own size
+    gate = out['parity_gate']
+    assert gate['pass'] is True
+    g0 = gate['step0_vs_oracle']
+    assert g0['pass'] and g0['logits_max_rel_err'] <= 1e-3 and g0['loss_rel_err'] <= 1e-3 and g0['argmax_mask']['mismatches'] == 0
+    assert g0['argmax_mask']['compared_bit_exact'] > 0.5 * g0['argmax_mask']['pixels']
+    assert gate['schedule_vs_serial_eager']['pass'] and gate['schedule_vs_serial_eager']['worst_rel_err'] <= 5e-5
+    sg = search['parity_gate']
+    assert sg['step0_vs_oracle']['pass'] and sg['step0_vs_oracle']['argmax_mask']['mismatches'] == 0
+    for k in ('architecture_pass_schedule_vs_serial_eager', 'weight_pass_schedule_vs_serial_eager'):
+        assert sg[k]['pass'] and sg[k]['replayed_by'] == 'lane scheduler', (k, sg[k])
     for mode in ('bf16x6', 'bf16x3', 'bf16'):
         blk = out['train_step_' + mode]
         assert blk['math'] == mode and blk['value'] > 0 and blk['dtype'] != 'f32'

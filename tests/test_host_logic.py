@@ -584,3 +584,124 @@ def test_lane_scheduler_plan_on_synthetic_dags():
                 edges.add((int(a), b))
         solo = [int(rng.rand() < 0.05) for _ in range(n)]
         _check_plan(n, sorted(edges), int(rng.randint(1, 7)), solo)
+
+
+def _contract(n, edges, kind):
+    import ctypes as C
+    from senas_amd import _lib
+    I = C.c_int32
+    m = len(edges)
+    frm, to = (I * max(m, 1))(*[a for a, _ in edges]), (I * max(m, 1))(*[b for _, b in edges])
+    cap = 4 * m * max(1, m) + 16
+    of, ot, om = (I * cap)(), (I * cap)(), I(0)
+    _lib.check(_lib.lib().senas_sched_contract(n, m, frm, to, (I * n)(*kind), C.byref(om), of, ot, cap), 'senas_sched_contract')
+    return sorted((of[i], ot[i]) for i in range(om.value))
+
+
+def test_typed_markers_give_a_reader_its_producer_and_the_origin_stream_everything():
+    """csrc/sched.hip contract_markers (through senas_sched_contract, no device) on the shape grid.Lanes.hand captures: two
+    hand-overs through the origin stream, A -> B and C -> D, with the origin stream's own kernels before, between and after.
+    Reader B must depend on A only (not on the origin stream's history), reader D on C only (not on A, which the chain of
+    relay markers carries along); the origin stream's next kernel keeps EVERY wait (A, C and its own previous kernel).
+    An untyped relay (no PRODUCER parent, no CONSUMER child: round 4's captures) contracts as it always did."""
+    # nodes (topological): 0 m0 (origin kernel) | 1 a (lane A kernel) | 2 Pa (PRODUCER on A) | 3 R1 (RELAY: parents m0, Pa)
+    # 4 b0 (lane B kernel) | 5 Cb (CONSUMER on B: parents b0, R1) | 6 b1 (B's reader kernel: parent Cb)
+    # 7 c (lane C kernel) | 8 Pc (PRODUCER) | 9 R2 (RELAY: parents R1 [stream order], Pc) | 10 d0 | 11 Cd (CONSUMER: d0, R2) | 12 d1
+    # 13 m1 (origin stream's next kernel: parent R2)
+    R, P, Cn, K = 0, 1, 2, -1
+    kind = [K, K, P, R, K, Cn, K, K, P, R, K, Cn, K, K]
+    edges = [(0, 3), (1, 2), (2, 3), (4, 5), (3, 5), (5, 6), (7, 8), (3, 9), (8, 9), (10, 11), (9, 11), (11, 12), (9, 13)]
+    got = _contract(14, edges, kind)
+    par = {}
+    for a, b in got:
+        par.setdefault(b, set()).add(a)
+    assert par[6] == {4, 1}                        # b1 <- b0 (its lane), a (the producer): not m0
+    assert par[12] == {10, 7}                      # d1 <- d0, c: neither m0 nor a
+    assert par[13] == {0, 1, 7}                    # the origin stream's next kernel: everything
+    assert all(kind[a] == K and kind[b] == K for a, b in got)
+    # untyped: relay with plain parents and children
+    kind2 = [K, K, R, K, K]
+    got2 = _contract(5, [(0, 2), (1, 2), (2, 3), (2, 4)], kind2)
+    assert got2 == [(0, 3), (0, 4), (1, 3), (1, 4)]
+    # an empty node in a chain
+    assert _contract(3, [(0, 1), (1, 2)], [K, 3, K]) == [(0, 2)]
+
+
+def _plan2(n, edges, streams, node_us=None, solo=None):
+    import ctypes as C
+    from senas_amd import _lib
+    I = C.c_int32
+    m = len(edges)
+    frm, to = (I * max(m, 1))(*[a for a, _ in edges]), (I * max(m, 1))(*[b for _, b in edges])
+    so = (C.c_uint8 * n)(*(solo or [0] * n))
+    us = (C.c_double * n)(*node_us) if node_us is not None else None
+    node_seg, seg_stream, seg_issue, dep_begin, deps = (I * n)(), (I * n)(), (I * n)(), (I * (n + 1))(), (I * max(m, 1))()
+    nseg = I(0)
+    _lib.check(_lib.lib().senas_sched_plan2(n, m, frm, to, so, us, streams, node_seg, C.byref(nseg), seg_stream, seg_issue, dep_begin, deps),
+               'senas_sched_plan2')
+    k = nseg.value
+    return (list(node_seg), [seg_stream[s] for s in range(k)], [seg_issue[s] for s in range(k)],
+            [[deps[i] for i in range(dep_begin[s], dep_begin[s + 1])] for s in range(k)])
+
+
+def _check_plan2(n, edges, streams, node_us=None, solo=None):
+    """Invariants of the "critical" plan: segments are linear runs (consecutive nodes joined by an edge), only a segment's first node
+    has parents outside it and only its last node children outside it, so every edge is enforced by "wait for the parent's whole
+    segment"; a segment's dependencies are exactly the segments of its first node's parents; the issue order is a permutation and
+    topological (every dependency is issued earlier -- which also makes a same-stream dependency the stream's own order)."""
+    seg, stream, issue, deps = _plan2(n, edges, streams, node_us, solo)
+    k = len(stream)
+    assert sorted(issue) == list(range(k)) and all(0 <= q < streams for q in stream)
+    when = {s: i for i, s in enumerate(issue)}
+    nodes = {}
+    for v in range(n):
+        nodes.setdefault(seg[v], []).append(v)
+    assert sorted(nodes) == list(range(k))
+    es = set(edges)
+    for s_, vs in nodes.items():
+        for a, b in zip(vs, vs[1:]):
+            assert (a, b) in es
+        want = set()
+        for a, b in edges:
+            if b in vs and a not in vs:
+                assert b == vs[0], ('a parent outside the segment in front of a node that is not its first', a, b)
+                assert a == nodes[seg[a]][-1], ('the parent is not the last node of its segment', a, b)
+                want.add(seg[a])
+            if a in vs and b not in vs:
+                assert a == vs[-1]
+        assert set(deps[s_]) == want
+        for d in deps[s_]:
+            assert when[d] < when[s_]
+    for s_, flag in enumerate(solo or []):
+        if flag:
+            assert len(nodes[seg[s_]]) == 1
+    return seg, stream, issue, deps
+
+
+def test_critical_path_plan_on_synthetic_dags():
+    """csrc/sched.hip cut_pieces + list_schedule through senas_sched_plan2 (no device): the invariants above on a chain, a
+    diamond, the macro grid's shape and seeded random DAGs; and the policy itself on a case with a known answer -- a long
+    chain beside short independent pieces on two streams: the long chain starts first and keeps a stream to itself."""
+    import numpy as np
+    seg, stream, issue, deps = _check_plan2(6, [(i, i + 1) for i in range(5)], 4)
+    assert len(stream) == 1
+    edges = [(0, 1), (1, 2), (2, 3), (0, 4), (4, 5), (5, 6), (3, 7), (6, 7)]
+    seg, stream, issue, deps = _check_plan2(8, edges, 4)
+    assert len(stream) == 4 and stream[seg[1]] != stream[seg[4]]             # the two arms side by side
+    # known answer: node 0 forks into a 6-node chain (1..6, 10 us each) and four single nodes (7..10, 10 us each); all join in 11
+    edges = [(0, 1)] + [(i, i + 1) for i in range(1, 6)] + [(0, 7), (0, 8), (0, 9), (0, 10)] + [(6, 11), (7, 11), (8, 11), (9, 11), (10, 11)]
+    seg, stream, issue, deps = _check_plan2(12, edges, 2, node_us=[10.0] * 12)
+    chain = seg[1]
+    assert all(seg[v] == chain for v in range(1, 7))
+    assert issue.index(chain) == 1                                           # right behind the fork: the longest remaining path first
+    others = [seg[v] for v in (7, 8, 9, 10)]
+    assert all(stream[o] != stream[chain] for o in others)                   # the short pieces share the other stream
+    rng = np.random.RandomState(7)
+    for trial in range(40):
+        n = int(rng.randint(2, 70))
+        edges = set()
+        for b in range(1, n):
+            for a in rng.choice(b, size=min(b, int(rng.randint(0, 4))), replace=False):
+                edges.add((int(a), b))
+        solo = [int(rng.rand() < 0.05) for _ in range(n)]
+        _check_plan2(n, sorted(edges), int(rng.randint(1, 6)), node_us=[float(rng.rand() * 50 + 1) for _ in range(n)], solo=solo)

@@ -117,13 +117,29 @@ static std::vector<hipStream_t>& lane_pool() {
     return pool[dev & 63];
 }
 
+// Stream priorities -- measured and NOT used (profiles/r5_sched_policies.txt).  The idea: streams 0 and 1 of the pool at the device's
+// greatest priority for the light segments (launch-bound kernels of a few workgroups: the small-map cells, which are the critical
+// path of a pass in both directions), the default priority for the heavy ones (kernels that fill the chip), the two classes
+// never queueing behind each other.  The measurement: on this runtime a kernel chain on a high-priority stream runs 3.5x SLOWER
+// (down1 forward: 372 -> 1 203 us; the search step 27.2 -> 59.3 ms, the train step 15.7 -> 27.4) -- whatever the queue
+// arbitration does with the priority, every launch of such a queue pays for it.  SENAS_SCHED_PRIORITY=1 turns it on again
+// (the classes and the priorities together) for a re-measurement on another runtime.
+static bool pool_priorities() {
+    const char* e = getenv("SENAS_SCHED_PRIORITY");
+    return e && e[0] == '1';
+}
+constexpr int kHighStreams = 2;
+
 // grow the pool to `want` streams on distinct hardware queues (fewer if the device does not give that many)
 static void lane_pool_grow(int want) {
     auto& pool = lane_pool();
     std::vector<hipStream_t> rejected;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int tries = 0; (int)pool.size() < want && tries < 16; ++tries) {
         hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        const int prio = (pool_priorities() && (int)pool.size() < kHighStreams) ? greatest : 0;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) break;
         bool ok = true;
         for (hipStream_t kept : pool) ok = ok && lanes_overlap(kept, st);
         if (ok) pool.push_back(st); else rejected.push_back(st);      // (kept alive until the end: a destroyed stream's queue slot is the next one handed out)
@@ -273,8 +289,13 @@ static void cut_pieces(int n, const std::vector<std::vector<int>>& par, const st
 // chain of dependants); an idle stream that ran one of the segment's dependencies is preferred (no event, no cross-queue
 // latency).  `stream[k]`, and `issue` = the segments in the order the simulation starts them (topological; per stream it is the
 // stream's FIFO order).
-static void list_schedule(const std::vector<Piece>& segs, const std::vector<double>& dur, int S, std::vector<int>& stream, std::vector<int>& issue) {
+// `light[k]` / `high` (optional): a light segment only goes to streams [0, high), a heavy one only to [high, S) -- the two classes
+// never queue behind each other (high == 0 or high >= S: one class).
+static void list_schedule(const std::vector<Piece>& segs, const std::vector<double>& dur, int S, std::vector<int>& stream, std::vector<int>& issue,
+                          const std::vector<char>* light = nullptr, int high = 0) {
     const int K = (int)segs.size();
+    const bool classes = light != nullptr && high > 0 && high < S;
+    auto fits = [&](int k, int q) { return !classes || ((*light)[k] ? q < high : q >= high); };
     std::vector<double> bottom(K, 0.0), finish(K, 0.0);
     for (int k = K - 1; k >= 0; --k) {
         double b = 0.0;
@@ -297,15 +318,18 @@ static void list_schedule(const std::vector<Piece>& segs, const std::vector<doub
                 running[q] = -1;
             }
         for (;;) {
-            int best = -1;
-            for (int k = 0; k < K; ++k) if (state[k] == 1 && (best < 0 || bottom[k] > bottom[best])) best = k;
-            if (best < 0) break;
-            int q = -1;
-            double latest = -1.0;
-            for (int d : segs[best].deps)                      // an idle stream that ran a dependency (the one that finished last)
-                if (running[stream[d]] < 0 && finish[d] > latest) { latest = finish[d]; q = stream[d]; }
-            for (int r = 0; r < S && q < 0; ++r) if (running[r] < 0) q = r;
-            if (q < 0) break;                                  // every stream is busy
+            // the ready segment with the longest remaining path among those an idle stream of their class can take
+            int best = -1, q = -1;
+            for (int k = 0; k < K; ++k) {
+                if (state[k] != 1 || (best >= 0 && bottom[k] <= bottom[best])) continue;
+                int mine = -1;
+                double latest = -1.0;
+                for (int d : segs[k].deps)                     // an idle stream that ran a dependency (the one that finished last)
+                    if (running[stream[d]] < 0 && fits(k, stream[d]) && finish[d] > latest) { latest = finish[d]; mine = stream[d]; }
+                for (int r = 0; r < S && mine < 0; ++r) if (running[r] < 0 && fits(k, r)) mine = r;
+                if (mine >= 0) { best = k; q = mine; }
+            }
+            if (best < 0) break;                               // nothing is ready, or no stream of the ready segments' class is idle
             stream[best] = q;
             running[q] = best;
             state[best] = 2;
@@ -673,7 +697,81 @@ extern "C" int senas_sched_create(void* hip_graph, int max_lanes, void** out) {
             if (!ok) { set_error("sched_create: the timing replay", hipGetLastError()); sched_free(S); return SENAS_ELAUNCH; }
         }
         std::vector<int> stream;
-        list_schedule(pieces, dur, P, stream, S->issue);
+        // light / heavy: by the average kernel time of the segment in the serial replay.  Measured on the search step (serial trace,
+        // profiles/r4_search_cells.txt): cells on maps <= 64 x 64 average 8.6 - 13.2 us per launch (the launch floor and a few
+        // workgroups each), cells on 128 x 128 maps 17 - 20 us, the head 53 us.
+        double light_us = 15.0;
+        if (const char* e = getenv("SENAS_SCHED_LIGHT_US")) light_us = atof(e);
+        std::vector<char> light(K, 0);
+        int n_light = 0;
+        for (int k = 0; k < K; ++k) { light[k] = dur[k] / (double)std::max<size_t>(1, S->segs[k].nodes.size()) < light_us; n_light += light[k]; }
+        const bool classes = pool_priorities() && P >= 4 && n_light > 0 && n_light < K;
+        list_schedule(pieces, dur, P, stream, S->issue, classes ? &light : nullptr, classes ? kHighStreams : 0);
+        // ---- refinement: the serial replay times every segment ALONE; side by side with others on the chip it takes longer (a small
+        // cell beside a 128 x 128 cell: 1.3 - 1.5x), so the simulation's time line drifts from the real one and a segment of the
+        // critical path ends up queued behind a side cell on its stream.  So: run the plan itself with a pair of timing events around
+        // every segment, plan again with the durations the segments had IN that plan, and keep whichever plan measured the shortest
+        // pass (the first one included: the result is never worse than the unrefined plan by its own measurement).
+        int refine = 2;
+        if (const char* e = getenv("SENAS_SCHED_REFINE")) refine = atoi(e);
+        if (refine > 0 && P > 1 && K > 1) {
+            std::vector<hipEvent_t> e0(K, nullptr), e1(K, nullptr);
+            hipEvent_t t0 = nullptr, t1 = nullptr;
+            bool ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
+            for (int k = 0; k < K && ok; ++k) ok = hipEventCreate(&e0[k]) == hipSuccess && hipEventCreate(&e1[k]) == hipSuccess;
+            auto run = [&](const std::vector<int>& st_of, const std::vector<int>& order, std::vector<double>& seen, double& span_us) {
+                bool fine = hipDeviceSynchronize() == hipSuccess;
+                for (int rep = 0; rep < 2 && fine; ++rep) {
+                    fine = hipEventRecord(t0, pool[0]) == hipSuccess;
+                    for (int q = 1; q < P && fine; ++q) fine = hipStreamWaitEvent(pool[q], t0, 0) == hipSuccess;
+                    for (int k : order) {
+                        if (!fine) break;
+                        hipStream_t st = pool[st_of[k]];
+                        for (int d : S->segs[k].deps)
+                            if (st_of[d] != st_of[k]) fine = fine && hipStreamWaitEvent(st, e1[d], 0) == hipSuccess;
+                        fine = fine && hipEventRecord(e0[k], st) == hipSuccess;
+                        if (S->segs[k].exec) fine = fine && hipGraphLaunch(S->segs[k].exec, st) == hipSuccess;
+                        fine = fine && hipEventRecord(e1[k], st) == hipSuccess;
+                    }
+                    // join on stream 0: the last segment issued on every stream
+                    std::vector<int> last(P, -1);
+                    for (int k : order) last[st_of[k]] = k;
+                    for (int q = 1; q < P && fine; ++q) if (last[q] >= 0) fine = hipStreamWaitEvent(pool[0], e1[last[q]], 0) == hipSuccess;
+                    fine = fine && hipEventRecord(t1, pool[0]) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                }
+                float ms = 0.f;
+                fine = fine && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+                span_us = 1e3 * (double)ms;
+                seen.assign(K, 0.0);
+                for (int k = 0; k < K && fine; ++k) {
+                    fine = hipEventElapsedTime(&ms, e0[k], e1[k]) == hipSuccess;
+                    seen[k] = 1e3 * (double)ms;
+                }
+                return fine;
+            };
+            std::vector<int> best_stream = stream, best_issue = S->issue;
+            std::vector<double> seen;
+            double best_span = 0.0, span = 0.0;
+            ok = ok && run(stream, S->issue, seen, best_span);
+            const bool verbose = getenv("SENAS_SCHED_VERBOSE") != nullptr;
+            if (verbose && ok) fprintf(stderr, "[sched] plan 0 (durations of the serial replay): the pass takes %.1f us\n", best_span);
+            for (int it = 1; it <= refine && ok; ++it) {
+                std::vector<int> st2, is2;
+                list_schedule(pieces, seen, P, st2, is2, classes ? &light : nullptr, classes ? kHighStreams : 0);
+                std::vector<double> seen2;
+                ok = run(st2, is2, seen2, span);
+                if (verbose && ok) fprintf(stderr, "[sched] plan %d (durations seen in plan %d): the pass takes %.1f us\n", it, it - 1, span);
+                if (ok && span < best_span) { best_span = span; best_stream = st2; best_issue = is2; }
+                seen.swap(seen2);
+            }
+            for (auto e : e0) if (e) (void)hipEventDestroy(e);
+            for (auto e : e1) if (e) (void)hipEventDestroy(e);
+            if (t0) (void)hipEventDestroy(t0);
+            if (t1) (void)hipEventDestroy(t1);
+            if (!ok) { set_error("sched_create: the refinement replay", hipGetLastError()); sched_free(S); return SENAS_ELAUNCH; }
+            stream = best_stream;
+            S->issue = best_issue;
+        }
         used = 0;
         for (int k = 0; k < K; ++k) { S->segs[k].lane = stream[k]; S->segs[k].dur_us = (float)dur[k]; used = std::max(used, stream[k] + 1); }
         for (int k = 0; k < K; ++k)

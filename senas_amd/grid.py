@@ -8,6 +8,7 @@ Reference: search/senas_search.py:16-112 and models/senas_model.py:78-179 build 
 grid; here the bookkeeping lives in one place.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -90,7 +91,7 @@ class Lanes(object):
     harmless)."""
 
     enabled = True          # class-wide switch (False: every cell on the caller's stream, as the reference's loop)
-    down_lane = True        # the down cells on a lane of their own (False: on the caller's stream, round 4's schedule)
+    down_lane = os.environ.get('SENAS_DOWN_LANE', '1') != '0'        # the down cells on a lane of their own (False: on the caller's stream, round 4's schedule)
     # Inside a stream capture the columns only fork when whoever captures has said that the captured graph goes to the lane
     # scheduler (``with Lanes.scheduled():`` -- the step drivers and the Evaluator): anybody else's ``torch.cuda.graph`` would
     # instantiate the multi-branch graph on the runtime's own executor (SIGSEGV in hip::Graph::UpdateStreams,

@@ -62,6 +62,16 @@ int64_t senas_conv2d_ws_bytes(const senas_conv_geom* g);     /* forward and data
  * repacks w into ws itself.  Ignored by the non-MFMA fallback kernels.                            */
 int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y,
                      int in_relu, double* stats, void* ws, const float* packed, void* stream);
+/* The same with the output in PLANAR groups of 8 channels: channel ch of pixel p (p over n*ho*wo) goes to
+ * y[(ch / 8) * y_plane + p * 8 + ch % 8], y_plane = n*ho*wo*8 floats, co a multiple of 8 -- every 8-channel group is a dense
+ * [n][ho][wo][8] tensor of its own.  For the STACKED convolutions of a search cell (search/cell.py:100-106: the same-named
+ * candidates of the edges that leave one state run as one convolution, weights stacked along c_out; every edge's 8-channel
+ * slice is then read by a different node kernel -- interleaved, each of those reads would fetch whole 128-byte pixels for 32
+ * bytes of payload).  Statistics are per channel as before.  SENAS_EUNSUPPORTED (nothing launched) when the geometry does not
+ * land on a kernel with that epilogue (the stride-1 LDS-window kernel, the stride-2 transposed one): the caller then makes the
+ * interleaved call.  senas_conv2d_fwd_pair_planar: the pair launch (below) likewise, both outputs planar.                      */
+int senas_conv2d_fwd_planar(const senas_conv_geom* g, const float* x, const float* w, float* y, int64_t y_plane,
+                            int in_relu, double* stats, void* ws, const float* packed, void* stream);
 /* Inference forward (experiments/testing_model.py:150-190 runs the model under model.eval()): eval-mode
  * nn.BatchNorm2d (operations.py:133-134) is a per-channel affine of the convolution output, so it -- together with
  * the node sum and ReLU of the cell (models/senas_model.py:55-63) -- rides in the epilogue of the producer:
@@ -102,6 +112,9 @@ int senas_pack_batched(const senas_pack_item* items_dev, int n, int64_t max_elem
 int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
                           float* ya, float* yb, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
                           const float* packed_a, const float* packed_b, void* stream);
+int senas_conv2d_fwd_pair_planar(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                                 float* ya, float* yb, int64_t y_plane, int in_relu, double* stats_a, double* stats_b, void* ws_a,
+                                 void* ws_b, const float* packed_a, const float* packed_b, void* stream);
 int senas_conv2d_bwd_data_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* dya, const float* dyb,
                                const float* wa, const float* wb, float* dxa, float* dxb, int in_relu, const float* x,
                                void* ws_a, void* ws_b, const float* packed_a, const float* packed_b, void* stream);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
-EXPECTED_ABI = 32          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
+EXPECTED_ABI = 33          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
 SKIP_MAX = 8               # SENAS_SKIP_MAX
 MAX_STACK = 4
@@ -88,6 +88,7 @@ _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     'senas_conv2d_ws_bytes': (C.c_int64, [_G]),
     'senas_conv2d_fwd': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_fwd_planar': (_I, [_G, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     'senas_conv2d_fwd_epilogue': (_I, [_G, _P, _P, _P, _I, C.POINTER(ConvEpilogue), _P, _P, _P]),
     'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
     'senas_conv2d_pack_layout': (_I, [_G, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -155,6 +156,7 @@ SIGNATURES = {
     'senas_node_fwd': (_I, [_N, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'senas_node_bwd': (_I, [_N, _PP, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _PP, _PP, _P, _I, _PP, _PP, _P, _PP, _P, _P, _P]),
     'senas_conv2d_fwd_pair': (_I, [_G, _G, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'senas_conv2d_fwd_pair_planar': (_I, [_G, _G, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     'senas_conv2d_bwd_data_pair': (_I, [_G, _G, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'senas_conv2d_bwd_weight_pair': (_I, [_G, _G, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(SumItem), C.POINTER(SumItem), _P]),
     'senas_conv2d_fwd_lp': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _I, _P]),

@@ -130,6 +130,10 @@ class Cell(nn.Module):
             self.__dict__.setdefault('_stacks', {}).setdefault(('post', id(post.conv)), F.StackedWeight([post.conv.weight], 1, pad_to=32))
         return [v for v in self.__dict__.get('_stacks', {}).values() if isinstance(v, F.StackedWeight)]
 
+    def _parts(self, convs):
+        """Parts of the stacked output of these edges' convolutions (with the zero-weight padding part, if any)."""
+        return len(convs) + self._stack(convs).pad_parts
+
     def _stacked_conv(self, convs, x, want_stats):
         """ONE convolution for the same-geometry convolutions of k edges that read the same tensor: weights stacked along
         c_out (every edge receives its slice of the stacked weight gradient).  Returns the stacked output and its
@@ -139,7 +143,7 @@ class Cell(nn.Module):
         tr = isinstance(c0, nn.ConvTranspose2d)
         w = self._stack(convs).tensor()
         return F.conv2d(x, w, stride=c0.stride[0], pad=c0.padding[0], dil=c0.dilation[0], transposed=tr,
-                        out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=want_stats)
+                        out_pad=c0.output_padding[0] if tr else 0, groups=1, want_stats=want_stats, stacked=self._parts(convs))
 
     def _depsep_job(self, items):
         """DepSepConv candidates (edge, position, module) that read one state: their depthwise convolutions, ONE batched
@@ -261,7 +265,8 @@ class Cell(nn.Module):
                 else:
                     wa, wb = ca[0].weight, cb[0].weight
                 (za, sta), (zb, stb) = F.conv2d_pair(xs[0], xs[1], wa, wb, ca[0].stride[0], ca[0].padding[0], ca[0].dilation[0],
-                                                    cb[0].padding[0], cb[0].dilation[0], want_stats=want)
+                                                    cb[0].padding[0], cb[0].dilation[0], want_stats=want,
+                                                    stacked=self._parts(ca) if k > 1 else 0)
                 out = []
                 for p, mods, z, st, convs in ((pa, ma, za, sta, ca), (pb, mb, zb, stb, cb)):
                     if k > 1:

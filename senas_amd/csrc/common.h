@@ -189,7 +189,18 @@ inline int stats_chunks_per_block(long per_img_elems, int c, long total_elems) {
 struct GatherGeom {
     int n, hin, win, cin, hout, wout, cout;
     int kh, kw, stride, pad, dil;
+    // Planar output groups (0: the usual interleaved NHWC).  A stacked convolution of a search cell (search/cell.py:100-106: the
+    // same-named candidates of the edges that leave one state, weights stacked along c_out) is read back one 8-channel edge at a
+    // time by DIFFERENT node kernels: interleaved, every such read takes 32 bytes of each 128-byte pixel and the rest of the line
+    // is fetched again by the next node (counters: the node family moved 3x its algorithmic bytes).  With oplane != 0 channel ch
+    // of pixel p goes to out[(ch / 8) * oplane + p * 8 + ch % 8]: every edge's slice is a dense [n][h][w][8] tensor.
+    long oplane;
 };
+
+// offset of (pixel index over n*h*w, channel) in a forward output
+__device__ __forceinline__ size_t out_offset(const GatherGeom& g, size_t pixel, int ch) {
+    return g.oplane == 0 ? pixel * (size_t)g.cout + ch : (size_t)(ch >> 3) * (size_t)g.oplane + pixel * 8 + (ch & 7);
+}
 
 template <bool TG>
 __device__ __forceinline__ bool tap_src(const GatherGeom& g, int o, int k, int lim, int& i) {

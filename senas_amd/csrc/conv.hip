@@ -816,12 +816,23 @@ static bool dw_x4_ok(const GatherGeom& gg, int transposed) {
 }
 
 // forward: Conv2d -> plain gather over x; ConvTranspose2d -> transposed gather over x
-extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
-                                double* stats, void* ws, const float* packed, void* stream) {
+// plane != 0: the output in planar 8-channel groups (common.h GatherGeom::oplane) -- only where the geometry lands on a kernel that
+// has that epilogue (the LDS-window stride-1 kernel, the stride-2 transposed one); SENAS_EUNSUPPORTED, nothing launched, otherwise
+static int conv2d_fwd_impl(const senas_conv_geom* g, const float* x, const float* w, float* y, int64_t plane, int in_relu,
+                           double* stats, void* ws, const float* packed, void* stream) {
     SENAS_REQUIRE(geom_ok(g), "conv2d_fwd: inconsistent geometry");
     SENAS_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     hipStream_t st = as_stream(stream);
     GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (plane != 0) {
+        SENAS_REQUIRE(plane == (int64_t)g->n * g->ho * g->wo * 8 && g->co % 8 == 0, "conv2d_fwd_planar: the plane is n * h * w * 8 floats, c_out a multiple of 8");
+        const bool lds = !g->transposed && lds_gather_ok(gg), t2 = g->transposed && !in_relu && t2_lds_ok(gg);
+        const bool c8 = g->groups == 1 && !g->transposed && !(stem_mfma_ok(gg)) && !in_relu && c8_mfma_ok(gg);      // (the 8 -> 16 stacks of the inner edges)
+        const bool elsewhere = g->groups != 1 || (!g->transposed && stem_mfma_ok(gg)) || (!c8 && thin_k_ok(gg)) ||
+                               (!c8 && thin_n_ok(gg) && (gg.cout <= 4 || g->transposed || !lds_gather_ok(gg)));
+        if (elsewhere || !(c8 || lds || t2)) return SENAS_EUNSUPPORTED;
+        gg.oplane = (long)plane;
+    }
     if (g->groups != 1) {
         const int V = (g->co % 4 == 0) ? 4 : 1;
         const size_t dw_lds = (size_t)g->kh * g->kw * g->co * sizeof(float);
@@ -890,6 +901,17 @@ extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const 
     else hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wp, g->ci, g->co, taps, 0);
     if (!g->transposed) return launch_direct<false>(gg, x, wp, y, in_relu, nullptr, stats, st);
     return launch_direct<true>(gg, x, wp, y, in_relu, nullptr, stats, st);
+}
+
+extern "C" int senas_conv2d_fwd(const senas_conv_geom* g, const float* x, const float* w, float* y, int in_relu,
+                                double* stats, void* ws, const float* packed, void* stream) {
+    return conv2d_fwd_impl(g, x, w, y, 0, in_relu, stats, ws, packed, stream);
+}
+
+extern "C" int senas_conv2d_fwd_planar(const senas_conv_geom* g, const float* x, const float* w, float* y, int64_t y_plane, int in_relu,
+                                       double* stats, void* ws, const float* packed, void* stream) {
+    if (y_plane == 0) return SENAS_EUNSUPPORTED;
+    return conv2d_fwd_impl(g, x, w, y, y_plane, in_relu, stats, ws, packed, stream);
 }
 
 // forward with the inference epilogue; SENAS_EUNSUPPORTED (nothing launched) when the geometry is not on a kernel
@@ -999,17 +1021,22 @@ static bool pair_geoms_ok(const senas_conv_geom* a, const senas_conv_geom* b) {
            a->groups == 1 && b->groups == 1;
 }
 
-extern "C" int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
-                                     float* ya, float* yb, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
-                                     const float* packed_a, const float* packed_b, void* stream) {
+static int conv2d_fwd_pair_impl(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                                float* ya, float* yb, int64_t plane, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
+                                const float* packed_a, const float* packed_b, void* stream) {
     if (!ga || !gb || !pair_geoms_ok(ga, gb)) return SENAS_EUNSUPPORTED;
     SENAS_REQUIRE(x && wa && wb && ya && yb, "conv2d_fwd_pair: null pointer");
     hipStream_t st = as_stream(stream);
-    const GatherGeom g1{ga->n, ga->hi, ga->wi, ga->ci, ga->ho, ga->wo, ga->co, ga->kh, ga->kw, ga->stride, ga->pad, ga->dil};
+    GatherGeom g1{ga->n, ga->hi, ga->wi, ga->ci, ga->ho, ga->wo, ga->co, ga->kh, ga->kw, ga->stride, ga->pad, ga->dil};
     const GatherGeom g2{gb->n, gb->hi, gb->wi, gb->ci, gb->ho, gb->wo, gb->co, gb->kh, gb->kw, gb->stride, gb->pad, gb->dil};
     if (stem_mfma_ok(g1) || stem_mfma_ok(g2)) return SENAS_EUNSUPPORTED;
     const bool c8a = !in_relu && c8_mfma_ok(g1), c8b = !in_relu && c8_mfma_ok(g2);
     if (c8a != c8b) return SENAS_EUNSUPPORTED;
+    if (plane != 0) {                                    // planar groups: the stride-1 LDS-window kernel only (see conv2d_fwd_impl)
+        SENAS_REQUIRE(plane == (int64_t)ga->n * ga->ho * ga->wo * 8 && ga->co % 8 == 0, "conv2d_fwd_pair_planar: the plane is n * h * w * 8 floats, c_out a multiple of 8");
+        if (!c8a && (thin_k_ok(g1) || thin_k_ok(g2) || !(lds_gather_ok(g1) && lds_gather_ok(g2)) || (thin_n_ok(g1) && g1.cout <= 4))) return SENAS_EUNSUPPORTED;
+        g1.oplane = (long)plane;
+    }
     if (c8a) return launch_c8_mfma(g1, x, wa, ga->ci, 1, 0, ya, stats_a, st, Pair2{x, wb, yb, nullptr, stats_b, g2.dil, g2.pad, 1});
     if (thin_k_ok(g1) || thin_k_ok(g2)) return SENAS_EUNSUPPORTED;
     const bool lds = lds_gather_ok(g1) && lds_gather_ok(g2), s2 = lds_gather_s2_ok(g1) && lds_gather_s2_ok(g2);
@@ -1023,6 +1050,19 @@ extern "C" int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv
     const Pair2 pr{x, ib, yb, nullptr, stats_b, g2.dil, g2.pad, 1};
     if (lds) return launch_lds_gather<false>(g1, x, ia, ya, in_relu, nullptr, stats_a, st, pr);
     return launch_lds_gather_s2(g1, x, ia, ya, in_relu, nullptr, stats_a, st, pr);
+}
+
+extern "C" int senas_conv2d_fwd_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                                     float* ya, float* yb, int in_relu, double* stats_a, double* stats_b, void* ws_a, void* ws_b,
+                                     const float* packed_a, const float* packed_b, void* stream) {
+    return conv2d_fwd_pair_impl(ga, gb, x, wa, wb, ya, yb, 0, in_relu, stats_a, stats_b, ws_a, ws_b, packed_a, packed_b, stream);
+}
+
+extern "C" int senas_conv2d_fwd_pair_planar(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* x, const float* wa, const float* wb,
+                                            float* ya, float* yb, int64_t y_plane, int in_relu, double* stats_a, double* stats_b, void* ws_a,
+                                            void* ws_b, const float* packed_a, const float* packed_b, void* stream) {
+    if (y_plane == 0) return SENAS_EUNSUPPORTED;
+    return conv2d_fwd_pair_impl(ga, gb, x, wa, wb, ya, yb, y_plane, in_relu, stats_a, stats_b, ws_a, ws_b, packed_a, packed_b, stream);
 }
 
 extern "C" int senas_conv2d_bwd_data_pair(const senas_conv_geom* ga, const senas_conv_geom* gb, const float* dya, const float* dyb,

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_c8_mfma_kernel(GatherGeom g, const f
         const int oy = oy0 + RW * wave + (j >> 1), ox = ox0 + 16 * (j & 1) + lp;
         if (ch_ok && oy < g.hout && ox < g.wout) {
             float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-            stv<4>(out + (((size_t)n * g.hout + oy) * g.wout + ox) * cout + 4 * lk, v);
+            stv<4>(out + out_offset(g, ((size_t)n * g.hout + oy) * g.wout + ox, 4 * lk), v);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { s1[q] += (double)v[q]; s2[q] += (double)v[q] * (double)v[q]; }
         }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
                     const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
                     if (oy < g.hout && ox < g.wout) {
                         float4 val = *reinterpret_cast<const float4*>(tp + (m * 32 + pq) * 36 + c4 * 4);
-                        const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + cot * 32 + c4 * 4;
+                        const size_t o = out_offset(g, ((size_t)n * g.hout + oy) * g.wout + ox, cot * 32 + c4 * 4);      // (mask / epilogue forms: interleaved only)
                         if (mask != nullptr) {
                             const float4 mk = *reinterpret_cast<const float4*>(mask + o);
                             if (!(mk.x > 0.f)) val.x = 0.f;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * RW * KS) void conv_lds_kernel(GatherGeom g, co
                 const int oy = oy0 + (MT * wave + m) * RPM + pq / TWL, ox = ox0 + pq % TWL;
                 float val = acc[m][v];
                 if (kg == 0 && oy < g.hout && ox < g.wout && cok) {
-                    const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox) * g.cout + co;
+                    const size_t o = out_offset(g, ((size_t)n * g.hout + oy) * g.wout + ox, co);
                     if (mask != nullptr && !(mask[o] > 0.f)) val = 0.f;
                     s += val;
                     q += (double)val * val;

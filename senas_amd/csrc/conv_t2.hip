@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_t2_lds_kernel(GatherGeom g, const fl
         const int i = acc_row_t(v, h);
         const int qy = qy0 + i / TQW, qx = qx0 + i % TQW;
         if (cok && qy < g.hin && qx < g.win) {
-            out[(((size_t)n * g.hout + 2 * qy + spy) * g.wout + 2 * qx + spx) * g.cout + co] = acc[v];
+            out[out_offset(g, ((size_t)n * g.hout + 2 * qy + spy) * g.wout + 2 * qx + spx, co)] = acc[v];
             s += (double)acc[v];
             q += (double)acc[v] * (double)acc[v];
         }

@@ -12,6 +12,8 @@
 // The prepare kernels are tiny (one block per term) and replace ~25 / ~40 elementwise launches.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace senas {
 
 constexpr int kMaxMid = 16;      // SE hidden width: c/16, c <= 256
@@ -394,6 +396,125 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
 static size_t fused_fwd_lds(const NodeDesc& d) {
     const int R = 256 / d.c;
     return ((size_t)R * d.c * 2 + d.c) * sizeof(double) + ((size_t)d.nterms * d.c + 4 * d.c + kMaxMid) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------ forward, wide
+// Many-term nodes on SMALL maps (the search cell's 12 - 24 addends on maps up to ~64 x 64: a handful of blocks): the
+// preparation runs as a prologue of every block with one thread per (term, channel) -- one launch instead of two on the
+// launch-bound chain of small cells that is the forward critical path of a search pass (profiles/r5_search_cells.txt).
+// Every expression and every order of summation is node_prepare_fwd_kernel's / node_combine_fwd_kernel's, so the result is
+// bit-identical to the two-launch form (tests/test_gpu_parity.py::test_wide_node_is_the_two_launch_node_bit_for_bit).
+// dynamic LDS floats: sc[TC] | sf[TC] | cf[TC] | sh[TC] | m[TC] | bias[c] | a1[T][kMaxMid]   (TC = T * c <= kWideTC)
+constexpr int kWideTC = 1024;
+
+template <int V>
+__global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z, const float* __restrict__ residual,
+                                                            float* __restrict__ y, uint8_t* __restrict__ mask8,
+                                                            float* __restrict__ coefs, float* __restrict__ gate,
+                                                            float* __restrict__ se_m, float* __restrict__ se_a1,
+                                                            double* __restrict__ out_stats, float* __restrict__ y2, int y2s, int y2pad) {
+    extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    const int n = blockIdx.y, nimg = d.n, c = d.c, T = d.nterms, TC = T * c;
+    const bool first = blockIdx.x == 0, writer0 = first && n == 0;
+    const int R = 256 / c;                  // the prepare kernel's image rows: the batch sums are associated as it associates them
+    float* sc = ldsw;
+    float* sf = sc + TC;
+    float* cf = sf + TC;
+    float* sh = cf + TC;
+    float* m_s = sh + TC;
+    float* bias = m_s + TC;
+    float* a_s = bias + c;
+    for (int i = threadIdx.x; i < TC; i += 256) {
+        const int t = i / c, ch = i - t * c;
+        const double* st = d.stats[t];
+        const bool se = d.w1[t] != nullptr;
+        double ss = 0.0, qq = 0.0, zown = 0.0;
+        if (st != nullptr && (d.training || se))
+            for (int rr = 0; rr < R; ++rr) {
+                double s = 0.0, q = 0.0;
+                for (int img = rr; img < nimg; img += R) {
+                    const double v0 = st[(size_t)img * d.sstride[t] + ch * 2], v1 = st[(size_t)img * d.sstride[t] + ch * 2 + 1];
+                    s += v0; q += v1;
+                    if (img == n) zown = v0;
+                }
+                ss += s; qq += q;
+            }
+        const float gam = d.gamma[t][ch], bet = d.beta[t][ch];
+        float rm = 0.f, rv = 0.f;
+        if (d.rmean[t] != nullptr) { rm = d.rmean[t][ch]; rv = d.rvar[t][ch]; }
+        float mean, invstd;
+        if (d.training) {
+            const double mm = (double)nimg * (double)d.hw, mu = ss / mm;
+            double var = qq / mm - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+            if (writer0 && d.rmean[t] != nullptr) {
+                const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
+                d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
+                d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
+            }
+        } else {
+            mean = rm;
+            invstd = 1.f / sqrtf(rv + d.eps);
+        }
+        const float scale = gam * invstd;
+        const float shift = bet - mean * scale;
+        if (writer0) {
+            float* co = coefs + (size_t)t * 4 * c;
+            co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
+        }
+        sc[i] = scale;
+        sf[i] = shift;
+        if (se) {
+            const double zbar = st != nullptr ? zown / (double)d.hw : 0.0;
+            const float mv = (float)((double)scale * zbar + (double)shift);
+            m_s[i] = mv;
+            if (first) se_m[((size_t)t * nimg + n) * c + ch] = mv;
+        }
+    }
+    if (writer0 && d.training)
+        for (int t = threadIdx.x; t < T; t += 256) if (d.nbt[t] != nullptr) *d.nbt[t] += 1;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * kMaxMid; idx += 256) {
+        const int t = idx / kMaxMid, j = idx - t * kMaxMid;
+        if (d.w1[t] == nullptr || j >= d.mid[t]) continue;
+        float a = 0.f;
+        for (int k = 0; k < c; ++k) a = fmaf(m_s[t * c + k], d.w1[t][j * c + k], a);
+        a_s[idx] = a;
+        if (first) se_a1[((size_t)t * nimg + n) * kMaxMid + j] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TC; i += 256) {
+        const int t = i / c, ch = i - t * c;
+        const float w = d.mix != nullptr ? d.mix[t] : 1.f;
+        const size_t o = ((size_t)t * nimg + n) * c + ch;
+        if (d.w1[t] == nullptr) {
+            if (first) gate[o] = 1.f;
+            cf[i] = w * sc[i];
+            sh[i] = w * sf[i];
+        } else {
+            const int mid = d.mid[t];
+            float a = 0.f;
+            for (int j = 0; j < mid; ++j) a = fmaf(fmaxf(a_s[t * kMaxMid + j], 0.f), d.w2[t][ch * mid + j], a);
+            const float g = 1.f / (1.f + expf(-a));
+            if (first) gate[o] = g;
+            cf[i] = w * g * sc[i];
+            sh[i] = w * g * sf[i];
+        }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float b = 0.f;
+        for (int t = 0; t < T; ++t) b += sh[t * c + ch];
+        bias[ch] = b;
+    }
+    __syncthreads();
+    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8, out_stats, y2, y2s, y2pad);
+}
+
+static size_t wide_fwd_lds(const NodeDesc& d) {
+    return ((size_t)5 * d.nterms * d.c + d.c + (size_t)d.nterms * kMaxMid) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------ backward reduce
@@ -989,6 +1110,20 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
         if (V == 4) hipLaunchKernelGGL((node_fused_fwd_kernel<4>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s, y2pad);
         else hipLaunchKernelGGL((node_fused_fwd_kernel<1>), grid, dim3(256), fused_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s, y2pad);
         return launch_status("node_fwd (fused)");
+    }
+    {
+        // many terms on a small map: prologue + stream in one launch (node_wide_fwd_kernel) while the whole grid is a few
+        // dozen blocks -- beyond that every block's prologue costs more than the launch it saves
+        const int V = (d.c % 4 == 0) ? 4 : 1;
+        const unsigned gx = node_grid(d.hw * (d.c / V), d.n);
+        const char* sw = getenv("SENAS_NODE_WIDE");                        // ("0": the two-launch form, for the bit-identity test)
+        const bool wide_on = !(sw && sw[0] == '0');
+        if (wide_on && d.nterms * d.c <= kWideTC && (long)gx * d.n <= 128 && wide_fwd_lds(d) <= 48 * 1024) {
+            dim3 grid(gx, d.n);
+            if (V == 4) hipLaunchKernelGGL((node_wide_fwd_kernel<4>), grid, dim3(256), wide_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s, y2pad);
+            else hipLaunchKernelGGL((node_wide_fwd_kernel<1>), grid, dim3(256), wide_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s, y2pad);
+            return launch_status("node_fwd (wide)");
+        }
     }
     const size_t lds1 = prepare_fwd_lds(d);
     SENAS_REQUIRE(lds1 <= 64 * 1024, "node_fwd: batch x channels too large for the prepare kernel");

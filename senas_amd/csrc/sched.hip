@@ -124,10 +124,12 @@ static std::vector<hipStream_t>& lane_pool() {
 // (down1 forward: 372 -> 1 203 us; the search step 27.2 -> 59.3 ms, the train step 15.7 -> 27.4) -- whatever the queue
 // arbitration does with the priority, every launch of such a queue pays for it.  SENAS_SCHED_PRIORITY=1 turns it on again
 // (the classes and the priorities together) for a re-measurement on another runtime.
-static bool pool_priorities() {
+// SENAS_SCHED_PRIORITY=2: the other way round -- the light streams at the default priority, the HEAVY ones at the device's least.
+static int pool_priority_mode() {
     const char* e = getenv("SENAS_SCHED_PRIORITY");
-    return e && e[0] == '1';
+    return e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)) : 0;
 }
+static bool pool_priorities() { return pool_priority_mode() != 0; }
 constexpr int kHighStreams = 2;
 
 // grow the pool to `want` streams on distinct hardware queues (fewer if the device does not give that many)
@@ -138,7 +140,10 @@ static void lane_pool_grow(int want) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int tries = 0; (int)pool.size() < want && tries < 16; ++tries) {
         hipStream_t st = nullptr;
-        const int prio = (pool_priorities() && (int)pool.size() < kHighStreams) ? greatest : 0;
+        const int mode = pool_priority_mode();
+        const bool light_stream = (int)pool.size() < kHighStreams;
+        const int prio = mode == 1 ? (light_stream ? greatest : 0) : (mode == 2 ? (light_stream ? 0 : least) : 0);
+        if (getenv("SENAS_SCHED_VERBOSE") && pool.empty()) fprintf(stderr, "[sched] stream priorities of this device: least %d, greatest %d\n", least, greatest);
         if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) break;
         bool ok = true;
         for (hipStream_t kept : pool) ok = ok && lanes_overlap(kept, st);

@@ -8,6 +8,7 @@ There is no CPU path: a non-CUDA tensor raises.
 """
 import contextlib
 import ctypes as C
+import os
 
 import torch
 
@@ -57,6 +58,32 @@ def new_nhwc(n, c, h, w, like):
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+# A STACKED convolution output / gradient (k edges x c channels each) travels between the autograd nodes of this package as a 5-D
+# tensor [k][n][c][h][w] whose strides say which of two layouts the memory has:
+#   planar      (k parts, each a dense NHWC tensor):   strides (n*h*w*c, h*w*c, 1, w*c, c)      -- senas_conv2d_fwd_planar
+#   interleaved (one NHWC tensor of k*c channels):     strides (c, h*w*k*c, 1, w*k*c, k*c)      -- what every other kernel reads
+def planar_empty(k, n, c, h, w, like):
+    flat = torch.empty(k * n * c * h * w, device=like.device, dtype=torch.float32)
+    return flat.as_strided((k, n, c, h, w), (n * h * w * c, h * w * c, 1, w * c, c))
+
+
+def stacked_5d(t4, k):
+    """The 5-D interleaved view of a dense NHWC tensor [n][k*c][h][w] (no copy)."""
+    n, kc, h, w = t4.shape
+    c = kc // k
+    t4 = nhwc(t4)
+    return t4.as_strided((k, n, c, h, w), (c, h * w * kc, 1, w * kc, kc), t4.storage_offset())
+
+
+def stacked_4d(t5):
+    """A 5-D stacked tensor as the dense NHWC tensor [n][k*c][h][w] the kernels read: a view when it is interleaved, else a copy."""
+    k, n, c, h, w = t5.shape
+    kc = k * c
+    if t5.stride() == (c, h * w * kc, 1, w * kc, kc):
+        return t5.as_strided((n, kc, h, w), (h * w * kc, 1, w * kc, kc), t5.storage_offset())
+    return t5.permute(1, 0, 2, 3, 4).reshape(n, kc, h, w).contiguous(memory_format=CL)
 
 
 def new_stats(n, c, like):
@@ -444,10 +471,12 @@ def _conv_wgrad_pair(ga, gb, x, in_relu, dya, dyb, wa, wb, da, db):
 
 
 class _Conv2d(torch.autograd.Function):
-    """y = conv(relu?(x), w) (+ producer-side batch-norm statistics of y)."""
+    """y = conv(relu?(x), w) (+ producer-side batch-norm statistics of y).  ``stacked`` = k > 0: the convolution is a stacked one
+    (k edges' candidates, weights stacked along c_out): y comes back 5-D [k][n][c_out/k][h][w] -- planar parts where a kernel
+    has that epilogue (senas_conv2d_fwd_planar), else the 5-D view of the interleaved tensor."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad, dil, transposed, out_pad, groups, in_relu, want_stats):
+    def forward(ctx, x, w, stride, pad, dil, transposed, out_pad, groups, in_relu, want_stats, stacked=0):
         x = nhwc(x)
         w = _dev(w).contiguous()
         n, ci, hi, wi = x.shape
@@ -464,18 +493,34 @@ class _Conv2d(torch.autograd.Function):
         wo = conv_out_size(wi, kw, stride, pad, dil, transposed, out_pad)
         g = ConvGeom(n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, dil, int(transposed), groups)
         L = _lib.lib()
-        y = new_nhwc(n, co, ho, wo, x)
         stats = new_stats(n, co, x) if want_stats else None
         ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
-        with _span('conv_fwd', g, x, w, y):
-            rc = _lib.UNSUPPORTED
-            if MATH_TERMS:
-                rc = L.senas_conv2d_fwd_lp(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
-                                           ws.data_ptr(), _packed_lp(w, 0), MATH_TERMS, _stream())
-            if rc == _lib.UNSUPPORTED:                      # (off the bf16 path: the fp32 kernels)
-                rc = L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y.data_ptr(), int(in_relu), _p(stats),
-                                        ws.data_ptr(), _packed(w, 0), _stream())
-            _lib.check(rc, 'senas_conv2d_fwd')
+        y = None
+        if stacked and PLANAR and not MATH_TERMS and co == stacked * 8:
+            # the 8-channel parts are read one by one by different node kernels: planar parts where a kernel has that epilogue
+            # (declined -> the interleaved launch below)
+            y5 = planar_empty(stacked, n, 8, ho, wo, x)
+            with _span('conv_fwd', g, x, w, y5):
+                rc = L.senas_conv2d_fwd_planar(C.byref(g), x.data_ptr(), w.data_ptr(), y5.data_ptr(), n * ho * wo * 8, int(in_relu),
+                                               _p(stats), ws.data_ptr(), _packed(w, 0), _stream())
+            if rc == _lib.UNSUPPORTED:
+                _unspan()
+            else:
+                _lib.check(rc, 'senas_conv2d_fwd_planar')
+                y = y5
+                PLANAR_LAUNCHES[0] += 1
+        if y is None:
+            y4 = new_nhwc(n, co, ho, wo, x)
+            with _span('conv_fwd', g, x, w, y4):
+                rc = _lib.UNSUPPORTED
+                if MATH_TERMS:
+                    rc = L.senas_conv2d_fwd_lp(C.byref(g), x.data_ptr(), w.data_ptr(), y4.data_ptr(), int(in_relu), _p(stats),
+                                               ws.data_ptr(), _packed_lp(w, 0), MATH_TERMS, _stream())
+                if rc == _lib.UNSUPPORTED:                      # (off the bf16 path: the fp32 kernels)
+                    rc = L.senas_conv2d_fwd(C.byref(g), x.data_ptr(), w.data_ptr(), y4.data_ptr(), int(in_relu), _p(stats),
+                                            ws.data_ptr(), _packed(w, 0), _stream())
+                _lib.check(rc, 'senas_conv2d_fwd')
+            y = stacked_5d(y4, stacked) if stacked else y4
         ctx.save_for_backward(x, w)
         ctx.g, ctx.in_relu = g, int(in_relu)
         ctx.set_materialize_grads(False)          # no zero tensor for the (non-differentiable) statistics output
@@ -488,8 +533,8 @@ class _Conv2d(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g, L = ctx.g, _lib.lib()
         if dy is None:
-            return (None,) * 10
-        dy = nhwc(dy)
+            return (None,) * 11
+        dy = nhwc(stacked_4d(dy) if dy.dim() == 5 else dy)
         dx = dw = None
         if ctx.needs_input_grad[1]:                       # (queued for the weight-gradient lane where there is one)
             dest = wgrad_dest(w)
@@ -508,12 +553,18 @@ class _Conv2d(torch.autograd.Function):
                     rc = L.senas_conv2d_bwd_data(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
                                                  x.data_ptr(), ws.data_ptr(), _packed(w, 1), _stream())
                 _lib.check(rc, 'senas_conv2d_bwd_data')
-        return dx, dw, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, stride=1, pad=0, dil=1, transposed=False, out_pad=0, groups=1, in_relu=False, want_stats=False):
-    """Returns (y, stats) -- stats is None unless want_stats."""
-    return _Conv2d.apply(x, w, stride, pad, dil, transposed, out_pad, groups, in_relu, want_stats)
+# Stacked convolutions of a search cell write planar 8-channel parts where a kernel has that epilogue (class-wide switch)
+PLANAR = os.environ.get('SENAS_PLANAR', '1') != '0'
+PLANAR_LAUNCHES = [0]        # (tests: how many stacked convolutions took the planar epilogue)
+
+
+def conv2d(x, w, stride=1, pad=0, dil=1, transposed=False, out_pad=0, groups=1, in_relu=False, want_stats=False, stacked=0):
+    """Returns (y, stats) -- stats is None unless want_stats.  ``stacked`` = k: the output is a stacked convolution's (k parts
+    of c_out / k channels each) and comes back 5-D [k][n][c][h][w]; functional.unstack takes it apart."""
+    return _Conv2d.apply(x, w, stride, pad, dil, transposed, out_pad, groups, in_relu, want_stats, stacked)
 
 
 class _Conv2dPair(torch.autograd.Function):
@@ -523,7 +574,7 @@ class _Conv2dPair(torch.autograd.Function):
     (its gradient is then ONE n-ary sum over all readers, functional.fan_out).  Outputs ya, stats_a, yb, stats_b."""
 
     @staticmethod
-    def forward(ctx, xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats):
+    def forward(ctx, xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats, stacked=0):
         x = nhwc(xa)
         wa, wb = _dev(wa).contiguous(), _dev(wb).contiguous()
         n, ci, hi, wi = x.shape
@@ -536,11 +587,31 @@ class _Conv2dPair(torch.autograd.Function):
         ga = ConvGeom(n, hi, wi, ci, ho, wo, co, k, k, stride, pad_a, dil_a, 0, 1)
         gb = ConvGeom(n, hi, wi, ci, ho, wo, co, k, k, stride, pad_b, dil_b, 0, 1)
         L = _lib.lib()
-        ya, yb = new_nhwc(n, co, ho, wo, x), new_nhwc(n, co, ho, wo, x)
         sa = new_stats(n, co, x) if want_stats else None
         sb = new_stats(n, co, x) if want_stats else None
         nb = int(L.senas_conv2d_ws_bytes(C.byref(ga)))
         wsa, wsb = (torch.empty(nb, device=x.device, dtype=torch.uint8) for _ in range(2))
+        planar = False
+        if stacked and PLANAR and not MATH_TERMS and co == stacked * 8:      # both outputs in planar 8-channel parts (see _Conv2d)
+            ya, yb = planar_empty(stacked, n, 8, ho, wo, x), planar_empty(stacked, n, 8, ho, wo, x)
+            with _span('conv_fwd', ga, x, wa, ya, problems=2):
+                rc = L.senas_conv2d_fwd_pair_planar(C.byref(ga), C.byref(gb), x.data_ptr(), wa.data_ptr(), wb.data_ptr(), ya.data_ptr(),
+                                                    yb.data_ptr(), n * ho * wo * 8, int(in_relu), _p(sa), _p(sb), wsa.data_ptr(), wsb.data_ptr(),
+                                                    _packed(wa, 0), _packed(wb, 0), _stream())
+            if rc == _lib.UNSUPPORTED:
+                _unspan()
+            else:
+                _lib.check(rc, 'senas_conv2d_fwd_pair_planar')
+                planar = True
+                PLANAR_LAUNCHES[0] += 2
+        if planar:
+            ctx.save_for_backward(x, wa, wb)
+            ctx.geoms, ctx.in_relu = (ga, gb), int(in_relu)
+            ctx.set_materialize_grads(False)
+            if want_stats:
+                ctx.mark_non_differentiable(sa, sb)
+            return ya, sa, yb, sb
+        ya, yb = new_nhwc(n, co, ho, wo, x), new_nhwc(n, co, ho, wo, x)
         with _span('conv_fwd', ga, x, wa, ya, problems=2):
             rc = L.senas_conv2d_fwd_pair(C.byref(ga), C.byref(gb), x.data_ptr(), wa.data_ptr(), wb.data_ptr(), ya.data_ptr(), yb.data_ptr(),
                                          int(in_relu), _p(sa), _p(sb), wsa.data_ptr(), wsb.data_ptr(), _packed(wa, 0), _packed(wb, 0), _stream())
@@ -557,6 +628,8 @@ class _Conv2dPair(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(sa, sb)
+        if stacked:
+            ya, yb = stacked_5d(ya, stacked), stacked_5d(yb, stacked)
         return ya, sa, yb, sb
 
     @staticmethod
@@ -564,9 +637,9 @@ class _Conv2dPair(torch.autograd.Function):
         x, wa, wb = ctx.saved_tensors
         (ga, gb), L = ctx.geoms, _lib.lib()
         if dya is None and dyb is None:
-            return (None,) * 11
-        dya = nhwc(dya) if dya is not None else None
-        dyb = nhwc(dyb) if dyb is not None else None
+            return (None,) * 12
+        dya = nhwc(stacked_4d(dya) if dya.dim() == 5 else dya) if dya is not None else None
+        dyb = nhwc(stacked_4d(dyb) if dyb.dim() == 5 else dyb) if dyb is not None else None
         dxa = dxb = None
         # the weight gradients: queued for the weight-gradient lane where there is one (see _Conv2d.backward)
         if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and dya is not None and dyb is not None and wa.data_ptr() != wb.data_ptr():
@@ -612,7 +685,7 @@ class _Conv2dPair(torch.autograd.Function):
                 dxa, dxb = outs
             else:
                 _lib.check(rc, 'senas_conv2d_bwd_data_pair')
-        return dxa, dxb, dwa, dwb, None, None, None, None, None, None, None
+        return dxa, dxb, dwa, dwb, None, None, None, None, None, None, None, None
 
 
 def _lp_serves(x, w, stride, pad, dil):
@@ -624,14 +697,15 @@ def _lp_serves(x, w, stride, pad, dil):
     return bool(_lib.lib().senas_conv2d_kernel_name_lp(C.byref(g), 0, MATH_TERMS))
 
 
-def conv2d_pair(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu=False, want_stats=False):
-    """((ya, stats_a), (yb, stats_b)) of two convolutions of one tensor (two aliases of it) that differ in the dilation only."""
+def conv2d_pair(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu=False, want_stats=False, stacked=0):
+    """((ya, stats_a), (yb, stats_b)) of two convolutions of one tensor (two aliases of it) that differ in the dilation only.
+    ``stacked``: as functional.conv2d."""
     if MATH_TERMS and _lp_serves(xa, wa, stride, pad_a, dil_a):
         # the bf16-pipe kernels have no pair form: two calls where they serve the shape (what they do not serve -- the search
         # cell's 8-channel edges, small maps -- keeps its fp32 pair launch in every math mode)
-        return (conv2d(xa, wa, stride, pad_a, dil_a, in_relu=in_relu, want_stats=want_stats),
-                conv2d(xb, wb, stride, pad_b, dil_b, in_relu=in_relu, want_stats=want_stats))
-    ya, sa, yb, sb = _Conv2dPair.apply(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats)
+        return (conv2d(xa, wa, stride, pad_a, dil_a, in_relu=in_relu, want_stats=want_stats, stacked=stacked),
+                conv2d(xb, wb, stride, pad_b, dil_b, in_relu=in_relu, want_stats=want_stats, stacked=stacked))
+    ya, sa, yb, sb = _Conv2dPair.apply(xa, xb, wa, wb, stride, pad_a, dil_a, pad_b, dil_b, in_relu, want_stats, stacked)
     return (ya, sa), (yb, sb)
 
 
@@ -1926,21 +2000,35 @@ class _UnstackView(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, k, landing, used):
-        z = nhwc(z)
-        n, kc, h, w = z.shape
-        c = kc // k
+        ctx.five = z.dim() == 5
         parts = []
-        for e in range(used):
-            # the same storage, not a view in autograd's eyes (this Function owns the backward pass)
-            parts.append(torch.empty(0, device=z.device, dtype=z.dtype).set_(z.untyped_storage(), z.storage_offset() + e * c,
-                                                                             (n, c, h, w), (h * w * kc, 1, w * kc, kc)))
+        if ctx.five:
+            # a stacked convolution's 5-D output [k][n][c][h][w], planar or interleaved: part e is z[e] with z's own strides
+            _dev(z)
+            if z.shape[0] != k:
+                raise SenasHipError('unstack: a %d-part stacked tensor into %d parts' % (z.shape[0], k))
+            n, c, h, w = z.shape[1:]
+            for e in range(used):
+                parts.append(torch.empty(0, device=z.device, dtype=z.dtype).set_(z.untyped_storage(), z.storage_offset() + e * z.stride(0),
+                                                                                 (n, c, h, w), tuple(z.stride()[1:])))
+        else:
+            z = nhwc(z)
+            n, kc, h, w = z.shape
+            c = kc // k
+            for e in range(used):
+                # the same storage, not a view in autograd's eyes (this Function owns the backward pass)
+                parts.append(torch.empty(0, device=z.device, dtype=z.dtype).set_(z.untyped_storage(), z.storage_offset() + e * c,
+                                                                                 (n, c, h, w), (h * w * kc, 1, w * kc, kc)))
         ctx.k, ctx.shape, ctx.k_total, ctx.landing = used, (n, c, h, w), k, landing
         ctx.set_materialize_grads(False)
         return tuple(parts)
 
     @staticmethod
     def backward(ctx, *grads):
-        return _Unstack.backward(ctx, *grads)[:4]
+        out = _Unstack.backward(ctx, *grads)[:4]
+        if ctx.five and out[0] is not None:                  # (the gradient of a 5-D stacked tensor: the 5-D view of the interleaved one)
+            out = (stacked_5d(out[0], ctx.k_total),) + tuple(out[1:])
+        return out
 
 
 def unstack(z, k, want_stats=True, used=None, owner=None, stats=None):
@@ -1949,7 +2037,10 @@ def unstack(z, k, want_stats=True, used=None, owner=None, stats=None):
     gradient landing buffer of this shape from pass to pass.  ``stats``: the stacked convolution's own statistics
     (double [n, k*c, 2]) -- with them (or when none are wanted) the parts are aliases of ``z`` and nothing is launched."""
     used = k if used is None else used
-    n, kc, h, w = z.shape
+    if z.dim() == 5:
+        n, kc, h, w = z.shape[1], z.shape[0] * z.shape[2], z.shape[3], z.shape[4]
+    else:
+        n, kc, h, w = z.shape
     landing = None
     if (kc // k) % 4 == 0:
         shape = (n, kc // k, h, w)
@@ -1965,7 +2056,7 @@ def unstack(z, k, want_stats=True, used=None, owner=None, stats=None):
         out = _UnstackView.apply(z, k, landing, used)
         return [(out[e], stats[:, e * c:(e + 1) * c] if stats is not None else None, (landing, e) if landing is not None else None)
                 for e in range(used)]
-    out = _Unstack.apply(z, k, want_stats, landing, used)
+    out = _Unstack.apply(stacked_4d(z) if z.dim() == 5 else z, k, want_stats, landing, used)
     return [(out[e], out[used + e] if want_stats else None, (landing, e) if landing is not None else None) for e in range(used)]
 
 

@@ -5,6 +5,7 @@ Tolerance: north_star asks for 1e-3 relative fp32; the checks here use 2e-4 of t
 magnitude for activations / gradients (tighter), bit-exact for genotypes.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -1893,3 +1894,114 @@ def test_dstail_vs_torch(case):
         close(dbns[t].running_mean, rm.numpy(), 'running_mean %d' % t, rel=2e-5)
         close(dbns[t].running_var, rv.numpy(), 'running_var %d' % t, rel=2e-5)
         assert int(dbns[t].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('cfg', [dict(n=4, c=8, h=16, w=16, T=12, se=True, zero=True, training=True, relu=True),
+                                 dict(n=4, c=8, h=64, w=64, T=24, se=True, zero=True, training=True, relu=True),
+                                 dict(n=3, c=8, h=9, w=7, T=18, se=True, zero=False, training=False, relu=True),
+                                 dict(n=2, c=32, h=8, w=8, T=12, se=True, zero=True, training=True, relu=False),
+                                 dict(n=5, c=12, h=5, w=6, T=9, se=False, zero=False, training=True, relu=True)],
+                         ids=lambda d: 'n%d_c%d_%dx%d_T%d%s' % (d['n'], d['c'], d['h'], d['w'], d['T'], '' if d['training'] else '_eval'))
+def test_wide_node_is_the_two_launch_node_bit_for_bit(cfg):
+    """csrc/node.hip node_wide_fwd_kernel (many-term nodes on small maps: preparation as a prologue of the one launch) against
+    the prepare + combine pair it replaces there (SENAS_NODE_WIDE=0): output, ReLU-masked gradients of every input, running
+    statistics and step counters -- the forward pass bit for bit, the gradients (fp64 atomics in the backward reduce) to 1e-6."""
+    import copy
+    import torch.nn as nn
+    from senas_amd import functional as F
+    from senas_amd.operations import SEBlock
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w, T = cfg['n'], cfg['c'], cfg['h'], cfg['w'], cfg['T']
+    zs = [torch.randn(n, c, h, w, generator=g) * (0.5 + 0.1 * t) + 0.05 * t for t in range(T)]
+    if cfg['zero']:
+        zs[1] = None
+    bns = []
+    for t in range(T):
+        bn = nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.train(cfg['training'])
+        bns.append(bn)
+    ses = [SEBlock(c) if (cfg['se'] and t % 3 == 0 and zs[t] is not None) else None for t in range(T)]
+    mix = torch.rand(T, generator=g) + 0.1
+    gy = torch.randn(n, c, h, w, generator=g)
+    res = []
+    keep = os.environ.get('SENAS_NODE_WIDE')
+    try:
+        for mode in ('1', '0'):
+            os.environ['SENAS_NODE_WIDE'] = mode
+            dbns = [copy.deepcopy(b).to(dev()) for b in bns]
+            dses = [copy.deepcopy(s_).to(dev()) if s_ is not None else None for s_ in ses]
+            zd = [z.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) if z is not None else None for z in zs]
+            md = mix.to(dev()).requires_grad_(True)
+            out = F.bn_combine([F.Term(zd[t], dbns[t], se=dses[t]) for t in range(T)], mix=md, relu=cfg['relu'])
+            out.backward(gy.to(dev()))
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), [b.running_mean.clone() for b in dbns], [b.running_var.clone() for b in dbns],
+                        [int(b.num_batches_tracked) for b in dbns], [z.grad.clone() for z in zd if z is not None], md.grad.clone(),
+                        [b.weight.grad.clone() for b in dbns]))
+    finally:
+        if keep is None:
+            os.environ.pop('SENAS_NODE_WIDE', None)
+        else:
+            os.environ['SENAS_NODE_WIDE'] = keep
+    a, b = res
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    for x, y_ in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.equal(x, y_)
+    assert a[3] == b[3]
+    for x, y_ in zip(a[4] + [a[5]] + a[6], b[4] + [b[5]] + b[6]):
+        assert float((x - y_).abs().max()) <= 1e-6 * (float(y_.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize('kind,size', [('up', 32), ('down', 32), ('up', 8), ('down', 64)])
+def test_planar_stacked_outputs_change_nothing_but_the_layout(kind, size):
+    """The stacked convolutions of a search cell with their 8-channel parts written PLANAR (senas_conv2d_fwd_planar: every edge's
+    slice a dense tensor, read in full lines by its node kernel) against the interleaved form (functional.PLANAR = False): the
+    same kernels compute the same values -- the cell's output bit for bit, every gradient to the order of atomics (1e-6)."""
+    from senas_amd import functional as F
+    from senas_amd.cell import Cell
+    torch.manual_seed(5)
+    cell = Cell(3, 1, 32 if kind == 'down' else 64, 32, 32, kind).to(dev()).train()
+    g = torch.Generator().manual_seed(6)
+    if kind == 'down':
+        in0 = torch.randn(2, 32, 2 * size, 2 * size, generator=g)
+        in1 = torch.randn(2, 32, size, size, generator=g)
+    else:
+        in0 = torch.randn(2, 64, size, size, generator=g)
+        in1 = torch.randn(2, 32, size // 2, size // 2, generator=g)
+    nops = 6
+    k = sum(2 + i for i in range(3))
+    w_norm = torch.softmax(torch.randn(k, nops, generator=g), -1).to(dev())
+    w_chg = torch.softmax(torch.randn(k, nops, generator=g), -1).to(dev())
+    betas = torch.softmax(torch.randn(k, generator=g), -1).to(dev())
+    res = []
+    keep = F.PLANAR
+    try:
+        for planar in (True, False):
+            F.PLANAR = planar
+            F.PLANAR_LAUNCHES[0] = 0
+            for p in cell.parameters():
+                p.grad = None
+            a = in0.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            b = in1.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wn, wc, bt = (t.clone().requires_grad_(True) for t in (w_norm, w_chg, betas))
+            out = cell(a, b, wn, wc, bt)
+            out.backward(torch.ones_like(out) * 0.01 + out.detach() * 0.1)
+            torch.cuda.synchronize()
+            res.append((F.PLANAR_LAUNCHES[0], out.detach().clone(), a.grad.clone(), b.grad.clone(), wn.grad.clone(), wc.grad.clone(), bt.grad.clone(),
+                        {k_: p.grad.clone() for k_, p in cell.named_parameters() if p.grad is not None}))
+    finally:
+        F.PLANAR = keep
+    on, off = res
+    assert on[0] >= 4 and off[0] == 0, (on[0], off[0])                    # the dilated pairs and the SE stacks of both input states
+    assert torch.equal(on[1], off[1]), float((on[1] - off[1]).abs().max())
+    for x_, y_ in zip(on[2:7], off[2:7]):
+        assert float((x_ - y_).abs().max()) <= 1e-6 * (float(y_.abs().max()) + 1e-12)
+    assert set(on[7]) == set(off[7])
+    top = max(float(v.abs().max()) for v in off[7].values())
+    for k_, v in off[7].items():
+        assert float((on[7][k_] - v).abs().max()) <= 1e-6 * max(float(v.abs().max()), 1e-3 * top), k_

@@ -471,7 +471,7 @@ def pmc_traffic(name):
     """HBM bytes per launch of kernel ``name`` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
     separate runs over this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; aggregated by
     tools/pmc_traffic.py).  Returns (bytes or None, source)."""
-    for fname in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+    for fname in ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             pmc = json.load(open(path))
@@ -489,7 +489,7 @@ def pmc_traffic(name):
 
 def pmc_traffic_lp(name):
     """pmc_traffic for the bf16x3 mode's dominant kernel (the committed --profile-math bf16x3 counter passes)."""
-    for fname in ('r4_pmc_traffic_bf16x3.json', 'r3_pmc_traffic_bf16x3.json'):
+    for fname in ('r5_pmc_traffic_bf16x3.json', 'r4_pmc_traffic_bf16x3.json', 'r3_pmc_traffic_bf16x3.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
             rec = pmc['kernels'].get(name)
@@ -508,7 +508,7 @@ def search_traffic():
     """HBM bytes per search step from the committed rocprofv3 --pmc passes over tools/search_profile.py (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled for gfx950; tools/pmc_traffic.py --all --steps N), with the time of the
     three heaviest kernel families from the committed steady-state table.  Returns (bytes or None, source, families)."""
-    for fname in ('r4_pmc_traffic_search.json', 'r3_pmc_traffic_search.json'):
+    for fname in ('r5_pmc_traffic_search.json', 'r4_pmc_traffic_search.json', 'r3_pmc_traffic_search.json'):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             pmc = json.load(open(path))
@@ -518,6 +518,36 @@ def search_traffic():
         except (OSError, ValueError, KeyError):
             continue
     return None, None, None
+
+
+def search_by_family(limit=14):
+    """Per kernel family of the search step: kernel time per step in a SERIAL trace (rocprofv3 --kernel-trace of the step on one
+    stream: what each family costs on its own, not what overlaps), HBM bytes per step from the counter passes, and the rate the
+    two give -- so that the family furthest from the HBM roof is readable from the bench line.  From the committed tables of the
+    same round (profiles/r<k>_search_steady.txt, r<k>_pmc_traffic_search.json); not measured in this run."""
+    import re
+    for tag in ('r5', 'r4'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic_search.json' % tag)))
+            rows = {}
+            for line in open(os.path.join(ROOT, 'profiles', '%s_search_steady.txt' % tag)):
+                m = re.match(r'\s*family (\S+)\s+([0-9.]+) launches/step\s+([0-9.]+) ms/step', line)
+                if m:
+                    rows[m.group(1)] = (float(m.group(2)), float(m.group(3)))
+            out = []
+            for name, (launches, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:limit]:
+                fam = pmc.get('families', {}).get(name)
+                gb = fam['hbm_bytes_per_step'] / 1e9 if fam else None
+                out.append({'family': name, 'launches_per_step': launches, 'serial_ms_per_step': round(ms, 3),
+                            'hbm_gb_per_step': round(gb, 3) if gb is not None else None,
+                            'tb_per_s': round(gb / ms, 2) if gb is not None and ms > 0 else None,
+                            'frac_of_hbm_peak': round(gb / ms / (HBM_PEAK_GBS / 1e3), 3) if gb is not None and ms > 0 else None})
+            if out:
+                return {'families': out, 'source': 'profiles/%s_search_steady.txt (serial kernel time per step) and profiles/%s_pmc_traffic_search.json '
+                                                   '(FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes); not measured in this run' % (tag, tag)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def main():
@@ -796,6 +826,7 @@ def bench_search(dev, steps, rank, world, use_graph=True, gate=False):
                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                         'traffic_gbs_at_this_step_time': round(traffic / dt / 1e9, 1) if traffic else None,
                         'top_families_by_traffic': top_families,
+                        'by_family': search_by_family(),
                         'algorithmic_gb_per_step': round(gbytes, 2),
                         'convention': '4 img x 5.690 GB (weight pass, fwd+bwd) + 4 img x 2/3 x 5.690 GB (architecture pass: '
                                       'weights frozen, forward + data gradients only); whole step, not one kernel -- the step is '

@@ -52,6 +52,13 @@ struct SeGradTable {            // per-term gradient destinations (each its own 
     int dmix_accumulate;        // d mix is added to what the buffer holds (shared mixing weights of the cells of one kind)
 };
 
+// (1 - momentum) * old + momentum * now, the same bits from every kernel below: in fp32 the compiler is free to contract the two
+// products and the sum into one FMA or another, differently from kernel to kernel; in fp64 both products of two floats are exact,
+// so the sum is rounded once whichever way it is contracted, and once more to fp32
+__device__ __forceinline__ float blend_stat(float momentum, float old, float now) {
+    return (float)((double)(1.f - momentum) * (double)old + (double)momentum * (double)now);
+}
+
 // ------------------------------------------------------------------------------------------ forward prepare
 // grid = nterms blocks of 256 threads; c <= 256.  thread = (image row, channel): 256/c images are handled
 // side by side, every global operand is requested before the first dependent instruction, and everything
@@ -107,15 +114,15 @@ __global__ __launch_bounds__(256) void node_prepare_fwd_kernel(NodeDesc d, float
             invstd = (float)(1.0 / sqrt(var + (double)d.eps));
             if (d.rmean[t] != nullptr) {
                 const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
-                d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
-                d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
+                d.rmean[t][ch] = blend_stat(d.momentum, rm, mean);
+                d.rvar[t][ch] = blend_stat(d.momentum, rv, (float)unbiased);
             }
         } else {
             mean = rm;
             invstd = 1.f / sqrtf(rv + d.eps);
         }
         scale = gam * invstd;
-        shift = bet - mean * scale;
+        shift = fmaf(-mean, scale, bet);              // (explicit: the same bits from every kernel, whatever the compiler would contract)
         float* co = coefs + (size_t)t * 4 * c;
         co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
     }
@@ -347,15 +354,15 @@ __global__ __launch_bounds__(256) void node_fused_fwd_kernel(NodeDesc d, ZTable 
                 invstd = (float)(1.0 / sqrt(var + (double)d.eps));
                 if (writer0 && d.rmean[t] != nullptr) {
                     const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
-                    d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
-                    d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
+                    d.rmean[t][ch] = blend_stat(d.momentum, rm, mean);
+                    d.rvar[t][ch] = blend_stat(d.momentum, rv, (float)unbiased);
                 }
             } else {
                 mean = rm;
                 invstd = 1.f / sqrtf(rv + d.eps);
             }
             scale = gam * invstd;
-            shift = bet - mean * scale;
+            shift = fmaf(-mean, scale, bet);              // (explicit: the same bits from every kernel, whatever the compiler would contract)
             if (writer0) {
                 float* co = coefs + (size_t)t * 4 * c;
                 co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
@@ -424,6 +431,27 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
     float* m_s = sh + TC;
     float* bias = m_s + TC;
     float* a_s = bias + c;
+    // ---- this thread's element (the host launches one thread per element of the image: grid.x * 256 >= hw * c / V) and its
+    // operands, requested before the preparation's own chain of loads: the two overlap instead of following each other
+    const int cv = c / V;
+    const long per_img = d.hw * cv, ei = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = ei < per_img;
+    const int ech = live ? (int)(ei % cv) * V : 0;
+    const size_t pixel = (size_t)n * d.hw + (size_t)(live ? ei / cv : 0);
+    const size_t off = (size_t)n * d.hw * c + (size_t)(live ? ei / cv : 0) * c + ech;
+    float tv[SENAS_MAX_TERMS][V], rsd[V];
+#pragma unroll
+    for (int t = 0; t < SENAS_MAX_TERMS; ++t) {
+        if (live && t < T && z.p[t] != nullptr) ldv<V>(z.p[t] + pixel * z.s[t] + ech, tv[t]);
+        else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) tv[t][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) rsd[j] = 0.f;
+    if (live && residual != nullptr) ldv<V>(residual + off, rsd);
+    // ---- the preparation: one thread per (term, channel)
     for (int i = threadIdx.x; i < TC; i += 256) {
         const int t = i / c, ch = i - t * c;
         const double* st = d.stats[t];
@@ -451,15 +479,15 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
             invstd = (float)(1.0 / sqrt(var + (double)d.eps));
             if (writer0 && d.rmean[t] != nullptr) {
                 const double unbiased = mm > 1.0 ? var * mm / (mm - 1.0) : var;
-                d.rmean[t][ch] = (1.f - d.momentum) * rm + d.momentum * mean;
-                d.rvar[t][ch] = (1.f - d.momentum) * rv + d.momentum * (float)unbiased;
+                d.rmean[t][ch] = blend_stat(d.momentum, rm, mean);
+                d.rvar[t][ch] = blend_stat(d.momentum, rv, (float)unbiased);
             }
         } else {
             mean = rm;
             invstd = 1.f / sqrtf(rv + d.eps);
         }
         const float scale = gam * invstd;
-        const float shift = bet - mean * scale;
+        const float shift = fmaf(-mean, scale, bet);              // (explicit: the same bits from every kernel, whatever the compiler would contract)
         if (writer0) {
             float* co = coefs + (size_t)t * 4 * c;
             co[ch] = mean; co[c + ch] = invstd; co[2 * c + ch] = scale; co[3 * c + ch] = shift;
@@ -510,7 +538,43 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
         bias[ch] = b;
     }
     __syncthreads();
-    combine_stream<V>(d.hw, c, T, n, z, cf, bias, residual, d.relu, y, mask8, out_stats, y2, y2s, y2pad);
+    // ---- the stream: y = act(bias + residual + sum_t cf[t] * z_t), exactly combine_stream's arithmetic for one element
+    Stats4 ost;
+    stats_init4(ost);
+    if (live) {
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = bias[ech + j];
+        if (residual != nullptr) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += rsd[j];
+        }
+#pragma unroll
+        for (int t = 0; t < SENAS_MAX_TERMS; ++t)
+            if (t < T && z.p[t] != nullptr) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(cf[t * c + ech + j], tv[t][j], acc[j]);
+            }
+        if (V == 4 && mask8 != nullptr) {
+            const unsigned bits = (acc[0] > 0.f ? 1u : 0u) | (acc[1 % V] > 0.f ? 2u : 0u) | (acc[2 % V] > 0.f ? 4u : 0u) |
+                                  (acc[3 % V] > 0.f ? 8u : 0u);
+            mask8[off >> 2] = (uint8_t)bits;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = d.relu ? fmaxf(acc[j], 0.f) : acc[j];
+        if (y != nullptr) stv<V>(y + off, acc);
+        if (y2 != nullptr) {
+            stv<V>(y2 + pixel * y2s + ech, acc);
+            if (y2pad > 0 && ech + V == c) {
+                float zero[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) zero[j] = 0.f;
+                for (int q = 0; q < y2pad; q += V) stv<V>(y2 + pixel * y2s + c + q, zero);
+            }
+        }
+        if constexpr (V == 4) stats_accumulate4(ost, out_stats, true, n, c, ech, acc, true);
+    }
+    if constexpr (V == 4) stats_flush4(ost, out_stats, true, n, c, (int)(threadIdx.x % cv) * V);
 }
 
 static size_t wide_fwd_lds(const NodeDesc& d) {
@@ -1118,7 +1182,7 @@ extern "C" int senas_node_fwd(const senas_node_desc* desc, const float* const* z
         const unsigned gx = node_grid(d.hw * (d.c / V), d.n);
         const char* sw = getenv("SENAS_NODE_WIDE");                        // ("0": the two-launch form, for the bit-identity test)
         const bool wide_on = !(sw && sw[0] == '0');
-        if (wide_on && d.nterms * d.c <= kWideTC && (long)gx * d.n <= 128 && wide_fwd_lds(d) <= 48 * 1024) {
+        if (wide_on && d.nterms * d.c <= kWideTC && (long)gx * d.n <= 128 && (long)gx * 256 >= d.hw * (d.c / V) && wide_fwd_lds(d) <= 48 * 1024) {
             dim3 grid(gx, d.n);
             if (V == 4) hipLaunchKernelGGL((node_wide_fwd_kernel<4>), grid, dim3(256), wide_fwd_lds(d), st, d, zt, residual, y, d.relu ? mask8 : nullptr, coefs, gate, se_m, se_a1, out_stats, y2, y2s, y2pad);
             else hipLaunchKernelGGL((node_wide_fwd_kernel<1>), grid, dim3(256), wide_fwd_lds(d), st, d, zt, residual, y, (uint8_t*)nullptr, coefs, gate, se_m, se_a1, (double*)nullptr, y2, y2s, y2pad);

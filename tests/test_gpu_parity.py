@@ -1930,6 +1930,9 @@ def test_wide_node_is_the_two_launch_node_bit_for_bit(cfg):
     gy = torch.randn(n, c, h, w, generator=g)
     res = []
     keep = os.environ.get('SENAS_NODE_WIDE')
+    # the producer-side statistics once, for both forms (they are accumulated with fp64 atomics: two runs differ in their last bits)
+    stats = [F.chan_stats(z.to(dev()).contiguous(memory_format=torch.channels_last)) if z is not None else None for z in zs]
+    torch.cuda.synchronize()
     try:
         for mode in ('1', '0'):
             os.environ['SENAS_NODE_WIDE'] = mode
@@ -1937,7 +1940,7 @@ def test_wide_node_is_the_two_launch_node_bit_for_bit(cfg):
             dses = [copy.deepcopy(s_).to(dev()) if s_ is not None else None for s_ in ses]
             zd = [z.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) if z is not None else None for z in zs]
             md = mix.to(dev()).requires_grad_(True)
-            out = F.bn_combine([F.Term(zd[t], dbns[t], se=dses[t]) for t in range(T)], mix=md, relu=cfg['relu'])
+            out = F.bn_combine([F.Term(zd[t], dbns[t], se=dses[t], stats=stats[t]) for t in range(T)], mix=md, relu=cfg['relu'])
             out.backward(gy.to(dev()))
             torch.cuda.synchronize()
             res.append((out.detach().clone(), [b.running_mean.clone() for b in dbns], [b.running_var.clone() for b in dbns],

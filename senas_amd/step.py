@@ -28,6 +28,9 @@ from .packing import WeightPacker
 from .parallel import SinkReducer
 
 
+LANES_FOR_WORLD = int(os.environ.get('SENAS_LANES_FOR_WORLD', 3))      # scheduler streams when world_size > 1
+
+
 def _lib_error():
     from ._lib import SenasHipError
     return SenasHipError
@@ -75,7 +78,11 @@ class GraphedForwardBackward(object):
         self.graph = self.graph_tail = None
         self.sched = self.sched_tail = None        # lane schedulers of the captured passes (None: the runtime's own graph replay)
         self.wlane = None                          # the weight-gradient lane of this driver's passes (functional.WLANE), or None
-        self.max_lanes = max_lanes                 # lanes of the scheduler (None: lanesched.MAX_LANES)
+        self.max_lanes = max_lanes                 # streams of the lane scheduler (None: lanesched.MAX_LANES)
+        if reducer.world > 1:
+            # the collective's own stream is busy while the second backward graph runs: with it, three scheduler streams beat four
+            # on both steps (rehearsed with a stand-in kernel stream on one GPU: profiles/r5_rccl_standin.txt)
+            self.max_lanes = min(int(max_lanes or LANES_FOR_WORLD), LANES_FOR_WORLD)
         self.frozen = [p for p in frozen if p.requires_grad]
         self.grid = _macro_grid(model)
         if (self.grid is not None and Lanes.enabled and self.grid._depth > 2 and not getattr(self.grid, '_supervision', False)
@@ -278,8 +285,9 @@ def _graph_nodes(graph):
         return None
 
 
-# chains the lane scheduler covers a pass of the search step with (on 4 hardware queues; 5 and 6 are within the run-to-run spread of
-# +-0.3 ms, 4 and 7 lose 0.7 - 1.0 ms -- profiles/r4_wlane_modes.txt)
+# "critical" policy (round 5): the number of streams the lane scheduler deals a pass's segments to (at most the four hardware queues).
+# "chain" policy (round 4): the chains it covers a pass of the search step with -- 5 and 6 within the run-to-run spread, 4 and 7 lose
+# 0.7 - 1.0 ms (profiles/r4_wlane_modes.txt).
 SEARCH_LANES = int(os.environ.get('SENAS_SEARCH_LANES', 6))
 
 
@@ -314,9 +322,6 @@ class SearchStep(object):
         self.reducer = SinkReducer(self.sink, 0, last, world_size, process_group)
         self.arch_reducer = SinkReducer(self.sink, last, last, world_size, process_group)
         early = SinkReducer(self.sink, 0, 0, world_size, process_group) if (world_size > 1 and last >= 2) else None
-        # SEARCH_LANES (six) scheduler chains on four hardware queues: the supernet's pass has six chains in flight (origin stream,
-        # four columns, weight gradients); five and six are within the run-to-run spread, four lose 0.7 - 1.0 ms
-        # (profiles/r4_lanes_queues.txt, r4_wlane_modes.txt)
         self.fb_arch = GraphedForwardBackward(model, criterion, x, y, self.arch_reducer, use_graph=use_graph, packer=packer,
                                               frozen=weights, count_nodes=count_nodes, max_lanes=SEARCH_LANES)
         # the weight pass does not repack: either the architecture pass just did, or __call__ does it (before alpha_begin)

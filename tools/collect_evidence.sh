@@ -38,6 +38,12 @@ cp $out/stats/*kernel_stats.csv $out/kernel_stats.csv
   echo; echo "# tools/lane_timeline.py search (columns of up cells on lanes, lane scheduler)"; python3 tools/lane_timeline.py search --steady --segments 2>/dev/null | grep -v amdgpu; } > $out/search_by_level.txt
 { echo "# tools/lane_timeline.py train --serial"; python3 tools/lane_timeline.py train --serial --steady 2>/dev/null | grep -v amdgpu;
   echo; echo "# tools/lane_timeline.py train (lanes + lane scheduler)"; python3 tools/lane_timeline.py train --steady --segments 2>/dev/null | grep -v amdgpu; } > $out/train_by_level.txt
+# kernel launches and kernel time per cell of the search step (serial schedule, cut at the stamp kernels), four cells launch by launch
+rocprofv3 --kernel-trace -d $out/cellstrace -o cells --output-format csv -- python3 tools/lane_timeline.py search --serial --order $out/order.json > $out/cells_timeline.log 2>&1
+{ echo "# tools/cell_kernels.py over rocprofv3 --kernel-trace -- python3 tools/lane_timeline.py search --serial --order order.json: launches and kernel time per cell"
+  echo "# (serial schedule: one stream; pass 1 = architecture pass, pass 2 = weight pass, whose weight-gradient launches sit in line here and on their own lane under lanes)"
+  python3 tools/cell_kernels.py $out/cellstrace $out/order.json --ordered down4 up13 up40 head; } > $out/search_cells.txt
+rm -rf $out/cellstrace
 # the bench line last: its `traffic` fields are read from the counter aggregates of THIS run
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 cp $out/pmc_traffic_search.json profiles/${tag}_pmc_traffic_search.json

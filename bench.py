@@ -51,9 +51,9 @@ def parse_args(argv=None):
                     help='N > 1: seconds the parent waits for the ranks before it kills them and exits non-zero')
     ap.add_argument('--pg-timeout', type=float, default=120.0, help='N > 1: torch.distributed rendezvous / collective timeout, seconds')
     ap.add_argument('--lp-steps', type=int, default=None,
-                    help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16; 0 = skip them).  Default: 60 on '
+                    help='timed train steps of each labelled bf16-pipe block (bf16x6 / bf16x3 / bf16 / bf16s; 0 = skip them).  Default: 60 on '
                          'one GPU, 0 on N > 1 -- a scaling run times the fp32 train step and the search step, nothing else')
-    ap.add_argument('--profile-math', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16'],
+    ap.add_argument('--profile-math', default='f32', choices=['f32', 'bf16x6', 'bf16x3', 'bf16', 'bf16s'],
                     help='PROFILING ONLY: run the primary (timed, event-probed) train step in this math mode, so that rocprofv3 sees '
                          'the bf16-pipe kernels in the steady-state window; the JSON line says so and is not a headline')
     ap.add_argument('--cpu-uncapped', action='store_true',
@@ -357,7 +357,7 @@ def lp_accuracy(dev):
     buffers = {k: v.detach().clone() for k, v in net.state_dict().items() if 'running' in k or 'num_batches' in k}
     out = {}
     prev = F.math_name()
-    for mode in ('f32', 'bf16x6', 'bf16x3', 'bf16'):
+    for mode in ('f32', 'bf16x6', 'bf16x3', 'bf16', 'bf16s'):
         F.set_math(mode)
         net.load_state_dict(buffers, strict=False)
         net.zero_grad(set_to_none=True)
@@ -417,7 +417,9 @@ def bench_train_mode(mode, args, dev, rank, world, ref_ms):
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12
         lp_traffic, lp_source = pmc_traffic_lp(name) if mode == 'bf16x3' else (None, None)
         peak = BF16_PEAK_TFLOPS / terms                         # fp32-equivalent FLOP/s the pipe can deliver with `terms` MFMAs per product
-        res = {'math': mode, 'dtype': {'bf16': 'bf16 operands (RNE), f32 accumulate, f32 storage',
+        res = {'math': mode, 'dtype': {'bf16s': 'bf16 operands (RNE), f32 accumulate; the dense convolutions\' OUTPUTS and the gradients that come back for them '
+                                                'STORED as bf16 (cell nodes read / write them as such), every other tensor f32',
+                                       'bf16': 'bf16 operands (RNE), f32 accumulate, f32 storage',
                                        'bf16x3': 'f32 split into 2 bf16 planes, 3 MFMA products, f32 accumulate, f32 storage',
                                        'bf16x6': 'f32 split into 3 bf16 planes, 6 MFMA products, f32 accumulate, f32 storage'}[mode],
                'value': round(args.batch * world * args.lp_steps / elapsed, 3), 'unit': 'images/s', 'ms_per_step': round(ms, 3),
@@ -690,14 +692,14 @@ def main():
         F.set_math('f32')
 
     if args.lp_steps > 0:
-        for mode in ('bf16x6', 'bf16x3', 'bf16'):
+        for mode in ('bf16x6', 'bf16x3', 'bf16', 'bf16s'):
             out['train_step_' + mode] = bench_train_mode(mode, args, dev, rank, world, ms_per_step)
             if rank == 0:
                 log('train step [%s]: %.2f ms/step, %.2f images/s' % (mode, out['train_step_' + mode]['ms_per_step'], out['train_step_' + mode]['value']))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             acc = lp_accuracy(dev)
             out['accuracy_vs_oracle'] = acc
-            for mode in ('bf16x6', 'bf16x3', 'bf16'):
+            for mode in ('bf16x6', 'bf16x3', 'bf16', 'bf16s'):
                 out['train_step_' + mode]['max_error_vs_oracle'] = acc[mode]
 
     if args.search_steps > 0:

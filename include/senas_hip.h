@@ -197,6 +197,21 @@ int senas_conv2d_bwd_weight_pair(const senas_conv_geom* ga, const senas_conv_geo
 int senas_conv2d_bwd_weight_ws_lp(const senas_conv_geom* g, int terms, int64_t* bytes);
 int senas_conv2d_bwd_weight_lp(const senas_conv_geom* g, const float* x, int in_relu, const float* dy, float* dw, void* ws,
                                int terms, senas_sum_item* defer, void* stream);
+/* ---- "bf16s": bf16-STORED convolution outputs and their gradients (math mode 'bf16s', senas_amd/functional.py) -----------------
+ * The bf16-pipe convolutions above in their plain bf16 form (terms = 1) with the tensor they PRODUCE kept in bf16: the forward
+ * pass writes y as bf16 (fp32 accumulators rounded to nearest even; `stats` are taken from the accumulators, before the rounding),
+ * and the gradient that comes back for y is a bf16 tensor too, which the data- and weight-gradient kernels stage by a copy.  x, dx,
+ * w and dw stay fp32.  Pointers named *_bf16 point to 2-byte elements in the same NHWC order.  Serves what senas_conv2d_fwd_lp
+ * serves with terms = 1 (stride-1 "same" 3x3 / 5x5, c_in % 32 == 0, c_out % 32 == 0, maps >= 32 wide); SENAS_EUNSUPPORTED
+ * otherwise.  The cell node reads such a term and writes its gradient through senas_node_fwd / _bwd with a NEGATIVE pixel stride
+ * for that term (|stride| elements of 2 bytes; at most 4 terms, c % 4 == 0).  Same nn.Conv2d call sites as the _lp entry points
+ * (models/senas_model.py:11-16,55-63); the reference has no reduced-precision path (requirements.txt:5, no AMP anywhere).     */
+int senas_conv2d_fwd_bf16s(const senas_conv_geom* g, const float* x, const float* w, void* y_bf16, int in_relu, double* stats,
+                           void* ws, const void* packed_lp, void* stream);
+int senas_conv2d_bwd_data_bf16s(const senas_conv_geom* g, const void* dy_bf16, const float* w, float* dx, int in_relu,
+                                const float* x, void* ws, const void* packed_lp, void* stream);
+int senas_conv2d_bwd_weight_bf16s(const senas_conv_geom* g, const float* x, int in_relu, const void* dy_bf16, float* dw, void* ws,
+                                  senas_sum_item* defer, void* stream);
 
 /* ---- pooling / resampling --------------------------------------------------------------------
  * nn.AvgPool2d(3, stride, 1, count_include_pad=False)  (operations.py:62,150)

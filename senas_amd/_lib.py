@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
-EXPECTED_ABI = 33          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
+EXPECTED_ABI = 34          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
 SKIP_MAX = 8               # SENAS_SKIP_MAX
 MAX_STACK = 4
@@ -88,6 +88,9 @@ _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     'senas_conv2d_ws_bytes': (C.c_int64, [_G]),
     'senas_conv2d_fwd': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_fwd_bf16s': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_bwd_data_bf16s': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'senas_conv2d_bwd_weight_bf16s': (_I, [_G, _P, _I, _P, _P, _P, C.POINTER(SumItem), _P]),
     'senas_conv2d_fwd_planar': (_I, [_G, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     'senas_conv2d_fwd_epilogue': (_I, [_G, _P, _P, _P, _I, C.POINTER(ConvEpilogue), _P, _P, _P]),
     'senas_conv2d_bwd_data': (_I, [_G, _P, _P, _P, _I, _P, _P, _P, _P]),

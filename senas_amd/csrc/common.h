@@ -308,6 +308,10 @@ template <bool TG>
 int launch_bf_gather(const GatherGeom& g, int terms, const float* in, const void* wimg, float* out, int in_relu, const float* mask,
                      double* stats, hipStream_t st);
 void bf_gather_name(const GatherGeom& g, int terms, bool tg, char* buf, int len);
+// "bf16s" (bf16-STORED convolution outputs and their gradients, plain bf16 products): forward x fp32 -> y bf16; data gradient
+// dy bf16 -> dx fp32
+int launch_bf_gather_stored(const GatherGeom& g, bool tg, const void* in, const void* wimg, void* out, int in_relu, const float* mask,
+                            double* stats, hipStream_t st);
 int64_t bf_image_bytes(int A, int B, int taps, int terms);
 void launch_bf_pack(const float* w, void* img, int d0, int d1, int taps, int swap, int terms, hipStream_t st);
 int launch_bf_pack_batched(const void* items_dev, int n, int64_t max_elems, hipStream_t st);
@@ -317,6 +321,8 @@ bool bf_wgrad_ok(const WgradGeom& g, int terms);
 int64_t bf_wgrad_ws_bytes(const WgradGeom& g, int terms);
 int launch_bf_wgrad(const WgradGeom& g, int terms, const float* X, const float* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
                     hipStream_t st);
+int launch_bf_wgrad_stored(const WgradGeom& g, const float* X, const void* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                           hipStream_t st);
 void bf_wgrad_name(const WgradGeom& g, int terms, char* buf, int len);
 
 // conv_stem.hip (stem forward: 1..4 input channels, (tap, channel) on the K axis of the fp32 MFMA)

@@ -1169,6 +1169,59 @@ extern "C" int senas_conv2d_bwd_weight_lp(const senas_conv_geom* g, const float*
     return senas_wgrad_sum_batched(&item, 1, stream);
 }
 
+// ---- "bf16s": the bf16-pipe convolutions with their OUTPUT (forward) and its GRADIENT (data / weight gradient operand) stored as
+// bf16 tensors; x, dx and dw stay fp32, products are plain bf16 x bf16 into fp32 accumulators, statistics from the accumulators
+extern "C" int senas_conv2d_fwd_bf16s(const senas_conv_geom* g, const float* x, const float* w, void* y_bf16, int in_relu, double* stats,
+                                      void* ws, const void* packed_lp, void* stream) {
+    SENAS_REQUIRE(geom_ok(g), "conv2d_fwd_bf16s: inconsistent geometry");
+    SENAS_REQUIRE(x && w && y_bf16, "conv2d_fwd_bf16s: null pointer");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    GatherGeom gg{g->n, g->hi, g->wi, g->ci, g->ho, g->wo, g->co, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!bf_gather_ok(gg, 1)) return SENAS_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const void* img = packed_lp;
+    if (img == nullptr) {
+        SENAS_REQUIRE(ws, "conv2d_fwd_bf16s: null workspace");
+        launch_bf_pack(w, ws, g->co, g->ci, g->kh * g->kw, 1, 1, st);
+        img = ws;
+    }
+    return launch_bf_gather_stored(gg, false, x, img, y_bf16, in_relu, nullptr, stats, st);
+}
+
+extern "C" int senas_conv2d_bwd_data_bf16s(const senas_conv_geom* g, const void* dy_bf16, const float* w, float* dx, int in_relu,
+                                           const float* x, void* ws, const void* packed_lp, void* stream) {
+    SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_data_bf16s: inconsistent geometry");
+    SENAS_REQUIRE(dy_bf16 && w && dx, "conv2d_bwd_data_bf16s: null pointer");
+    SENAS_REQUIRE(!in_relu || x, "conv2d_bwd_data_bf16s: in_relu needs x");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    GatherGeom gg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil};
+    if (!bf_gather_ok(gg, 1)) return SENAS_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const void* img = packed_lp;
+    if (img == nullptr) {
+        SENAS_REQUIRE(ws, "conv2d_bwd_data_bf16s: null workspace");
+        launch_bf_pack(w, ws, g->co, g->ci, g->kh * g->kw, 0, 1, st);
+        img = ws;
+    }
+    return launch_bf_gather_stored(gg, true, dy_bf16, img, dx, 0, in_relu ? x : nullptr, nullptr, st);
+}
+
+extern "C" int senas_conv2d_bwd_weight_bf16s(const senas_conv_geom* g, const float* x, int in_relu, const void* dy_bf16, float* dw, void* ws,
+                                             senas_sum_item* defer, void* stream) {
+    if (defer != nullptr) defer->kind = 0;
+    SENAS_REQUIRE(geom_ok(g), "conv2d_bwd_weight_bf16s: inconsistent geometry");
+    SENAS_REQUIRE(x && dy_bf16 && dw, "conv2d_bwd_weight_bf16s: null pointer");
+    if (g->groups != 1 || g->transposed) return SENAS_EUNSUPPORTED;
+    const WgradGeom wg{g->n, g->ho, g->wo, g->co, g->hi, g->wi, g->ci, g->kh, g->kw, g->stride, g->pad, g->dil, 0};
+    if (!bf_wgrad_ok(wg, 1)) return SENAS_EUNSUPPORTED;
+    SENAS_REQUIRE(ws, "conv2d_bwd_weight_bf16s: null workspace");
+    senas_sum_item item;
+    const int rc = launch_bf_wgrad_stored(wg, x, dy_bf16, reinterpret_cast<float*>(ws), dw, in_relu, &item, as_stream(stream));
+    if (rc != SENAS_OK) return rc;
+    if (defer != nullptr) { *defer = item; return SENAS_OK; }
+    return senas_wgrad_sum_batched(&item, 1, stream);
+}
+
 extern "C" const char* senas_conv2d_kernel_name_lp(const senas_conv_geom* g, int which, int terms) {
     if (!geom_ok(g) || which < 0 || which > 2 || !lp_terms_ok(terms) || g->groups != 1 || g->transposed) return "";
     if (which == 2) {

@@ -100,8 +100,12 @@ constexpr int bf_pieces(int mt, int ns, int ksz) {
     return ((4 * mt + 2 * halo) * (32 + 2 * halo) + xl - 1) / xl;
 }
 
-template <bool TG, int MT, int NS, int KSZ>
+// IB: the input tensor is bf16 in HBM (a stored gradient of a bf16-stored convolution output: the data gradient's operand) -- its
+// staging is a copy; OB: the output tensor is written as bf16 (fp32 accumulators rounded to nearest even on the way out; the
+// producer-side statistics are taken from the accumulators, before the rounding).  NS = 1 only ("bf16s": section 4c of DESIGN.md).
+template <bool TG, int MT, int NS, int KSZ, bool IB = false, bool OB = false>
 __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
+    static_assert(!(IB || OB) || NS == 1, "bf16-stored operands go with the plain bf16 products");
     constexpr int CP = NS == 1 ? 32 : 16;           // channels per pass
     constexpr int Q = CP / 4;                       // float4 pieces per pixel and pass
     constexpr int XL = 256 / Q;                     // window pixels per staging sweep of the 4 producer waves
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
         auto issue = [&](int j, float4 (&pf)[PF], unsigned& ok) {
             int n, cot, oy0, ox0;
             decode(t0 + j / npass, n, cot, oy0, ox0);
-            const float* src = a.in + (size_t)n * g.hin * g.win * g.cin + (j % npass) * CP + sq * 4;
+            const size_t base = (size_t)n * g.hin * g.win * g.cin + (j % npass) * CP + sq * 4;
+            const float* src = a.in + base;
+            const unsigned short* srch = reinterpret_cast<const unsigned short*>(a.in) + base;      // (IB: the same element offsets, 2-byte elements)
             const int by = oy0 - halo, bx = ox0 - halo;
             ok = 0;                                     // bit k: piece k of the item lies inside the image
 #pragma unroll
@@ -188,7 +194,12 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
                 const bool inb = pos[k] >= 0 && (unsigned)iy < (unsigned)g.hin && (unsigned)ix < (unsigned)g.win;
                 ok |= inb ? (1u << k) : 0u;
                 const int off = (iy * rowc + ix * g.cin) & -(int)inb;          // (arithmetic, not a select: no branch)
-                pf[k] = *reinterpret_cast<const float4*>(src + off);
+                if constexpr (IB) {
+                    const uint2 raw = *reinterpret_cast<const uint2*>(srch + off);      // four bf16: the plane itself
+                    pf[k] = make_float4(__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y), 0.f, 0.f);
+                } else {
+                    pf[k] = *reinterpret_cast<const float4*>(src + off);
+                }
             }
         };
         auto commit = [&](int j, const float4 (&pf)[PF], unsigned ok) {
@@ -197,6 +208,11 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
             for (int k = 0; k < PF; ++k) {
                 float4 v = pf[k];
                 const bool inb = (ok >> k) & 1u;
+                if constexpr (IB) {                     // already bf16 (no ReLU on load on this path: the launcher checks): a copy
+                    const uint2 raw = make_uint2(inb ? __builtin_bit_cast(unsigned, v.x) : 0u, inb ? __builtin_bit_cast(unsigned, v.y) : 0u);
+                    *reinterpret_cast<uint2*>(buf + k * (XL * P16 * 16)) = raw;
+                    continue;
+                }
                 v.x = inb ? fmaxf(v.x, lo_clamp) : 0.f; v.y = inb ? fmaxf(v.y, lo_clamp) : 0.f;
                 v.z = inb ? fmaxf(v.z, lo_clamp) : 0.f; v.w = inb ? fmaxf(v.w, lo_clamp) : 0.f;
                 uint2 pl[NS];
@@ -374,8 +390,14 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
                         for (int v = 0; v < 16; ++v)
                             if (!(mk[v] > 0.f)) acc[m][v] = 0.f;
                     }
+                    if constexpr (OB) {
+                        __bf16* __restrict__ outh = reinterpret_cast<__bf16*>(a.out);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) outp[row + (size_t)acc_row(v, h) * g.cout] = acc[m][v];
+                        for (int v = 0; v < 16; ++v) outh[row + (size_t)acc_row(v, h) * g.cout] = (__bf16)acc[m][v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) outp[row + (size_t)acc_row(v, h) * g.cout] = acc[m][v];
+                    }
                     if (a.stats != nullptr) {               // 16 values in fp32, then into the fp64 running sums
                         float s16 = 0.f, q16 = 0.f;
 #pragma unroll
@@ -392,7 +414,8 @@ __global__ __launch_bounds__(512) void conv_bf_kernel(BfArgs a) {
                             const size_t o = row + (size_t)acc_row(v, h) * g.cout;
                             if (maskp != nullptr && !(maskp[o] > 0.f)) val = 0.f;
                             if (a.stats != nullptr) { s_sum += val; q_sum += (double)val * val; }
-                            outp[o] = val;
+                            if constexpr (OB) reinterpret_cast<__bf16*>(a.out)[o] = (__bf16)val;
+                            else outp[o] = val;
                         }
                     }
                 }
@@ -421,7 +444,7 @@ static int bf_mt(const GatherGeom& g, int terms) {
     return tiles8 >= 512 ? 2 : 1;            // (measured: 8-row tiles from two tiles per CU on, tools/bf_probe2.py)
 }
 
-template <bool TG, int MT, int NS, int KSZ>
+template <bool TG, int MT, int NS, int KSZ, bool IB = false, bool OB = false>
 static int launch_bf(const GatherGeom& g, const float* in, const void* wimg, float* out, int in_relu, const float* mask, double* stats,
                      hipStream_t st) {
     constexpr int TH = 4 * MT, P16 = NS == 3 ? 7 : 5;
@@ -442,11 +465,30 @@ static int launch_bf(const GatherGeom& g, const float* in, const void* wimg, flo
     const size_t bytes = 2 * wbytes;
     if (bytes > 160 * 1024) { set_error_msg("conv_bf: window does not fit in LDS"); return SENAS_EUNSUPPORTED; }
     if (bytes > 64 * 1024)
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&conv_bf_kernel<TG, MT, NS, KSZ>), 160 * 1024,
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&conv_bf_kernel<TG, MT, NS, KSZ, IB, OB>), 160 * 1024,
                                      "conv_bf: raising the dynamic LDS limit")) return rc;
     int blocks = a.ntiles < 256 ? a.ntiles : 256;
-    hipLaunchKernelGGL((conv_bf_kernel<TG, MT, NS, KSZ>), dim3(blocks), dim3(512), bytes, st, a);
+    hipLaunchKernelGGL((conv_bf_kernel<TG, MT, NS, KSZ, IB, OB>), dim3(blocks), dim3(512), bytes, st, a);
     return launch_status("conv_bf");
+}
+
+// "bf16s": the forward pass writes a bf16 tensor (OB), the data gradient reads a bf16 gradient tensor (IB); plain bf16 products
+int launch_bf_gather_stored(const GatherGeom& g, bool tg, const void* in, const void* wimg, void* out, int in_relu, const float* mask,
+                            double* stats, hipStream_t st) {
+    const int mt = bf_mt(g, 1);
+    const float* inf = reinterpret_cast<const float*>(in);
+    float* outf = reinterpret_cast<float*>(out);
+    if (tg) {
+        if (in_relu) { set_error_msg("conv_bf (bf16-stored gradient): no ReLU on load on this path"); return SENAS_EINVAL; }
+        if (mt == 2) { if (g.kh == 3) return launch_bf<true, 2, 1, 3, true, false>(g, inf, wimg, outf, 0, mask, stats, st);
+                       return launch_bf<true, 2, 1, 5, true, false>(g, inf, wimg, outf, 0, mask, stats, st); }
+        if (g.kh == 3) return launch_bf<true, 1, 1, 3, true, false>(g, inf, wimg, outf, 0, mask, stats, st);
+        return launch_bf<true, 1, 1, 5, true, false>(g, inf, wimg, outf, 0, mask, stats, st);
+    }
+    if (mt == 2) { if (g.kh == 3) return launch_bf<false, 2, 1, 3, false, true>(g, inf, wimg, outf, in_relu, mask, stats, st);
+                   return launch_bf<false, 2, 1, 5, false, true>(g, inf, wimg, outf, in_relu, mask, stats, st); }
+    if (g.kh == 3) return launch_bf<false, 1, 1, 3, false, true>(g, inf, wimg, outf, in_relu, mask, stats, st);
+    return launch_bf<false, 1, 1, 5, false, true>(g, inf, wimg, outf, in_relu, mask, stats, st);
 }
 
 template <bool TG>

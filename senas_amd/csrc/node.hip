@@ -38,12 +38,37 @@ struct NodeDesc {                // device-visible copy of senas_node_desc
 
 struct ZTable {
     const float* p[SENAS_MAX_TERMS];
-    int s[SENAS_MAX_TERMS];         // pixel stride of z_t in floats (c when dense; wider: a channel slice of a stacked tensor)
+    int s[SENAS_MAX_TERMS];         // pixel stride of z_t in ELEMENTS (c when dense; wider: a channel slice of a stacked tensor)
+    int bf[SENAS_MAX_TERMS];        // 1: z_t is a bf16 tensor (a bf16-stored convolution output, "bf16s"); few-term vector kernels only
 };
 struct DzTable {
     float* p[SENAS_MAX_TERMS];
-    int s[SENAS_MAX_TERMS];       // pixel stride of dz_t in floats (c when dense; wider: a channel slice of a stacked tensor)
+    int s[SENAS_MAX_TERMS];       // pixel stride of dz_t in elements (c when dense; wider: a channel slice of a stacked tensor)
+    int bf[SENAS_MAX_TERMS];      // 1: dz_t is written as bf16 (the gradient of a bf16-stored tensor)
 };
+
+// four channels of a term that is fp32 or bf16 in memory (element offset `off`)
+__device__ __forceinline__ void ldz4(const float* base, size_t off, int bf, float (&v)[4]) {
+    if (bf) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+        v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    } else {
+        ldv<4>(base + off, v);
+    }
+}
+__device__ __forceinline__ void stz4(float* base, size_t off, int bf, const float (&v)[4]) {
+    if (bf) {
+        typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const f2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+        const uint2 r = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf2_t)),
+                                   __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf2_t)));      // round to nearest even
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = r;
+    } else {
+        stv<4>(base + off, v);
+    }
+}
 struct SeGradTable {            // per-term gradient destinations (each its own tensor on the host side)
     float* w1[SENAS_MAX_TERMS];
     float* w2[SENAS_MAX_TERMS];
@@ -235,7 +260,8 @@ __device__ __forceinline__ void combine_stream(long hw, int c, int nterms, int n
         } else {
             for (int t = 0; t < nterms; ++t) {
                 if (z.p[t] == nullptr) continue;
-                ldv<V>(z.p[t] + pixel * z.s[t] + ch, tmp);
+                if constexpr (V == 4) ldz4(z.p[t], pixel * z.s[t] + ch, z.bf[t], tmp);
+                else ldv<V>(z.p[t] + pixel * z.s[t] + ch, tmp);
 #pragma unroll
                 for (int j = 0; j < V; ++j) acc[j] = fmaf(lds[t * c + ch + j], tmp[j], acc[j]);
             }
@@ -680,8 +706,11 @@ __global__ __launch_bounds__(256) void node_reduce_vec_kernel(long hw, int c, lo
             }
 #pragma unroll
             for (int t = 0; t < TT; ++t)
-                if (t < tt && z.p[t0 + t] != nullptr)
-                    zv[t][u] = reinterpret_cast<const float4*>(z.p[t0 + t])[(img + (ok ? pp : q0)) * (size_t)(z.s[t0 + t] >> 2) + q];
+                if (t < tt && z.p[t0 + t] != nullptr) {
+                    float zt4[4];
+                    ldz4(z.p[t0 + t], ((img + (ok ? pp : q0)) * (size_t)(z.s[t0 + t] >> 2) + q) * 4, z.bf[t0 + t], zt4);
+                    zv[t][u] = make_float4(zt4[0], zt4[1], zt4[2], zt4[3]);
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1060,13 +1089,15 @@ __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, 
             float* out = dz.p[t];
             if (out == nullptr) continue;
             const int ko = t * kt + kbase + ch;
-            ldv<V>(z.p[t] + ((size_t)n * hw + (size_t)(i / cv)) * z.s[t] + ch, zv);
+            if constexpr (V == 4) ldz4(z.p[t], ((size_t)n * hw + (size_t)(i / cv)) * z.s[t] + ch, z.bf[t], zv);
+            else ldv<V>(z.p[t] + ((size_t)n * hw + (size_t)(i / cv)) * z.s[t] + ch, zv);
             ldv<V>(A + ko, av);
             ldv<V>(B + ko, bv);
             ldv<V>(K + ko, kv);
 #pragma unroll
             for (int j = 0; j < V; ++j) zv[j] = fmaf(av[j], ds[j], fmaf(bv[j], zv[j], kv[j]));
-            stv<V>(out + ((size_t)n * hw + (size_t)(i / cv)) * dz.s[t] + ch, zv);
+            if constexpr (V == 4) stz4(out, ((size_t)n * hw + (size_t)(i / cv)) * dz.s[t] + ch, dz.bf[t], zv);
+            else stv<V>(out + ((size_t)n * hw + (size_t)(i / cv)) * dz.s[t] + ch, zv);
         }
     }
 }
@@ -1126,12 +1157,15 @@ using namespace senas;
 
 // z pixel strides: dense (c) unless given; a strided term must keep 16-byte alignment for the vector kernels
 static bool fill_ztable(const NodeDesc& d, const float* const* z, const int32_t* z_pixel_stride, ZTable& zt) {
-    for (int t = 0; t < SENAS_MAX_TERMS; ++t) { zt.p[t] = nullptr; zt.s[t] = d.c; }
+    for (int t = 0; t < SENAS_MAX_TERMS; ++t) { zt.p[t] = nullptr; zt.s[t] = d.c; zt.bf[t] = 0; }
     for (int t = 0; t < d.nterms; ++t) {
         zt.p[t] = z[t];
-        zt.s[t] = (z_pixel_stride != nullptr && z_pixel_stride[t] > 0) ? z_pixel_stride[t] : d.c;
+        const int st = z_pixel_stride != nullptr ? z_pixel_stride[t] : 0;
+        zt.bf[t] = st < 0;                                   // a NEGATIVE pixel stride: the term is a bf16 tensor of that stride (in elements)
+        zt.s[t] = st != 0 ? (st < 0 ? -st : st) : d.c;
         if (zt.s[t] < d.c) return false;
-        if (zt.s[t] != d.c && d.c % 4 == 0 && (zt.s[t] % 4 != 0 || (reinterpret_cast<uintptr_t>(z[t]) & 15) != 0)) return false;
+        if (zt.bf[t] && (d.c % 4 != 0 || zt.s[t] % 4 != 0 || (reinterpret_cast<uintptr_t>(z[t]) & 7) != 0 || d.nterms > kFuseTerms)) return false;
+        if (!zt.bf[t] && zt.s[t] != d.c && d.c % 4 == 0 && (zt.s[t] % 4 != 0 || (reinterpret_cast<uintptr_t>(z[t]) & 15) != 0)) return false;
         if (d.sstride[t] < 2 * d.c) return false;
     }
     return true;
@@ -1223,9 +1257,13 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     bool any_se = false, any_dz = false;
     for (int t = 0; t < d.nterms; ++t) {
         dzt.p[t] = dz[t];
-        dzt.s[t] = (dz_pixel_stride != nullptr && dz_pixel_stride[t] > 0) ? dz_pixel_stride[t] : d.c;
-        SENAS_REQUIRE(dzt.s[t] >= d.c && (d.c % 4 != 0 || dzt.s[t] == d.c ||
-                                          (dzt.s[t] % 4 == 0 && (reinterpret_cast<uintptr_t>(dz[t]) & 15) == 0)),
+        const int dst = dz_pixel_stride != nullptr ? dz_pixel_stride[t] : 0;
+        dzt.bf[t] = dst < 0;                                 // a NEGATIVE stride: dz_t is written as bf16
+        dzt.s[t] = dst != 0 ? (dst < 0 ? -dst : dst) : d.c;
+        SENAS_REQUIRE(!dzt.bf[t] || (d.c % 4 == 0 && dzt.s[t] % 4 == 0 && (reinterpret_cast<uintptr_t>(dz[t]) & 7) == 0 && d.nterms <= kFuseTerms),
+                      "node_bwd: a bf16 dz needs c % 4 == 0, 8-byte alignment and at most 4 terms");
+        SENAS_REQUIRE(dzt.bf[t] || (dzt.s[t] >= d.c && (d.c % 4 != 0 || dzt.s[t] == d.c ||
+                                          (dzt.s[t] % 4 == 0 && (reinterpret_cast<uintptr_t>(dz[t]) & 15) == 0))),
                       "node_bwd: a strided dz must keep 16-byte alignment");
         SENAS_REQUIRE(dgamma[t] && dbeta[t], "node_bwd: null batch-norm gradient destination");
         seg.dgamma[t] = dgamma[t];

@@ -65,9 +65,11 @@ template <> struct WProd<3> { static constexpr int N = 6; static constexpr int a
 }  // namespace
 
 // dynamic LDS: X planes [a tile][plane][window pixel][32 ch] bf16, then G planes [plane][tile pixel][32 ch] bf16
-template <int A, int Q, int REM, int PFX, int NS>
+// GB: the gradient operand G is a bf16 tensor in HBM (the stored gradient of a bf16-stored convolution output): staged by a copy
+template <int A, int Q, int REM, int PFX, int NS, bool GB = false>
 __global__ __launch_bounds__(512) void wgrad_bf_kernel(WgradGeom g, const float* __restrict__ X, const float* __restrict__ G,
                                                        float* __restrict__ part, int x_relu, int th, int tiles_x, int tiles_y) {
+    static_assert(!GB || NS == 1, "a bf16-stored gradient goes with the plain bf16 products");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int UW = Q + REM;
     constexpr int PP = A / 4;                    // 16-byte fp32 pieces per pixel of X
@@ -126,13 +128,21 @@ __global__ __launch_bounds__(512) void wgrad_bf_kernel(WgradGeom g, const float*
             ty += dty; tx += dtx;
             if (tx >= tile_w) { tx -= tile_w; ++ty; }
         }
-        const float* gsrc = G + (size_t)n * g.hg * g.wg * 32 + gq * 4;
+        const size_t gbase = (size_t)n * g.hg * g.wg * 32 + gq * 4;
+        const float* gsrc = G + gbase;
+        const unsigned short* gsrch = reinterpret_cast<const unsigned short*>(G) + gbase;       // (GB: the same element offsets, 2-byte elements)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int pix = k * 64 + gpl;
             const int gy = oy0 + (pix >> 5), gx = ox0 + (pix & 31);
             const bool inb = pix < gpix && gy < g.hg && gx < g.wg;
-            pg[k] = *reinterpret_cast<const float4*>(gsrc + (inb ? ((size_t)gy * g.wg + gx) * 32 : 0));
+            const size_t o = inb ? ((size_t)gy * g.wg + gx) * 32 : 0;
+            if constexpr (GB) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(gsrch + o);
+                pg[k] = make_float4(__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y), 0.f, 0.f);
+            } else {
+                pg[k] = *reinterpret_cast<const float4*>(gsrc + o);
+            }
         }
     };
     auto put_x = [&](int slot_pix, float4 v) {
@@ -184,7 +194,8 @@ __global__ __launch_bounds__(512) void wgrad_bf_kernel(WgradGeom g, const float*
                 uint2 pl[NS];
                 float4 v = pg[k];
                 if (!(gy < g.hg && gx < g.wg)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                split4<NS>(v, pl);
+                if constexpr (GB) pl[0] = make_uint2(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y));
+                else split4<NS>(v, pl);
 #pragma unroll
                 for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(gs + (size_t)p * gplane + (size_t)pix * 64 + gq * 8) = pl[p];
             }
@@ -340,17 +351,17 @@ int64_t bf_wgrad_ws_bytes(const WgradGeom& g, int terms) {
     return (int64_t)wgrad_bf_blocks(g, ns) * g.kh * g.kw * (g.A / 32) * 1024 * sizeof(float);
 }
 
-template <int A, int Q, int REM, int PFX, int NS>
+template <int A, int Q, int REM, int PFX, int NS, bool GB = false>
 static int launch_wbf(const WgradGeom& g, const float* X, const float* G, float* part, int x_relu, hipStream_t st) {
     const int th = wgrad_bf_rows(g, NS);
     size_t bytes = wgrad_bf_bytes(g, th, NS);
     const size_t fold = (size_t)4 * REM * 4096;
     if (fold > bytes) bytes = fold;
     if (bytes > 64 * 1024)
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&wgrad_bf_kernel<A, Q, REM, PFX, NS>), 160 * 1024,
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(&wgrad_bf_kernel<A, Q, REM, PFX, NS, GB>), 160 * 1024,
                                      "wgrad_bf: raising the dynamic LDS limit")) return rc;
     const int tiles_x = (g.wg + 31) / 32, tiles_y = (g.hg + th - 1) / th;
-    hipLaunchKernelGGL((wgrad_bf_kernel<A, Q, REM, PFX, NS>), dim3(wgrad_bf_blocks(g, NS)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
+    hipLaunchKernelGGL((wgrad_bf_kernel<A, Q, REM, PFX, NS, GB>), dim3(wgrad_bf_blocks(g, NS)), dim3(512), bytes, st, g, X, G, part, x_relu, th,
                        tiles_x, tiles_y);
     return launch_status("wgrad_bf");
 }
@@ -381,6 +392,26 @@ int launch_bf_wgrad(const WgradGeom& g, int terms, const float* X, const float* 
     if (!found) { set_error_msg("wgrad_bf: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
     if (rc != SENAS_OK) return rc;
     *defer = senas_sum_item{part, dw, 2, g.A, g.B, g.kh * g.kw, 0, wgrad_bf_blocks(g, ns)};
+    return SENAS_OK;
+}
+
+// "bf16s": the same with G a bf16 tensor (plain bf16 products); X stays fp32
+int launch_bf_wgrad_stored(const WgradGeom& g, const float* X, const void* G, float* part, float* dw, int x_relu, senas_sum_item* defer,
+                           hipStream_t st) {
+    const int units = g.kh * g.kw * (g.A / 32);
+    const float* Gf = reinterpret_cast<const float*>(G);
+    int rc = SENAS_EINVAL;
+    bool found = false;
+#define SENAS_CASE(A_, Q_, REM_, PF_)                                                                      \
+    if (!found && g.A == A_ && units == 8 * Q_ + REM_) {                                                   \
+        found = true;                                                                                      \
+        rc = launch_wbf<A_, Q_, REM_, PF_, 1, true>(g, X, Gf, part, x_relu, st);                           \
+    }
+    SENAS_WGRAD_BF_SHAPES(SENAS_CASE)
+#undef SENAS_CASE
+    if (!found) { set_error_msg("wgrad_bf: no kernel for this (channels, taps) pair"); return SENAS_EINVAL; }
+    if (rc != SENAS_OK) return rc;
+    *defer = senas_sum_item{part, dw, 2, g.A, g.B, g.kh * g.kw, 0, wgrad_bf_blocks(g, 1)};
     return SENAS_OK;
 }
 

@@ -40,9 +40,25 @@ def nhwc(t):
     return t.contiguous(memory_format=CL)
 
 
+def nhwc_stored(t):
+    """nhwc() for a tensor that may be a bf16-STORED convolution output or its gradient (math mode 'bf16s'): float32 or
+    bfloat16, CUDA, dense NHWC."""
+    if t.dtype != torch.bfloat16:
+        return nhwc(t)
+    if not t.is_cuda:
+        raise SenasHipError('senas_amd runs on the GPU only (got a %s tensor); there is no CPU fallback' % t.device)
+    if t.dim() != 4:
+        raise SenasHipError('expected a 4-d NCHW tensor, got shape %s' % (tuple(t.shape),))
+    return t.contiguous(memory_format=CL)
+
+
 def nhwc_slice(t):
-    """(tensor, pixel stride in floats) for a kernel that can read a channel slice of a wider NHWC tensor in place: the
-    slice itself when its layout is [n][h][w][wider c] with 16-byte alignment, else a dense NHWC copy."""
+    """(tensor, pixel stride in elements) for a kernel that can read a channel slice of a wider NHWC tensor in place: the
+    slice itself when its layout is [n][h][w][wider c] with 16-byte alignment, else a dense NHWC copy.  A bf16 tensor (a
+    bf16-stored convolution output, math mode 'bf16s') comes back dense with a NEGATIVE stride: the node kernels' convention."""
+    if t.dtype == torch.bfloat16:
+        t = nhwc_stored(t)
+        return t, -t.shape[1]
     _dev(t)
     if t.dim() == 4:
         n, c, h, w = t.shape
@@ -186,22 +202,30 @@ def _packed(w, direction):
 # fp32 FMA chains, the default), else the number of bf16 products per fp32 product: 1 "bf16" (operands rounded to bf16),
 # 3 "bf16x3", 6 "bf16x6" (operands split into 2 / 3 bf16 planes; fp32 accumulation throughout).  Tensors in HBM stay fp32.
 MATH_TERMS = 0
-MATH_NAMES = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}
+MATH_NAMES = {'f32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6, 'bf16s': 1}
+# 'bf16s': plain bf16 products (as 'bf16') AND the outputs of those convolutions -- and the gradients that come back for them --
+# STORED as bf16 tensors: the convolution writes bf16 (statistics from its fp32 accumulators), the cell node reads bf16 terms and
+# writes bf16 term gradients, the data- and weight-gradient kernels stage that gradient by a copy.  States / node outputs, their
+# gradients, weights and weight gradients stay fp32.
+MATH_STORED = False
 
 
 def set_math(name):
-    """Select the arithmetic of the dense convolutions: 'f32' | 'bf16x6' | 'bf16x3' | 'bf16'.  Returns the previous name.
-    Step drivers / packers built before the call keep the images of the mode they were built in: set it first."""
-    global MATH_TERMS
+    """Select the arithmetic of the dense convolutions: 'f32' | 'bf16x6' | 'bf16x3' | 'bf16' | 'bf16s'.  Returns the previous
+    name.  Step drivers / packers built before the call keep the images of the mode they were built in: set it first."""
+    global MATH_TERMS, MATH_STORED
     if name not in MATH_NAMES:
         raise SenasHipError('unknown math mode %r (one of %s)' % (name, sorted(MATH_NAMES)))
     prev = math_name()
     MATH_TERMS = MATH_NAMES[name]
+    MATH_STORED = name == 'bf16s'
     return prev
 
 
 def math_name():
-    return next(k for k, v in MATH_NAMES.items() if v == MATH_TERMS)
+    if MATH_STORED:
+        return 'bf16s'
+    return next(k for k, v in MATH_NAMES.items() if v == MATH_TERMS and k != 'bf16s')
 
 
 def _packed_lp(w, direction):
@@ -410,6 +434,18 @@ def _conv_wgrad(g, x, in_relu, dy, w, dest=None):
     L = _lib.lib()
     dwt, dw = wgrad_dest(w) if dest is None else dest
     nbytes, zero = C.c_int64(), C.c_int32()
+    if dy.dtype == torch.bfloat16:                  # 'bf16s': the bf16-pipe form with the gradient operand staged by a copy
+        _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), 1, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
+        if not nbytes.value:
+            raise SenasHipError('conv2d: a bf16-stored gradient for a geometry the bf16-pipe weight-gradient kernel does not serve')
+        wsw = torch.empty(nbytes.value, device=x.device, dtype=torch.uint8)
+        with _span('conv_wgrad', g, x, w, dy):
+            item = _lib.SumItem() if may_defer(dw) else None
+            _lib.check(L.senas_conv2d_bwd_weight_bf16s(C.byref(g), x.data_ptr(), in_relu, dy.data_ptr(), dwt.data_ptr(), wsw.data_ptr(),
+                                                       C.byref(item) if item is not None else None, _stream()), 'senas_conv2d_bwd_weight_bf16s')
+            if item is not None and item.kind:
+                DEFER.append((item, wsw))
+        return dw
     if MATH_TERMS:                                  # the bf16-pipe form, where the geometry has one
         _lib.check(L.senas_conv2d_bwd_weight_ws_lp(C.byref(g), MATH_TERMS, C.byref(nbytes)), 'senas_conv2d_bwd_weight_ws_lp')
     if MATH_TERMS and nbytes.value:
@@ -509,6 +545,17 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(rc, 'senas_conv2d_fwd_planar')
                 y = y5
                 PLANAR_LAUNCHES[0] += 1
+        if y is None and MATH_STORED and not stacked:
+            # 'bf16s': the output as a bf16 tensor where the bf16-pipe kernel serves the shape (declined -> the launches below)
+            yh = torch.empty((n, co, ho, wo), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+            with _span('conv_fwd', g, x, w, yh):
+                rc = L.senas_conv2d_fwd_bf16s(C.byref(g), x.data_ptr(), w.data_ptr(), yh.data_ptr(), int(in_relu), _p(stats), ws.data_ptr(),
+                                              _packed_lp(w, 0), _stream())
+            if rc == _lib.UNSUPPORTED:
+                _unspan()
+            else:
+                _lib.check(rc, 'senas_conv2d_fwd_bf16s')
+                y = yh
         if y is None:
             y4 = new_nhwc(n, co, ho, wo, x)
             with _span('conv_fwd', g, x, w, y4):
@@ -534,7 +581,8 @@ class _Conv2d(torch.autograd.Function):
         g, L = ctx.g, _lib.lib()
         if dy is None:
             return (None,) * 11
-        dy = nhwc(stacked_4d(dy) if dy.dim() == 5 else dy)
+        dy = nhwc_stored(stacked_4d(dy) if dy.dim() == 5 else dy)
+        stored = dy.dtype == torch.bfloat16              # ('bf16s': the gradient of a bf16-stored output arrives as bf16)
         dx = dw = None
         if ctx.needs_input_grad[1]:                       # (queued for the weight-gradient lane where there is one)
             dest = wgrad_dest(w)
@@ -546,7 +594,11 @@ class _Conv2d(torch.autograd.Function):
             ws = torch.empty(int(L.senas_conv2d_ws_bytes(C.byref(g))), device=x.device, dtype=torch.uint8)
             with _span('conv_dgrad', g, x, w, dy):
                 rc = _lib.UNSUPPORTED
-                if MATH_TERMS:
+                if stored:
+                    rc = L.senas_conv2d_bwd_data_bf16s(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu, x.data_ptr(),
+                                                       ws.data_ptr(), _packed(w, (1, 1)), _stream())
+                    _lib.check(rc, 'senas_conv2d_bwd_data_bf16s')       # (what wrote a bf16 output serves its gradient: no fallback)
+                elif MATH_TERMS:
                     rc = L.senas_conv2d_bwd_data_lp(C.byref(g), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctx.in_relu,
                                                     x.data_ptr(), ws.data_ptr(), _packed_lp(w, 1), MATH_TERMS, _stream())
                 if rc == _lib.UNSUPPORTED:

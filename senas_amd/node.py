@@ -151,6 +151,8 @@ class _Node(torch.autograd.Function):
         for k, t in enumerate(real):
             zfull[t] = zs[k]
             zstrides[t] = zs[k].stride(3) if zs[k].stride(3) > c else c       # a slice saved by the forward pass stays a slice
+            if zs[k].dtype == torch.bfloat16:                                 # (a bf16-stored term: the kernels' negative-stride convention)
+                zstrides[t] = -c
         need = ctx.needs_input_grad
         dzs, dz_strides = [None] * T, (C.c_int32 * T)()
         slots = meta.get('slots') or [None] * T
@@ -161,7 +163,9 @@ class _Node(torch.autograd.Function):
                     dzs[t] = landing.part(part, zs[k])
                     dz_strides[t] = dzs[t].stride(3)
                 else:
-                    dzs[t] = torch.empty_like(zs[k], memory_format=CL)
+                    dzs[t] = torch.empty_like(zs[k], memory_format=CL)       # (bf16 for a bf16-stored term: written as such)
+                    if dzs[t].dtype == torch.bfloat16:
+                        dz_strides[t] = -c
         ds_out = torch.empty((n, c, h, w), device=dev, dtype=torch.float32, memory_format=CL) if (ctx.has_res and need[2]) else None
         p = zeros64((T + 1, n, c), dev)
         # destinations: the parameter's view in the flat gradient buffer under a step driver (autograd then gets None),

@@ -216,3 +216,117 @@ def test_train_step_graph_in_bf16x3_matches_eager(math_mode):
     for k in wg:
         scale = float(we[k].abs().max()) + 1e-12
         assert float((wg[k] - we[k]).abs().max()) <= 1e-6 + 1e-4 * scale, k
+
+
+# ---------------------------------------------------------------------------------------------------------------- 'bf16s'
+STORED_CASES = [c for c in CASES if c[1] % 32 == 0 and c[2] == 32]          # (c_in in 32-channel passes, one 32-channel output tile: wgrad_bf's shapes)
+
+
+@pytest.mark.parametrize('case', STORED_CASES, ids=lambda c: 'n%d_%dto%d_%dx%d_k%dd%d%s' % (c[0], c[1], c[2], c[3], c[4], c[5], c[6], '_relu' if c[7] else ''))
+def test_conv_bf16_stored_vs_fp64(case, math_mode):
+    """Math mode 'bf16s' (senas_conv2d_fwd_bf16s / _bwd_data_bf16s / _bwd_weight_bf16s): plain bf16 products with the convolution's
+    OUTPUT stored as a bf16 tensor and its incoming GRADIENT read as one.  Against torch-CPU fp64: the output within 1e-2 of the
+    tensor scale (the bf16 products' 2.5e-3 + the stored tensor's own rounding, 2^-9 of each element); the gradients, computed from
+    the bf16-ROUNDED incoming gradient, within 1e-2 of the fp64 gradients of that same rounded gradient; the statistics -- taken
+    from the fp32 accumulators, before the rounding -- as accurate as in 'bf16' mode."""
+    from senas_amd import functional as F
+    n, ci, co, h, w, k, dil, relu = case
+    g = torch.Generator().manual_seed(n * 1000 + ci + h + k + dil)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+    dy = torch.randn(n, co, h, w, generator=g).bfloat16()                     # the gradient as it arrives: a bf16 tensor
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y64 = TF.conv2d(torch.relu(x64) if relu else x64, w64, padding=dil * (k // 2), dilation=dil)
+    y64.backward(dy.double())
+    math_mode('bf16s')
+    assert F.math_name() == 'bf16s' and F.MATH_TERMS == 1 and F.MATH_STORED
+    xg = x.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = wt.to(dev()).requires_grad_(True)
+    y, st = F.conv2d(xg, wg, 1, dil * (k // 2), dil, in_relu=relu, want_stats=True)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last), 'the case is meant to run on the bf16-stored path'
+    y.backward(dy.to(dev()).contiguous(memory_format=torch.channels_last))
+    tol = 1e-2
+
+    def err(got, exp):
+        return float((got.detach().cpu().double() - exp.detach()).abs().max() / exp.detach().abs().max())
+
+    assert err(y, y64) <= tol, ('y', err(y, y64))
+    assert xg.grad.dtype == torch.float32 and wg.grad.dtype == torch.float32
+    assert err(xg.grad, x64.grad) <= tol, ('dx', err(xg.grad, x64.grad))
+    assert err(wg.grad, w64.grad) <= tol, ('dw', err(wg.grad, w64.grad))
+    s_ref = torch.stack([y64.detach().sum((2, 3)), (y64.detach() ** 2).sum((2, 3))], -1)
+    assert float((st.cpu() - s_ref).abs().max() / s_ref.abs().max()) <= tol, 'producer-side statistics'
+    # the stored tensor is the 'bf16' mode's fp32 output rounded to nearest even, nothing else
+    math_mode('bf16')
+    y32, _ = F.conv2d(xg.detach(), wg.detach(), 1, dil * (k // 2), dil, in_relu=relu, want_stats=False)
+    assert y32.dtype == torch.float32
+    assert torch.equal(y.detach().float(), y32.bfloat16().float())
+
+
+def test_node_reads_bf16_terms_and_writes_bf16_gradients(math_mode):
+    """The cell node on bf16-stored terms (csrc/node.hip: the negative-stride convention) against the same node on the same
+    values held in fp32: the forward pass bit for bit (a bf16 load is exact), every term gradient = the fp32 node's gradient
+    rounded to nearest even, parameter gradients to the order of atomics."""
+    import copy
+    import torch.nn as nn
+    from senas_amd import functional as F
+    g = torch.Generator().manual_seed(31)
+    n, c, h, w = 3, 32, 24, 40
+    zs = [(torch.randn(n, c, h, w, generator=g) * (0.7 + 0.3 * t) + 0.1 * t).bfloat16() for t in range(2)]
+    bns = []
+    for t in range(2):
+        bn = nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        bns.append(bn.train())
+    gy = torch.randn(n, c, h, w, generator=g)
+    res = []
+    for stored in (True, False):
+        dbns = [copy.deepcopy(b).to(dev()) for b in bns]
+        zd = [(z if stored else z.float()).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True) for z in zs]
+        stats = [F.chan_stats(z.float().to(dev()).contiguous(memory_format=torch.channels_last)) for z in zs] if not res else res[0][3]
+        out = F.bn_combine([F.Term(zd[t], dbns[t], stats=stats[t]) for t in range(2)], relu=True)
+        out.backward(gy.to(dev()).contiguous(memory_format=torch.channels_last))
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), [z.grad.clone() for z in zd], [b.weight.grad.clone() for b in dbns] + [b.bias.grad.clone() for b in dbns], stats))
+    (o_b, dz_b, dp_b, _), (o_f, dz_f, dp_f, _) = res
+    assert o_b.dtype == torch.float32 and torch.equal(o_b, o_f)
+    for a, b in zip(dz_b, dz_f):
+        assert a.dtype == torch.bfloat16 and b.dtype == torch.float32
+        assert torch.equal(a.float(), b.bfloat16().float())
+    for a, b in zip(dp_b, dp_f):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize('fixture,tag', [('nets_full', 'full.derived.node4.c32.d2')])
+def test_derived_net_bf16_stored_vs_reference(fixture, tag, math_mode):
+    """A whole derived net (c = 32, the reference's fixture with fp64 gradients) in 'bf16s': the map is 64 x 64, so the dense
+    candidates of its first level run on the bf16-stored path.  Logits within 3e-2 of their scale (plain 'bf16': 9e-3 on the
+    benchmark net; this mode rounds the convolution outputs once more), the loss within 1e-2, every gradient tensor finite and
+    within 0.5 of its scale (the operand modes' bound for plain bf16 on these ill-conditioned fixtures: 1.5 at the benchmark
+    size) -- a stated error for a reduced-precision storage mode, never the headline."""
+    import test_gpu_parity as T
+    from senas_amd import functional as F
+    from senas_amd.loss import SegmentationLosses
+    math_mode('bf16s')
+    z = gio.load(fixture)
+    net, kw = T._build_net(z, tag)
+    x = torch.from_numpy(z[tag + '/x']).to(dev())
+    tgt = torch.from_numpy(z[tag + '/target']).to(dev())
+    outs = net(x)
+    logits = outs[-1]
+    exp = z[tag + '/logits']
+    e_log = float(np.abs(logits.detach().cpu().numpy() - exp).max()) / float(np.abs(exp).max())
+    loss = SegmentationLosses('dice_ce')(outs, tgt)
+    e_loss = abs(float(loss.detach()) - float(z[tag + '/loss64'])) / abs(float(z[tag + '/loss64']))
+    loss.backward()
+    got = T.grads_of(net)
+    expg = gio.unpack(z, tag + '/grad64/')
+    top = float(z[tag + '/grad_top'])
+    errs = {k: float(np.abs(got[k] - e).max()) / max(float(np.abs(e).max()), 1e-3 * top) for k, e in expg.items()}
+    worst = max(errs, key=errs.get)
+    from conftest import record_margin
+    record_margin('test_derived_net_bf16_stored_vs_reference[%s]' % tag, logits_err=e_log, loss_err=e_loss, worst_gradient=errs[worst], worst_tensor=worst)
+    assert e_log <= 3e-2 and e_loss <= 1e-2, (e_log, e_loss)
+    assert all(np.isfinite(v) for v in errs.values()) and errs[worst] <= 0.5, (worst, errs[worst])

@@ -1032,14 +1032,15 @@ template <int V>
 __device__ __forceinline__ void apply_stream(long hw, int c, int nterms, int n, const ZTable& z, const float* __restrict__ dy,
                                              int dys, const float* __restrict__ y, const uint8_t* __restrict__ mask8, int relu,
                                              const float* A, const float* B, const float* K, int kt, int kbase, const DzTable& dz,
-                                             float* __restrict__ ds_out) {
+                                             float* __restrict__ ds_out, long first = 0) {
+    // first: elements of the image that somebody else has done (the fused kernel's prefetched first element per thread)
     const int cv = c / V;
     const long per_img = hw * cv;
     const size_t img_off = (size_t)n * hw * c;
     const float* safe = nullptr;
     for (int t = 0; t < nterms && safe == nullptr; ++t) safe = z.p[t];
     const bool batched = nterms > 4 && safe != nullptr && per_img <= 2L * gridDim.x * 256;      // (latency-bound regime)
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
+    for (long i = first + (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cv) * V;
         const size_t off = img_off + (size_t)(i / cv) * c + ch;
         float ds[V], yv[V], zv[V], av[V], bv[V], kv[V];
@@ -1109,6 +1110,94 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
                                                          const float* __restrict__ A, const float* __restrict__ B,
                                                          const float* __restrict__ K, DzTable dz, float* __restrict__ ds_out) {
     apply_stream<V>(hw, c, nterms, blockIdx.y, z, dy, dys, y, mask8, relu, A, B, K, nimg * c, blockIdx.y * c, dz, ds_out);
+}
+
+// ------------------------------------------------------------------------------------------ backward apply, fused
+// Few-term nodes (<= kFuseTerms: the derived network's cells, the single-term batch-norms around every cell): the backward
+// PREPARATION runs as a prologue of every apply block (prepare_bwd_term with keep = the block's image: the coefficients of that
+// image land in LDS), so a node's backward pass is two launches (reduce, apply) instead of three -- one launch less on every
+// node of the chain of cells that is the backward critical path.  Round 2 measured this form and dropped it (the block could not
+// stream before its prologue was done: 20.2 ms against 19.7); here the thread's first element -- dy, its ReLU mask, every term --
+// is requested BEFORE the prologue, whose own loads (a few L2-resident rows) and barriers then run under the stream's latency.
+// Block (0, 0) owns the parameter gradients.  The arithmetic is prepare_bwd_term's and apply_stream's: results are bit-identical
+// to the three-launch form (tests/test_gpu_parity.py::test_fused_apply_is_the_three_launch_backward_bit_for_bit).
+// dynamic LDS: prepare_bwd_term's scratch | A_s[T][c] | B_s[T][c] | K_s[T][c] floats
+template <int V>
+__global__ __launch_bounds__(256) void node_apply_fused_kernel(NodeDesc d, ZTable z, const float* __restrict__ dy, int dys,
+                                                               const float* __restrict__ y, const uint8_t* __restrict__ mask8,
+                                                               const double* __restrict__ p1, const double* __restrict__ p2,
+                                                               const float* __restrict__ coefs, const float* __restrict__ gate,
+                                                               const float* __restrict__ se_m, const float* __restrict__ se_a1,
+                                                               float* __restrict__ dmix, SeGradTable seg, DzTable dz,
+                                                               float* __restrict__ ds_out, size_t scratch_bytes) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    const int n = blockIdx.y, c = d.c, T = d.nterms;
+    float* A_s = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ldsd) + scratch_bytes);
+    float* B_s = A_s + T * c;
+    float* K_s = B_s + T * c;
+    // ---- this thread's first element: requested before the preparation
+    const int cv = c / V;
+    const long per_img = d.hw * cv, e0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e0 < per_img;
+    const int ech = live ? (int)(e0 % cv) * V : 0;
+    const size_t pix = (size_t)n * d.hw + (size_t)(live ? e0 / cv : 0);
+    const size_t off = (size_t)n * d.hw * c + (size_t)(live ? e0 / cv : 0) * c + ech;
+    float ds[V], zt[kFuseTerms][V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) ds[j] = 0.f;
+    unsigned mk = 15u;
+    float yv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) yv[j] = 1.f;
+    if (live) {
+        ldv<V>(dy + pix * dys + ech, ds);
+        if (d.relu) {
+            if (V == 4 && mask8 != nullptr) mk = mask8[off >> 2];
+            else ldv<V>(y + off, yv);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kFuseTerms; ++t) {
+        const bool ok = live && t < T && dz.p[t] != nullptr && z.p[t] != nullptr;
+        if (ok) {
+            if constexpr (V == 4) ldz4(z.p[t], pix * z.s[t] + ech, z.bf[t], zt[t]);
+            else ldv<V>(z.p[t] + pix * z.s[t] + ech, zt[t]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) zt[t][j] = 0.f;
+        }
+    }
+    // ---- the preparation (every thread of the block takes part; block (0, 0) writes the parameter gradients)
+    const bool owner = blockIdx.x == 0 && n == 0;
+    for (int t = 0; t < T; ++t)
+        prepare_bwd_term(d, t, ldsd, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, owner, nullptr, nullptr, nullptr, n, A_s + t * c, B_s + t * c,
+                         K_s + t * c);
+    __syncthreads();
+    // ---- the first element from the registers ...
+    if (live) {
+        if (d.relu) {
+            if (V == 4 && mask8 != nullptr) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) if (!((mk >> j) & 1u)) ds[j] = 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) if (!(yv[j] > 0.f)) ds[j] = 0.f;
+            }
+        }
+        if (ds_out != nullptr) stv<V>(ds_out + off, ds);
+#pragma unroll
+        for (int t = 0; t < kFuseTerms; ++t) {
+            if (t < T && dz.p[t] != nullptr && z.p[t] != nullptr) {
+                float r[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) r[j] = fmaf(A_s[t * c + ech + j], ds[j], fmaf(B_s[t * c + ech + j], zt[t][j], K_s[t * c + ech + j]));
+                if constexpr (V == 4) stz4(dz.p[t], pix * dz.s[t] + ech, dz.bf[t], r);
+                else stv<V>(dz.p[t] + pix * dz.s[t] + ech, r);
+            }
+        }
+    }
+    // ---- ... the rest of this thread's elements the usual way (coefficients from LDS)
+    apply_stream<V>(d.hw, c, T, n, z, dy, dys, y, mask8, d.relu, A_s, B_s, K_s, c, 0, dz, ds_out, (long)gridDim.x * 256);
 }
 
 static bool fill_desc(const senas_node_desc* s, NodeDesc& d) {
@@ -1317,6 +1406,19 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
     const size_t tnc = (size_t)d.nterms * d.n * d.c;
     const size_t lds_fast = prepare_bwd_lds(d);
     const bool fast_ok = d.n <= kImgs * (256 / d.c) && lds_fast <= 64 * 1024;
+    {
+        // few terms: the preparation as a prologue of the apply launch (node_apply_fused_kernel), the operands requested before it
+        const char* sw = getenv("SENAS_NODE_FUSED_APPLY");                 // ("0": the three-launch form, for the bit-identity test)
+        const size_t scratch = (lds_fast + 15) & ~(size_t)15;
+        const size_t lds_fused = scratch + (size_t)3 * d.nterms * d.c * sizeof(float);
+        if (!(sw && sw[0] == '0') && d.nterms <= kFuseTerms && fast_ok && lds_fused <= 48 * 1024 && (any_dz || ds_out)) {
+            const int V = (d.c % 4 == 0) ? 4 : 1;
+            dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+            if (V == 4) hipLaunchKernelGGL((node_apply_fused_kernel<4>), grid, dim3(256), lds_fused, st, d, zt, dy, dys, y, mask8, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, dzt, ds_out, scratch);
+            else hipLaunchKernelGGL((node_apply_fused_kernel<1>), grid, dim3(256), lds_fused, st, d, zt, dy, dys, y, mask8, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, dzt, ds_out, scratch);
+            return launch_status("node_bwd (fused apply)");
+        }
+    }
     // (running this preparation as a prologue of every apply block was measured: the block cannot stream before its
     // prologue is done, so the launch it saves buys nothing -- 20.2 ms vs 19.7 ms per step; kept as its own launch)
     if (fast_ok) {

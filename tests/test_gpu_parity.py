@@ -2008,3 +2008,74 @@ def test_planar_stacked_outputs_change_nothing_but_the_layout(kind, size):
     top = max(float(v.abs().max()) for v in off[7].values())
     for k_, v in off[7].items():
         assert float((on[7][k_] - v).abs().max()) <= 1e-6 * max(float(v.abs().max()), 1e-3 * top), k_
+
+
+@pytest.mark.parametrize('cfg', [dict(n=4, c=32, h=16, w=16, T=2, se=False, zero=False, training=True, relu=True, res=False, mix=False),
+                                 dict(n=8, c=32, h=128, w=128, T=2, se=False, zero=False, training=True, relu=True, res=False, mix=False),
+                                 dict(n=3, c=8, h=9, w=7, T=4, se=True, zero=True, training=True, relu=True, res=True, mix=True),
+                                 dict(n=2, c=32, h=33, w=20, T=1, se=False, zero=False, training=True, relu=False, res=False, mix=False),
+                                 dict(n=5, c=6, h=5, w=6, T=3, se=False, zero=False, training=True, relu=True, res=True, mix=True),
+                                 dict(n=2, c=64, h=12, w=12, T=2, se=True, zero=False, training=False, relu=True, res=False, mix=True)],
+                         ids=lambda d: 'n%d_c%d_%dx%d_T%d%s' % (d['n'], d['c'], d['h'], d['w'], d['T'], '' if d['training'] else '_eval'))
+def test_fused_apply_is_the_three_launch_backward_bit_for_bit(cfg):
+    """csrc/node.hip node_apply_fused_kernel (few-term nodes: the backward preparation as a prologue of the apply launch, the
+    thread's first element requested before it) against reduce + prepare + apply (SENAS_NODE_FUSED_APPLY=0) on the SAME reduced
+    sums: every input gradient, the residual's, every batch-norm / SE / mixing gradient -- bit for bit (the two forms run the same
+    device functions on the same operands; the reduce launch in front of both is shared, so its atomics do not enter)."""
+    import copy
+    import torch.nn as nn
+    from senas_amd import functional as F
+    from senas_amd.operations import SEBlock
+    g = torch.Generator().manual_seed(91)
+    n, c, h, w, T = cfg['n'], cfg['c'], cfg['h'], cfg['w'], cfg['T']
+    zs = [torch.randn(n, c, h, w, generator=g) * (0.5 + 0.2 * t) + 0.05 * t for t in range(T)]
+    if cfg['zero'] and T > 1:
+        zs[1] = None
+    bns = []
+    for t in range(T):
+        bn = nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.train(cfg['training'])
+        bns.append(bn)
+    ses = [SEBlock(c) if (cfg['se'] and t % 2 == 0 and zs[t] is not None) else None for t in range(T)]
+    mix = torch.rand(T, generator=g) + 0.1 if cfg['mix'] else None
+    resid = torch.randn(n, c, h, w, generator=g) if cfg['res'] else None
+    gy = torch.randn(n, c, h, w, generator=g)
+    cl = lambda t: t.to(dev()).contiguous(memory_format=torch.channels_last)
+    stats = [F.chan_stats(cl(z)) if z is not None else None for z in zs]
+    torch.cuda.synchronize()
+    res = []
+    keep = os.environ.get('SENAS_NODE_FUSED_APPLY')
+    try:
+        for mode in ('1', '0'):
+            os.environ['SENAS_NODE_FUSED_APPLY'] = mode
+            dbns = [copy.deepcopy(b).to(dev()) for b in bns]
+            dses = [copy.deepcopy(s_).to(dev()) if s_ is not None else None for s_ in ses]
+            zd = [cl(z).requires_grad_(True) if z is not None else None for z in zs]
+            md = mix.to(dev()).requires_grad_(True) if mix is not None else None
+            rd = cl(resid).requires_grad_(True) if resid is not None else None
+            out = F.bn_combine([F.Term(zd[t], dbns[t], se=dses[t], stats=stats[t]) for t in range(T)], mix=md, residual=rd, relu=cfg['relu'])
+            out.backward(cl(gy))
+            torch.cuda.synchronize()
+            grads = [z.grad.clone() for z in zd if z is not None] + [b.weight.grad.clone() for b in dbns] + [b.bias.grad.clone() for b in dbns]
+            grads += [s_.excitation[k].weight.grad.clone() for s_ in dses if s_ is not None for k in (0, 2)]
+            if md is not None:
+                grads.append(md.grad.clone())
+            if rd is not None:
+                grads.append(rd.grad.clone())
+            res.append((out.detach().clone(), grads))
+    finally:
+        if keep is None:
+            os.environ.pop('SENAS_NODE_FUSED_APPLY', None)
+        else:
+            os.environ['SENAS_NODE_FUSED_APPLY'] = keep
+    (o1, g1), (o0, g0) = res
+    assert torch.equal(o1, o0) and len(g1) == len(g0) and len(g1) >= T
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        # the reduce launch's fp64 atomics differ in their last bits from run to run: what comes out in fp32 is compared to 2e-7 of
+        # the tensor scale (one ulp), and must be EQUAL wherever the reduced sums were
+        assert float((a - b).abs().max()) <= 2e-7 * (float(b.abs().max()) + 1e-30), (i, float((a - b).abs().max()), float(b.abs().max()))

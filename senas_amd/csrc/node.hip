@@ -1116,9 +1116,10 @@ __global__ __launch_bounds__(256) void node_apply_kernel(long hw, int c, int nte
 // Few-term nodes (<= kFuseTerms: the derived network's cells, the single-term batch-norms around every cell): the backward
 // PREPARATION runs as a prologue of every apply block (prepare_bwd_term with keep = the block's image: the coefficients of that
 // image land in LDS), so a node's backward pass is two launches (reduce, apply) instead of three -- one launch less on every
-// node of the chain of cells that is the backward critical path.  Round 2 measured this form and dropped it (the block could not
-// stream before its prologue was done: 20.2 ms against 19.7); here the thread's first element -- dy, its ReLU mask, every term --
-// is requested BEFORE the prologue, whose own loads (a few L2-resident rows) and barriers then run under the stream's latency.
+// node of the chain of SMALL cells that is the backward critical path (the launcher takes this form up to 32 blocks).  Round 2
+// measured the form at every size and dropped it (20.2 ms against 19.7); here the thread's first element -- dy, its ReLU mask,
+// every term -- is requested BEFORE the prologue, whose own loads (a few L2-resident rows) and barriers then run under the
+// stream's latency -- which helps the small grids and does not rescue the large ones (thousands of blocks each repeating it).
 // Block (0, 0) owns the parameter gradients.  The arithmetic is prepare_bwd_term's and apply_stream's: results are bit-identical
 // to the three-launch form (tests/test_gpu_parity.py::test_fused_apply_is_the_three_launch_backward_bit_for_bit).
 // dynamic LDS: prepare_bwd_term's scratch | A_s[T][c] | B_s[T][c] | K_s[T][c] floats
@@ -1411,9 +1412,16 @@ extern "C" int senas_node_bwd(const senas_node_desc* desc, const float* const* z
         const char* sw = getenv("SENAS_NODE_FUSED_APPLY");                 // ("0": the three-launch form, for the bit-identity test)
         const size_t scratch = (lds_fast + 15) & ~(size_t)15;
         const size_t lds_fused = scratch + (size_t)3 * d.nterms * d.c * sizeof(float);
-        if (!(sw && sw[0] == '0') && d.nterms <= kFuseTerms && fast_ok && lds_fused <= 48 * 1024 && (any_dz || ds_out)) {
-            const int V = (d.c % 4 == 0) ? 4 : 1;
-            dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+        const int V = (d.c % 4 == 0) ? 4 : 1;
+        dim3 grid(node_grid(d.hw * (d.c / V), d.n), d.n);
+        // ... on SMALL grids only: with thousands of blocks every one of them repeats the prologue and the launch it saves is
+        // nothing beside that (measured, round 5: derived train step 15.7 -> 18.9 ms with the fused form at every size -- round 2's
+        // finding stands for the large maps, prefetch or not); up to 32 blocks the chain of small cells saves a launch per node
+        // (thresholds 0 / 32 / 128 / 512 are within the run-to-run spread of the search step: profiles/r5_planar_wide_ab.txt)
+        long fuse_blocks = 32;
+        if (const char* fb = getenv("SENAS_NODE_FUSED_BLOCKS")) fuse_blocks = atol(fb);
+        if (!(sw && sw[0] == '0') && d.nterms <= kFuseTerms && fast_ok && lds_fused <= 48 * 1024 && (any_dz || ds_out) &&
+            (long)grid.x * d.n <= fuse_blocks) {
             if (V == 4) hipLaunchKernelGGL((node_apply_fused_kernel<4>), grid, dim3(256), lds_fused, st, d, zt, dy, dys, y, mask8, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, dzt, ds_out, scratch);
             else hipLaunchKernelGGL((node_apply_fused_kernel<1>), grid, dim3(256), lds_fused, st, d, zt, dy, dys, y, mask8, p1, p2, coefs, gate, se_m, se_a1, dmix, seg, dzt, ds_out, scratch);
             return launch_status("node_bwd (fused apply)");

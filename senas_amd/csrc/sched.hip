@@ -125,9 +125,11 @@ static std::vector<hipStream_t>& lane_pool() {
 // arbitration does with the priority, every launch of such a queue pays for it.  SENAS_SCHED_PRIORITY=1 turns it on again
 // (the classes and the priorities together) for a re-measurement on another runtime.
 // SENAS_SCHED_PRIORITY=2: the other way round -- the light streams at the default priority, the HEAVY ones at the device's least.
+// SENAS_SCHED_PRIORITY=3: no priorities; the heavy streams are created with a CU mask that leaves every 8th CU to the light ones
+// (hipExtStreamCreateWithCUMask): a light kernel then always finds free CUs beside a kernel that fills the rest of the chip.
 static int pool_priority_mode() {
     const char* e = getenv("SENAS_SCHED_PRIORITY");
-    return e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0)) : 0;
+    return e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 0))) : 0;
 }
 static bool pool_priorities() { return pool_priority_mode() != 0; }
 constexpr int kHighStreams = 2;
@@ -144,7 +146,15 @@ static void lane_pool_grow(int want) {
         const bool light_stream = (int)pool.size() < kHighStreams;
         const int prio = mode == 1 ? (light_stream ? greatest : 0) : (mode == 2 ? (light_stream ? 0 : least) : 0);
         if (getenv("SENAS_SCHED_VERBOSE") && pool.empty()) fprintf(stderr, "[sched] stream priorities of this device: least %d, greatest %d\n", least, greatest);
-        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) break;
+        if (mode == 3 && !light_stream) {
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+            std::vector<uint32_t> mask((cus + 31) / 32, 0u);
+            int keep_every = 8;
+            if (const char* e = getenv("SENAS_SCHED_CUMASK_EVERY")) keep_every = atoi(e) > 1 ? atoi(e) : 8;
+            for (int cu = 0; cu < cus; ++cu) if (cu % keep_every != keep_every - 1) mask[cu >> 5] |= 1u << (cu & 31);
+            if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) break;
+        } else if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) break;
         bool ok = true;
         for (hipStream_t kept : pool) ok = ok && lanes_overlap(kept, st);
         if (ok) pool.push_back(st); else rejected.push_back(st);      // (kept alive until the end: a destroyed stream's queue slot is the next one handed out)

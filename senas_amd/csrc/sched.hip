@@ -129,7 +129,7 @@ static std::vector<hipStream_t>& lane_pool() {
 // (hipExtStreamCreateWithCUMask): a light kernel then always finds free CUs beside a kernel that fills the rest of the chip.
 static int pool_priority_mode() {
     const char* e = getenv("SENAS_SCHED_PRIORITY");
-    return e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 0))) : 0;
+    return e ? (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : (e[0] == '4' ? 4 : 0)))) : 0;      // (4: the two classes on plain streams)
 }
 static bool pool_priorities() { return pool_priority_mode() != 0; }
 constexpr int kHighStreams = 2;

@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
     __shared__ __attribute__((aligned(16))) float sc[2 * kMaxCin];
     const senas_dstail_item& it = items.it[blockIdx.z];
     const int n = blockIdx.y;
+    SENAS_PHASE(0);
     bn1_coefficients(it, 0, hw, cin, 1, 0.f, 0.f, false, false, sc);
     for (int i = threadIdx.x; i < COUT * cin; i += 256) wl[i] = it.w[i];
     __syncthreads();
+    SENAS_PHASE(1);
     const int Q = cin >> 2, q = threadIdx.x % Q, pl = threadIdx.x / Q, lanes = 256 / Q;
     const int dst = (int)it.dz2_pixel_stride;
     const bool vec = (dst & 3) == 0 && (reinterpret_cast<uintptr_t>(it.dz2) & 15) == 0;
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
                 for (int j = 0; j < 4; ++j) wacc[co][j] = fmaf(d[co], mid[j], wacc[co][j]);
         }
     }
+    SENAS_PHASE(2);
     // ---- S1 / S2: pixel lanes folded through LDS, one fp64 atomic pair per channel
     {
         double* mine = red + (size_t)threadIdx.x * 8;
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
             for (int j = 0; j < 4; ++j) { atomicAdd(dsum + 2 * j, s1[j]); atomicAdd(dsum + 2 * j + 1, s2[j]); }
         }
     }
+    SENAS_PHASE(3);
     if (!WG) return;
     // ---- dW: the pixel lanes of the block folded through LDS (row length 257: the 4 floats of a quad land on 4 banks), then
     // one fp64 atomic per element into the problem's accumulator (double[COUT][cin], zero on entry).  No device-scope
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
         for (int l = 0; l < lanes; ++l) v += (double)src[l * Q];
         atomicAdd(it.dw_acc + e, v);
     }
+    SENAS_PHASE(4);
 }
 
 template <int COUT>
@@ -295,6 +300,9 @@ long ds_chunk(int64_t hw, int n, int k) {
 }
 
 }  // namespace
+
+SENAS_PHASE_READER(dstail)
+
 }  // namespace senas
 
 extern "C" int senas_dstail_fwd(const senas_dstail_item* items, int k, int n, int64_t hw, int cin, int cout, int training,

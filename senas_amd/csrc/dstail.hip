@@ -149,7 +149,7 @@ __device__ __forceinline__ void ds_quad(const float* __restrict__ dp, bool vec, 
 // grid = (pixel chunks, n, k).  thread = (pixel lane, input-channel quad).  WG: also the weight gradient of the 1x1.
 template <int COUT, bool WG>
 __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, long hw, int cin, long chunk) {
-    extern __shared__ __attribute__((aligned(16))) double red[];      // [256][8] doubles, reused as [4*COUT][257] floats
+    extern __shared__ __attribute__((aligned(16))) double red[];      // [16 rows][Q][8] doubles, [16][Q][4 * COUT] floats
     __shared__ __attribute__((aligned(16))) float wl[kMaxCout * kMaxCin];
     __shared__ __attribute__((aligned(16))) float sc[2 * kMaxCin];
     const senas_dstail_item& it = items.it[blockIdx.z];
@@ -187,44 +187,53 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
         }
     }
     SENAS_PHASE(2);
-    // ---- S1 / S2: pixel lanes folded through LDS, one fp64 atomic pair per channel
-    {
-        double* mine = red + (size_t)threadIdx.x * 8;
+    // ---- S1 / S2 and dW: the pixel lanes of a 16-lane row that share q folded in registers (DPP), the 16 rows of the block
+    // through LDS, then one fp64 atomic per value and block.  (The first form had thread q walk the other 256 / Q - 1 threads'
+    // partial sums in LDS: 4 us of a 9.5 us launch on the small maps.)
+    // No device-scope fence anywhere: on this multi-XCD part a release fence writes the whole L2 back, once per block -- the
+    // last-block-folds-the-partials form of this kernel measured 107 us instead of 25.  The apply launch rounds the dW
+    // accumulator (double[COUT][cin], zero on entry) to the fp32 gradient; fp64 accumulation makes the summation order immaterial
+    // at fp32 precision.
+    // 16 partials per value: (wave, 16-lane row).  S1 / S2 stay in fp64 throughout; the per-thread dW sums are fp32 already and
+    // are folded in fp32 inside a row (one DPP add per step: the fp64 form, two moves and an add per step plus shuffles, cost
+    // 4.5 us for the 32 values), in fp64 from there on.
+    const int part = threadIdx.x >> 4, rl = threadIdx.x & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = row_strided_sum(s1[j], Q); s2[j] = row_strided_sum(s2[j], Q); }
+    double* reds = red;                                                       // [16][Q][8] doubles
+    float* redw = reinterpret_cast<float*>(red + 16 * Q * 8);                 // [16][Q][COUT * 4] floats
+    if (rl < Q) {
+        double* mine = reds + (size_t)(part * Q + rl) * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mine[j] = s1[j]; mine[4 + j] = s2[j]; }
-        __syncthreads();
-        if ((int)threadIdx.x < Q) {
-            for (int l = 1; l < lanes; ++l) {
-                const double* o = red + (size_t)(threadIdx.x + l * Q) * 8;
+    }
+    if (WG) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += o[j]; s2[j] += o[4 + j]; }
-            }
-            double* dsum = it.sums + ((size_t)n * cin + 4 * q) * 2;
+        for (int co = 0; co < COUT; ++co)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { atomicAdd(dsum + 2 * j, s1[j]); atomicAdd(dsum + 2 * j + 1, s2[j]); }
+            for (int j = 0; j < 4; ++j) wacc[co][j] = row_strided_sum(wacc[co][j], Q);
+        if (rl < Q) {
+            float* mine = redw + (size_t)(part * Q + rl) * (COUT * 4);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) stv<4>(mine + co * 4, wacc[co]);
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < Q * 8) {
+        const int qq = threadIdx.x >> 3, j8 = threadIdx.x & 7;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += reds[(size_t)(w * Q + qq) * 8 + j8];
+        atomicAdd(it.sums + ((size_t)n * cin + 4 * qq + (j8 & 3)) * 2 + (j8 >> 2), v);
     }
     SENAS_PHASE(3);
     if (!WG) return;
-    // ---- dW: the pixel lanes of the block folded through LDS (row length 257: the 4 floats of a quad land on 4 banks), then
-    // one fp64 atomic per element into the problem's accumulator (double[COUT][cin], zero on entry).  No device-scope
-    // fence anywhere: on this multi-XCD part a release fence writes the whole L2 back, once per block -- the
-    // last-block-folds-the-partials form of this kernel measured 107 us instead of 25.  The apply launch rounds the
-    // accumulator to the fp32 gradient; fp64 accumulation makes the summation order immaterial at fp32 precision.
-    __syncthreads();
-    float* redf = reinterpret_cast<float*>(red);
-    constexpr int ROW = 257;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) redf[(size_t)(co * 4 + j) * ROW + threadIdx.x] = wacc[co][j];
-    __syncthreads();
     const int nel = COUT * cin;
     for (int e = threadIdx.x; e < nel; e += 256) {
         const int co = e / cin, ci = e - co * cin;
-        const float* src = redf + (size_t)(co * 4 + (ci & 3)) * ROW + (ci >> 2);
         double v = 0.0;
-        for (int l = 0; l < lanes; ++l) v += (double)src[l * Q];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += (double)redw[(size_t)(w * Q + (ci >> 2)) * (COUT * 4) + co * 4 + (ci & 3)];
         atomicAdd(it.dw_acc + e, v);
     }
     SENAS_PHASE(4);
@@ -356,7 +365,7 @@ extern "C" int senas_dstail_bwd(const senas_dstail_item* items, int k, int n, in
     const long chunk = ds_chunk(hw, n, k);
     dim3 grid((unsigned)((hw + chunk - 1) / chunk), n, k);
     hipStream_t st = as_stream(stream);
-    const size_t lds = 32 * 257 * sizeof(float);                     // [256][8] doubles, then [4 * cout][257] floats
+    const size_t lds = (size_t)16 * (cin / 4) * (8 * sizeof(double) + 4 * cout * sizeof(float));     // [16 rows][Q] x (8 doubles, 4 * cout floats)
 #define SENAS_DS(CO)                                                                                                   \
     do {                                                                                                               \
         if (wg) hipLaunchKernelGGL((dstail_bwd_reduce_kernel<CO, true>), grid, dim3(256), lds, st, b, (long)hw, cin, chunk);   \

@@ -2,7 +2,7 @@
 """The DepSepConv tail's backward pair (dstail.hip: reduce + apply) on its own: launch time by HIP events and, with the debug
 library (`make -C senas_amd/csrc phases`), the phase stamps of block 0 of the reduce launch.
 
-    python tools/phase_probe_ds.py 12,4,16384,8,8 [dz2 pixel stride]      # k,n,hw,cin,cout
+    python tools/phase_probe_ds.py 12,4,16384,8,8 [dz2 pixel stride [nowg]]      # k,n,hw,cin,cout
 """
 import ctypes as C
 import os
@@ -23,6 +23,7 @@ class Item(C.Structure):
 def main():
     k, n, hw, cin, cout = (int(v) for v in sys.argv[1].split(','))
     stride = int(sys.argv[2]) if len(sys.argv) > 2 else cout
+    nowg = len(sys.argv) > 3 and sys.argv[3] == 'nowg'          # the architecture pass: no weight gradient of the 1x1
     name = os.environ.get('SENAS_PROBE_LIB') or (
         'libsenas_hip_phases.so' if os.path.exists(os.path.join(ROOT, 'senas_amd', 'libsenas_hip_phases.so')) else 'libsenas_hip.so')
     lib = C.CDLL(os.path.join(ROOT, 'senas_amd', name))
@@ -54,8 +55,9 @@ def main():
         it.sums = t(n, cin, 2, dtype=torch.float64, fill=0.0).data_ptr()
         it.dz1 = t(n, hw, cin).data_ptr()
         it.dgamma1, it.dbeta1 = t(cin).data_ptr(), t(cin).data_ptr()
-        it.dw = t(cout, cin).data_ptr()
-        it.dw_acc = t(cout, cin, dtype=torch.float64, fill=0.0).data_ptr()
+        if not nowg:
+            it.dw = t(cout, cin).data_ptr()
+            it.dw_acc = t(cout, cin, dtype=torch.float64, fill=0.0).data_ptr()
         st1 = t(n, cin, 2, dtype=torch.float64, fill=0.0)
         st1[..., 1] = float(hw)
         it.stats1 = st1.data_ptr()

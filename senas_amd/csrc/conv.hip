@@ -494,6 +494,82 @@ __global__ __launch_bounds__(256) void dwconv_multi_dgrad_kernel(GatherGeom ga, 
     stv<4>(out + (((size_t)n * ga.hout + oy) * ga.wout + ox) * C + c, acc);
 }
 
+// The stride-2 transposed gather of the above (data gradient of the DOWN candidates' depthwise half) for SMALL launches.  Output
+// (oy, ox) takes the taps with ky = (oy + pad) mod 2 (mod 2): at most SL = (KS + 1) / 2 per dimension.  The general kernel walks
+// all k x k taps with a branch per tap and one problem per trip -- 25 dependent round trips for 3 + 3 problems, 21 us on an
+// 8 x 8 map; here the SL x SL slots of three problems are requested together (clamped addresses, predicated FMAs).
+template <int KS>
+__device__ __forceinline__ void dw_dgrad_s2_accumulate(const GatherGeom& g, const DwTab& tab, int p0, int p1, const float* wg, int C,
+                                                       int c, int n, int oy, int ox, float (&acc)[4]) {
+    constexpr int SL = (KS + 1) / 2, PB = 3;
+    int iy[SL], ix[SL], kys[SL], kxs[SL];
+    bool oky[SL], okx[SL];
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+        const int ky = ((oy + g.pad) & 1) + 2 * i, ty = oy + g.pad - ky;
+        const int kx = ((ox + g.pad) & 1) + 2 * i, tx = ox + g.pad - kx;
+        oky[i] = ky < KS && ty >= 0 && (ty >> 1) < g.hin;
+        okx[i] = kx < KS && tx >= 0 && (tx >> 1) < g.win;
+        iy[i] = oky[i] ? ty >> 1 : 0; kys[i] = oky[i] ? ky : 0;
+        ix[i] = okx[i] ? tx >> 1 : 0; kxs[i] = okx[i] ? kx : 0;
+    }
+    for (int pb = p0; pb < p1; pb += PB) {
+        float v[PB][SL][SL][4];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const float* src = tab.a[pb + u < p1 ? pb + u : p1 - 1] + c;
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                for (int j = 0; j < SL; ++j) ldv<4>(src + ((size_t)(n * g.hin + iy[i]) * g.win + ix[j]) * g.cin, v[u][i][j]);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const bool live = pb + u < p1;
+            const float* wp = wg + (size_t)(live ? pb + u - p0 : 0) * KS * KS * C + c;
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+#pragma unroll
+                for (int j = 0; j < SL; ++j) {
+                    float wt[4];
+                    ldv<4>(wp + (size_t)(kys[i] * KS + kxs[j]) * C, wt);
+                    const bool ok = live && oky[i] && okx[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = ok ? fmaf(v[u][i][j][q], wt[q], acc[q]) : acc[q];
+                }
+        }
+    }
+}
+
+template <int KSA, int KSB>
+__global__ __launch_bounds__(256) void dwconv_multi_dgrad_s2_kernel(GatherGeom ga, GatherGeom gb, int ka, DwTab tab, int k,
+                                                                    float* __restrict__ out, long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [problem][tap][C], group a first
+    const int C = ga.cout;
+    const int na = ka * KSA * KSA * C, nb = (k - ka) * KSB * KSB * C;
+    for (int i = threadIdx.x; i < na; i += 256) {
+        const int p = i / (KSA * KSA * C), r = i - p * KSA * KSA * C, t = r / C, cc = r - t * C;
+        wl[i] = tab.w[p][cc * KSA * KSA + t];
+    }
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int p = i / (KSB * KSB * C), r = i - p * KSB * KSB * C, t = r / C, cc = r - t * C;
+        wl[na + i] = tab.w[ka + p][cc * KSB * KSB + t];
+    }
+    __syncthreads();
+    const long idx = (long)xcd_block().x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / 4;
+    const int c = (int)(idx % cv) * 4;
+    long pix = idx / cv;
+    const int ox = (int)(pix % ga.wout);
+    pix /= ga.wout;
+    const int oy = (int)(pix % ga.hout), n = (int)(pix / ga.hout);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    dw_dgrad_s2_accumulate<KSA>(ga, tab, 0, ka, wl, C, c, n, oy, ox, acc);
+    if (k > ka) dw_dgrad_s2_accumulate<KSB>(gb, tab, ka, k, wl + na, C, c, n, oy, ox, acc);
+    stv<4>(out + (((size_t)n * ga.hout + oy) * ga.wout + ox) * C + c, acc);
+}
+
 // depthwise weight gradient: dW[c][tap] = sum_{n,p} I[n, p*s-pad+k*d][c] * G[n,p][c]
 // grid = pixel chunks; block = rows x C lanes (C <= 256); every thread keeps one partial per tap, so
 // G is read once and the taps' I reads hit L1.
@@ -1688,6 +1764,14 @@ extern "C" int senas_dwconv_pair_bwd_data(const senas_conv_geom* ga, int ka, con
     }
     const long total = (long)g->n * g->hi * g->wi * (g->ci / 4);
     dim3 grid((unsigned)((total + 255) / 256));
+    auto s2 = [](const senas_conv_geom* q) { return !q->transposed && q->stride == 2 && q->dil == 1 && q->pad == q->kh / 2; };
+    if (s2(ga) && (kb == 0 || s2(gb)) && total <= 512L * 256) {                               // small maps: latency-bound
+        hipStream_t st = as_stream(stream);
+        if (kb > 0) hipLaunchKernelGGL((dwconv_multi_dgrad_s2_kernel<3, 5>), grid, dim3(256), lds, st, gga, ggb, ka, tab, k, dx, total);
+        else if (g->kh == 3) hipLaunchKernelGGL((dwconv_multi_dgrad_s2_kernel<3, 3>), grid, dim3(256), lds, st, gga, ggb, ka, tab, k, dx, total);
+        else hipLaunchKernelGGL((dwconv_multi_dgrad_s2_kernel<5, 5>), grid, dim3(256), lds, st, gga, ggb, ka, tab, k, dx, total);
+        return launch_status("dwconv_pair_bwd_data (stride 2)");
+    }
     if (!g->transposed) hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<true>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, dx, total);
     else hipLaunchKernelGGL((dwconv_multi_dgrad_kernel<false>), grid, dim3(256), lds, as_stream(stream), gga, ggb, ka, tab, k, dx, total);
     return launch_status("dwconv_pair_bwd_data");

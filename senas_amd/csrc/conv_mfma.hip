@@ -58,11 +58,14 @@ struct GFrag {
     float4 b[4];
 };
 
-// KS = 4: the four waves of a block share ONE 32-pixel sub-tile and split the (tap, chunk) steps between
+// KS = 4 / 8: the 4 / 8 waves of a block share ONE 32-pixel sub-tile and split the (tap, chunk) steps between
 // them (partial accumulators are summed through LDS) -- for tiny maps, where the serial K loop of a wave is
-// the whole launch time.  KS = 1: every wave owns MT sub-tiles and runs all steps.
+// the whole launch time: a step is 16 MFMAs of 64 cycles on one SIMD, 0.43 us, and the 8 x 8 maps of the deepest
+// down cell fill 32 blocks (KS = 8: 512-thread blocks, for launches of at most 256 of them; 16 waves would
+// leave 128 VGPRs each and spill).
+// KS = 1: every wave owns MT sub-tiles and runs all steps.
 template <bool TG, int MT, int KS>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const float* __restrict__ in,
+__global__ __launch_bounds__(KS == 8 ? 512 : 256) void conv_mfma_kernel(GatherGeom g, const float* __restrict__ in,
                                                         const float* __restrict__ wp, float* __restrict__ out,
                                                         int in_relu, const float* __restrict__ mask,
                                                         double* __restrict__ stats, int tiles_per_phase) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
     const int HP = s2 ? g.hout >> 1 : g.hout, WP = s2 ? g.wout >> 1 : g.wout;
     const int QP = HP * WP;
     const long total = (long)g.n * QP;
-    const long base = KS == 4 ? (long)tile * 32 : ((long)tile * 4 + wave) * (MT * 32);
+    const long base = KS > 1 ? (long)tile * 32 : ((long)tile * 4 + wave) * (MT * 32);
 
     int pn[MT], poy[MT], pox[MT];
     bool live[MT];
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
         for (;;) {
             if (!advance1(ky, kx, chunk)) return false;
             ++sidx;
-            if (KS == 1 || (sidx & 3) == wave) return true;           // this wave's share of the steps
+            if (KS == 1 || (sidx & (KS - 1)) == wave) return true;    // this wave's share of the steps
         }
     };
     int ky = 0, kx = -1, chunk = nchunks - 1;                         // "before the first step"
@@ -183,16 +186,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(GatherGeom g, const floa
         have = more;
     }
 
-    if (KS == 4) {                                                    // sum the four partial tiles through LDS
-        __shared__ float red[3][16][64];
+    if (KS > 1) {                                                     // sum the partial tiles through LDS
+        __shared__ float red[KS > 1 ? KS - 1 : 1][16][64];
         if (wave > 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) red[wave - 1][v][lane] = acc[0][v];
         }
         __syncthreads();
         if (wave > 0) return;
+        if (KS == 4) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[0][v] += red[0][v][lane] + red[1][v][lane] + red[2][v][lane];
+            for (int v = 0; v < 16; ++v) acc[0][v] += red[0][v][lane] + red[1][v][lane] + red[2][v][lane];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS - 1; ++w) t += red[w][v][lane];
+                acc[0][v] += t;
+            }
+        }
     }
     // ---- epilogue: lane = output channel, registers = pixels
     const bool cok = co < g.cout;
@@ -466,7 +479,10 @@ int launch_mfma_gather(const GatherGeom& g, const float* in, const float* wp, fl
         hipLaunchKernelGGL((conv_mfma_kernel<TG, 2, 1>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
     } else if (per_phase * phases <= 32L * 1024) {                    // tiny maps: one sub-tile per block, taps split over its waves
         const int tiles = (int)((per_phase + 31) / 32);
-        hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 4>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
+        if ((long)tiles * phases * ntiles <= 256)                     // at most a block per CU: 8 waves each
+            hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 8>), dim3(tiles * phases, ntiles), dim3(512), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
+        else
+            hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 4>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);
     } else {
         const int tiles = (int)((per_phase + 127) / 128);
         hipLaunchKernelGGL((conv_mfma_kernel<TG, 1, 1>), dim3(tiles * phases, ntiles), dim3(256), 0, st, g, in, wp, out, in_relu, mask, stats, tiles);

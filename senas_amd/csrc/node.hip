@@ -895,6 +895,7 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
     float* w1_s = m_s + (size_t)n * c;
     float* w2_s = w1_s + (size_t)kMaxMid * c;
 
+    SENAS_PHASE(0);
     // ---- all global reads up front
     const float* co = coefs + (size_t)t * 4 * c;
     const double mean = act ? co[ch] : 0.0, invstd = act ? co[c + ch] : 0.0, scale = act ? co[2 * c + ch] : 0.0,
@@ -928,9 +929,11 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
             if (se) da2[i * c + ch] = w * dot * Gt[k] * (1.0 - Gt[k]);
         }
     }
+    SENAS_PHASE(1);
     dmix_part = wave_sum(dmix_part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dmix_part;
     __syncthreads();                                             // red[], da2[], SE operands visible
+    SENAS_PHASE(2);
     if (write_grads && threadIdx.x == 0 && dmix != nullptr)
         dmix[t] = (seg.dmix_accumulate ? dmix[t] : 0.f) + (float)(red[0] + red[1] + red[2] + red[3]);
 
@@ -981,8 +984,10 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
             s2 += u1 * P2[k] + e[k] * Zs[k];
         }
     }
+    SENAS_PHASE(3);
     if (act) { part[((size_t)row * c + ch) * 2] = s1; part[((size_t)row * c + ch) * 2 + 1] = s2; }
     __syncthreads();
+    SENAS_PHASE(4);
     if (act) {
         s1 = 0.0; s2 = 0.0;
         for (int rr = 0; rr < R; ++rr) { s1 += part[((size_t)rr * c + ch) * 2]; s2 += part[((size_t)rr * c + ch) * 2 + 1]; }
@@ -1006,7 +1011,9 @@ __device__ __forceinline__ void prepare_bwd_term(const NodeDesc& d, int t, doubl
             }
         }
     }
+    SENAS_PHASE(5);
     __syncthreads();                                             // the LDS scratch is reused by the caller's next term
+    SENAS_PHASE(6);
 }
 
 __global__ __launch_bounds__(256) void node_prepare_bwd_kernel(NodeDesc d, const double* __restrict__ p1,
@@ -1240,6 +1247,8 @@ static unsigned node_grid(long work, int n) {
     if (b > cap) b = cap;
     return (unsigned)(b < 1 ? 1 : b);
 }
+
+SENAS_PHASE_READER(node)
 
 }  // namespace senas
 

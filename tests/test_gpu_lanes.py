@@ -127,7 +127,8 @@ def test_step_drivers_on_lanes_track_the_serial_eager_step(kind, lanes_switch):
     """The captured step (lanes + lane scheduler + weight-gradient lane) against the same driver run eagerly on one stream.
     After ONE optimizer step over ONE pass nothing has been amplified yet: every tensor's UPDATE (clip, SGD with momentum and
     weight decay on the captured pass's gradients) must agree to 1e-4 of the update's scale (the order of atomics in the
-    gradients: ~5e-6; a tensor whose update is below 1 % of the largest one is held on that scale), batch-norm running
+    gradients: ~5e-6; a tensor whose update is below 1 % of the largest one is held on that scale; one unit in the last
+    place of the stored fp32 weight, through which the update is read, is taken off first), batch-norm running
     statistics to 1e-5.  For the search driver that first step is the weight step alone (before ``alpha_begin``,
     experiments/search_arc.py:262-266); its architecture pass on lanes is held to 5e-5 by the gradient test below.  A full
     search step is two passes with an optimizer between them: the second pass's forward already sees architecture weights
@@ -186,7 +187,12 @@ def test_step_drivers_on_lanes_track_the_serial_eager_step(kind, lanes_switch):
     for k, u in upd0.items():
         assert bool(torch.equal(b0[k], b1[k])), k                        # (same start)
         scale = max(float(u.abs().max()), 1e-2 * top)
-        err = float((u - upd1[k]).abs().max()) / scale
+        # The update is read off as (weight after) - (weight before), both fp32: ONE unit in the last place of a weight of
+        # magnitude 0.1 is 7.5e-9, 1.6e-4 of an update of 4.7e-5 -- which is what the gradients' agreement to 2e-7
+        # (tools/diag_lanes_vs_serial.py 32) turns into whenever it tips a rounding.  That one unit of the stored weight is
+        # taken off before the comparison; what the schedules may differ in beyond it stays held to 1e-4.
+        ulp = torch.finfo(torch.float32).eps * s0[k].abs()
+        err = float(((u - upd1[k]).abs() - ulp).clamp_min(0).max()) / scale
         worst = (err, k) if err > worst[0] else worst
         assert err <= 1e-4, (k, err, scale)
     for k in s0:

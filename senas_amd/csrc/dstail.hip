@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mine[j] = s1[j]; mine[4 + j] = s2[j]; }
     }
+    SENAS_PHASE(5);
     if (WG) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co)
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
             for (int co = 0; co < COUT; ++co) stv<4>(mine + co * 4, wacc[co]);
         }
     }
+    SENAS_PHASE(6);
     __syncthreads();
+    SENAS_PHASE(7);
     if ((int)threadIdx.x < Q * 8) {
         const int qq = threadIdx.x >> 3, j8 = threadIdx.x & 7;
         double v = 0.0;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Phase stamps of the LAST node_prepare_bwd launch of one eager search step -- run with the debug library in the
+"""Phase stamps of the LAST node_prepare_bwd (or dstail_bwd_reduce) launch of one eager search step -- run with the debug library in the
 shipped library's place (both built here: `make -C senas_amd/csrc phases`):
 
-    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py
+    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py [node|dstail]
 """
 import ctypes as C
 import os
@@ -20,11 +20,15 @@ def main():
     bench.bench_search(dev, 1, 0, 1, use_graph=False)
     torch.cuda.synchronize()
     L = _lib.lib()
+    which = sys.argv[1] if len(sys.argv) > 1 else 'node'
+    names = {'node': ['start', 'operands requested, dmix partial', 'wave sum + barrier', 'image sums', 'LDS + barrier', 'coefficients stored',
+                      'last barrier'],
+             'dstail': ['start', 'coefficients + weights in LDS', 'pixel loop done', 'S atomics issued', 'dW atomics issued', 'S rows folded',
+                        'dW rows folded', 'barrier passed']}[which]
     buf = (C.c_ulonglong * 64)()
-    assert L.senas_debug_read_phases_node(buf) == 0
+    assert getattr(L, 'senas_debug_read_phases_' + which)(buf) == 0
     v = [int(x) for x in buf]
-    names = ['start', 'operands requested, dmix partial', 'wave sum + barrier', 'image sums', 'LDS + barrier', 'coefficients stored', 'last barrier']
-    for i, nm in enumerate(names):
+    for i, nm in sorted(enumerate(names), key=lambda e: v[e[0]]):
         print('%-36s +%7.2f us' % (nm, (v[i] - v[0]) / 100.0))
 
 

@@ -463,8 +463,8 @@ int senas_bnrelu_multi_bwd(const senas_bnrelu_item* items, int k, int n, int64_t
  *             (ADDED into, may be NULL), mean_invstd (float[2][cin], kept for backward), the running buffers of BN1.
  *   backward: reads z1, dz2 (pixel stride dz2_pixel_stride floats, 0 = cout), w, gamma1, beta1, mean_invstd; sums:
  *             double[n][cin][2], ZERO on entry; writes dz1 (NULL: skipped), dgamma1, dbeta1 (float[cin]) and -- when dw
- *             is given (for all problems or none) -- dw [cout][cin], accumulated in dw_acc (double[cout][cin] =
- *             senas_dstail_ws_bytes(...) bytes per problem, ZERO on entry).                                          */
+ *             is given (for all problems or none) -- dw [cout][cin], accumulated in dw_acc (several double[cout][cin]
+ *             images per batch image: senas_dstail_ws_bytes(...) bytes per problem, ZERO on entry).                  */
 #define SENAS_MAX_DSTAIL 12
 typedef struct senas_dstail_item {
     const float* z1;

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsenas_hip.so')
 
 OK = 0
-EXPECTED_ABI = 34          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
+EXPECTED_ABI = 35          # senas_abi_version() of the library these bindings were written against (include/senas_hip.h)
 MAX_TERMS = 32
 SKIP_MAX = 8               # SENAS_SKIP_MAX
 MAX_STACK = 4

@@ -33,5 +33,5 @@ int raise_lds_limit(const void* kernel, int bytes, const char* what) {
 }  // namespace senas
 
 extern "C" const char* senas_last_error(void) { return senas::g_err; }
-extern "C" int senas_abi_version(void) { return 34; }
+extern "C" int senas_abi_version(void) { return 35; }
 

@@ -23,6 +23,7 @@ struct DsItems {
 };
 
 constexpr int kMaxCin = 64, kMaxCout = 8;
+constexpr int kDwSlots = 1;     // weight-gradient accumulators per image (more, dealt by chunk index, bought nothing: 17.5 us against 17.2)
 
 // scale / shift of BN1 into LDS (sc[0..c) scale, sc[c..2c) shift); training: from the producer-side sums, eval: running
 __device__ __forceinline__ void bn1_coefficients(const senas_dstail_item& it, int nimg, long hw, int c, int training, float momentum,
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
     // partial sums in LDS: 4 us of a 9.5 us launch on the small maps.)
     // No device-scope fence anywhere: on this multi-XCD part a release fence writes the whole L2 back, once per block -- the
     // last-block-folds-the-partials form of this kernel measured 107 us instead of 25.  The apply launch rounds the dW
-    // accumulator (double[COUT][cin], zero on entry) to the fp32 gradient; fp64 accumulation makes the summation order immaterial
+    // accumulators (double[n][kDwSlots][COUT][cin], zero on entry) to the fp32 gradient; fp64 accumulation makes the summation order immaterial
     // at fp32 precision.
     // 16 partials per value: (wave, 16-lane row).  S1 / S2 stay in fp64 throughout; the per-thread dW sums are fp32 already and
     // are folded in fp32 inside a row (one DPP add per step: the fp64 form, two moves and an add per step plus shuffles, cost
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void dstail_bwd_reduce_kernel(DsItems items, l
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += (double)redw[(size_t)(w * Q + (ci >> 2)) * (COUT * 4) + co * 4 + (ci & 3)];
-        atomicAdd(it.dw_acc + e, v);
+        // (an accumulator per image: the 256 blocks of a 256 x 256 problem on ONE address cost 12 - 20 us per launch)
+        atomicAdd(it.dw_acc + ((size_t)n * kDwSlots + (blockIdx.x % kDwSlots)) * nel + e, v);
     }
     SENAS_PHASE(4);
 }
@@ -266,8 +268,13 @@ __global__ __launch_bounds__(256) void dstail_bwd_apply_kernel(DsItems items, in
             if (it.dbeta1 != nullptr) it.dbeta1[ch] = (float)S1;
         }
     }
-    if (writer && it.dw != nullptr)                              // the reduce launch's fp64 accumulator -> the fp32 gradient
-        for (int i = threadIdx.x; i < COUT * cin; i += 256) it.dw[i] = (float)it.dw_acc[i];
+    if (writer && it.dw != nullptr)                              // the reduce launch's fp64 accumulators (kDwSlots per image) -> the fp32 gradient
+        for (int i = threadIdx.x; i < COUT * cin; i += 256) {
+            double v = 0.0;
+#pragma unroll 8
+            for (int im = 0; im < nimg * kDwSlots; ++im) v += it.dw_acc[(size_t)im * COUT * cin + i];       // (fixed order)
+            it.dw[i] = (float)v;
+        }
     for (int i = threadIdx.x; i < COUT * cin; i += 256) wl[i] = it.w[i];
     __syncthreads();
     if (it.dz1 == nullptr) return;
@@ -346,7 +353,7 @@ extern "C" int senas_dstail_fwd(const senas_dstail_item* items, int k, int n, in
 extern "C" int64_t senas_dstail_ws_bytes(int k, int n, int64_t hw, int cin, int cout) {
     using namespace senas;
     if (!ds_ok(k, n, hw, cin, cout)) return 0;
-    return (int64_t)cin * cout * sizeof(double);                    // the fp64 weight-gradient accumulator of one problem
+    return (int64_t)n * kDwSlots * cin * cout * sizeof(double);     // the fp64 weight-gradient accumulators of one problem: kDwSlots per image
 }
 
 extern "C" int senas_dstail_bwd(const senas_dstail_item* items, int k, int n, int64_t hw, int cin, int cout, void* stream) {

@@ -1826,7 +1826,8 @@ class _DsTail(torch.autograd.Function):
         dbt, dbs = zip(*[wgrad_dest(b) for b in betas])
         dwt, dws = zip(*[wgrad_dest(w) for w in ws]) if want_w else ((None,) * k, (None,) * k)
         sums = zeros64((k, n, cin, 2), dev)
-        dw_acc = zeros64((k, cout * cin), dev) if want_w else None          # fp64 accumulators of the k weight gradients
+        # fp64 accumulators of the k weight gradients (senas_dstail_ws_bytes per problem: one image of cout x cin per batch image)
+        dw_acc = zeros64((k, int(L.senas_dstail_ws_bytes(k, n, h * w_, cin, cout)) // 8), dev) if want_w else None
         items = (_lib.DsTailItem * k)()
         keep = []
         for t in range(k):

@@ -57,7 +57,7 @@ def main():
         it.dgamma1, it.dbeta1 = t(cin).data_ptr(), t(cin).data_ptr()
         if not nowg:
             it.dw = t(cout, cin).data_ptr()
-            it.dw_acc = t(cout, cin, dtype=torch.float64, fill=0.0).data_ptr()
+            it.dw_acc = t(n, cout, cin, dtype=torch.float64, fill=0.0).data_ptr()       # (senas_dstail_ws_bytes)
         st1 = t(n, cin, 2, dtype=torch.float64, fill=0.0)
         st1[..., 1] = float(hw)
         it.stats1 = st1.data_ptr()

@@ -632,6 +632,8 @@ _CONV_CASES = [
     (2, 24, 32, 24, 40, 3, 1, 1, False, False),     # c_in = 24: not a 16-channel multiple -> direct-global MFMA
     (2, 32, 8, 32, 32, 5, 1, 3, False, False),      # supernet width (8 output channels)
     (2, 32, 32, 32, 48, 5, 2, 3, False, False),     # stride-2 conv: dgrad runs the 4-phase transposed gather
+    (2, 64, 32, 16, 16, 5, 2, 2, False, False),     # ... 32 blocks: 8 waves split the K steps of a sub-tile; even dilation (3 empty phases)
+    (4, 32, 64, 48, 48, 3, 2, 1, False, False),     # ... 288 blocks: 4 waves per sub-tile
     (2, 32, 32, 16, 24, 5, 2, 2, True, False),      # ConvTranspose2d (UP ops), even dilation: 3 empty phases
     (2, 32, 32, 16, 24, 3, 2, 1, True, True),
     (3, 1, 32, 40, 40, 7, 1, 1, False, False),      # stem: small-c_in weight gradient
@@ -1579,6 +1581,8 @@ def test_bnrelu_multi_vs_torch(case):
                                   # kernel size 0: dep_sep_conv_3 and dep_sep_conv_5 of the same edges share the launches (3, 5, 3, 5, ...)
                                   (6, 4, 32, 16, 16, 0, 1, False), (6, 2, 32, 16, 24, 0, 2, False), (6, 2, 32, 8, 12, 0, 2, True),
                                   (2, 2, 8, 12, 12, 0, 1, False), (4, 3, 8, 9, 11, 0, 1, False), (8, 1, 16, 8, 8, 0, 2, True),
+                                  # stride 2 on small maps: the data gradient requests the tap slots of three problems together
+                                  (3, 2, 16, 10, 14, 5, 2, False), (5, 1, 8, 9, 11, 0, 2, False), (7, 2, 32, 8, 8, 0, 2, False),
                                   # past 128 blocks of outputs the data gradient is one thread per output again (no problem split)
                                   (6, 4, 8, 128, 144, 0, 1, False), (6, 4, 8, 128, 144, 0, 2, False)])
 def test_dwconv_multi_vs_single(case):

@@ -47,6 +47,7 @@ rm -rf $out/cellstrace
 # the bench line last: its `traffic` fields are read from the counter aggregates of THIS run
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 cp $out/pmc_traffic_search.json profiles/${tag}_pmc_traffic_search.json
+cp $out/search_steady.txt profiles/${tag}_search_steady.txt          # (search_step.roofline.by_family reads this table)
 python3 bench.py > $out/bench.log 2> $out/bench.err
 tail -1 $out/bench.log > $out/bench.json
 # keep what travels back small: the raw traces are only needed for the aggregates above

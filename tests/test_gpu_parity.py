@@ -1836,7 +1836,9 @@ def test_skip_stack_vs_torch(case):
 
 @pytest.mark.parametrize('case', [(3, 2, 32, 8, 12, 20, True, False), (6, 4, 32, 8, 16, 16, True, True), (2, 2, 8, 8, 9, 7, True, False),
                                   (8, 1, 64, 4, 8, 8, True, True), (1, 3, 16, 8, 5, 5, True, False), (4, 2, 32, 8, 8, 12, False, False),
-                                  (6, 4, 32, 8, 64, 64, True, False)])
+                                  (6, 4, 32, 8, 64, 64, True, False),
+                                  # one channel quad (every lane of a row folds into one), 12 problems, 8 images (an accumulator each)
+                                  (2, 2, 4, 4, 6, 10, True, False), (12, 2, 8, 8, 16, 16, True, False), (3, 8, 16, 8, 12, 12, True, True)])
 def test_dstail_vs_torch(case):
     """senas_dstail_fwd / _bwd -- BatchNorm2d + ReLU + 1x1 convolution of k DepSepConv candidates as one pass, the activated
     tensor recomputed instead of stored -- against float64 torch: outputs, producer statistics, running buffers, dz1,

@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
                                                             float* __restrict__ se_m, float* __restrict__ se_a1,
                                                             double* __restrict__ out_stats, float* __restrict__ y2, int y2s, int y2pad) {
     extern __shared__ __attribute__((aligned(16))) float ldsw[];
+    SENAS_PHASE(8);
     const int n = blockIdx.y, nimg = d.n, c = d.c, T = d.nterms, TC = T * c;
     const bool first = blockIdx.x == 0, writer0 = first && n == 0;
     const int R = 256 / c;                  // the prepare kernel's image rows: the batch sums are associated as it associates them
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
 #pragma unroll
     for (int j = 0; j < V; ++j) rsd[j] = 0.f;
     if (live && residual != nullptr) ldv<V>(residual + off, rsd);
+    SENAS_PHASE(9);
     // ---- the preparation: one thread per (term, channel)
     for (int i = threadIdx.x; i < TC; i += 256) {
         const int t = i / c, ch = i - t * c;
@@ -527,9 +529,11 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
             if (first) se_m[((size_t)t * nimg + n) * c + ch] = mv;
         }
     }
+    SENAS_PHASE(10);
     if (writer0 && d.training)
         for (int t = threadIdx.x; t < T; t += 256) if (d.nbt[t] != nullptr) *d.nbt[t] += 1;
     __syncthreads();
+    SENAS_PHASE(11);
     for (int idx = threadIdx.x; idx < T * kMaxMid; idx += 256) {
         const int t = idx / kMaxMid, j = idx - t * kMaxMid;
         if (d.w1[t] == nullptr || j >= d.mid[t]) continue;
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
         if (first) se_a1[((size_t)t * nimg + n) * kMaxMid + j] = a;
     }
     __syncthreads();
+    SENAS_PHASE(12);
     for (int i = threadIdx.x; i < TC; i += 256) {
         const int t = i / c, ch = i - t * c;
         const float w = d.mix != nullptr ? d.mix[t] : 1.f;
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
         bias[ch] = b;
     }
     __syncthreads();
+    SENAS_PHASE(13);
     // ---- the stream: y = act(bias + residual + sum_t cf[t] * z_t), exactly combine_stream's arithmetic for one element
     Stats4 ost;
     stats_init4(ost);
@@ -600,7 +606,9 @@ __global__ __launch_bounds__(256) void node_wide_fwd_kernel(NodeDesc d, ZTable z
         }
         if constexpr (V == 4) stats_accumulate4(ost, out_stats, true, n, c, ech, acc, true);
     }
+    SENAS_PHASE(14);
     if constexpr (V == 4) stats_flush4(ost, out_stats, true, n, c, (int)(threadIdx.x % cv) * V);
+    SENAS_PHASE(15);
 }
 
 static size_t wide_fwd_lds(const NodeDesc& d) {

@@ -2,7 +2,7 @@
 """Phase stamps of the LAST node_prepare_bwd (or dstail_bwd_reduce) launch of one eager search step -- run with the debug library in the
 shipped library's place (both built here: `make -C senas_amd/csrc phases`):
 
-    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py [node|dstail]
+    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py [node|wide|dstail]
 """
 import ctypes as C
 import os
@@ -23,13 +23,16 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'node'
     names = {'node': ['start', 'operands requested, dmix partial', 'wave sum + barrier', 'image sums', 'LDS + barrier', 'coefficients stored',
                       'last barrier'],
+             'wide': [None] * 8 + ['start', 'operands requested', 'prologue items done', 'barrier 1', 'SE hidden layer + barrier 2',
+                                   'coefficients + bias + barriers', 'element written', 'statistics flushed'],
              'dstail': ['start', 'coefficients + weights in LDS', 'pixel loop done', 'S atomics issued', 'dW atomics issued', 'S rows folded',
                         'dW rows folded', 'barrier passed']}[which]
     buf = (C.c_ulonglong * 64)()
-    assert getattr(L, 'senas_debug_read_phases_' + which)(buf) == 0
+    assert getattr(L, 'senas_debug_read_phases_' + ('node' if which == 'wide' else which))(buf) == 0
     v = [int(x) for x in buf]
-    for i, nm in sorted(enumerate(names), key=lambda e: v[e[0]]):
-        print('%-36s +%7.2f us' % (nm, (v[i] - v[0]) / 100.0))
+    base = min(v[i] for i, nm in enumerate(names) if nm is not None)
+    for i, nm in sorted(((i, nm) for i, nm in enumerate(names) if nm is not None), key=lambda e: v[e[0]]):
+        print('%-36s +%7.2f us' % (nm, (v[i] - base) / 100.0))
 
 
 if __name__ == '__main__':

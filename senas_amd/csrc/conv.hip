@@ -261,11 +261,13 @@ __device__ __forceinline__ void dwconv_x4_body(const GatherGeom& g, const float*
     extern __shared__ __attribute__((aligned(16))) float wl[];      // [tap][C]
     constexpr int TAPS = KS * KS, COLS = 3 * S + KS;
     const int C = g.cout;
+    SENAS_PHASE(16);
     for (int i = threadIdx.x; i < TAPS * C; i += 256) {
         const int t = i / C, cc = i - t * C;
         wl[i] = w[cc * TAPS + (flip ? TAPS - 1 - t : t)];
     }
     __syncthreads();
+    SENAS_PHASE(17);
     Stats4 acc_st;
     stats_init4(acc_st);
     const bool uniform = P > 0;
@@ -310,6 +312,7 @@ __device__ __forceinline__ void dwconv_x4_body(const GatherGeom& g, const float*
                 }
             }
         }
+        SENAS_PHASE(18);
         const size_t o = (((size_t)n * g.hout + oy) * g.wout + ox0) * C + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -317,7 +320,9 @@ __device__ __forceinline__ void dwconv_x4_body(const GatherGeom& g, const float*
             stats_accumulate4(acc_st, stats, uniform, n, C, c, acc[j], active);
         }
     }
+    SENAS_PHASE(19);
     stats_flush4(acc_st, stats, uniform, n_blk, C, c_thr);
+    SENAS_PHASE(20);
 }
 
 template <int KS, int S>

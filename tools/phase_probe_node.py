@@ -2,7 +2,7 @@
 """Phase stamps of the LAST node_prepare_bwd (or dstail_bwd_reduce) launch of one eager search step -- run with the debug library in the
 shipped library's place (both built here: `make -C senas_amd/csrc phases`):
 
-    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py [node|wide|dstail]
+    cp senas_amd/libsenas_hip_phases.so senas_amd/libsenas_hip.so && python tools/phase_probe_node.py [node|wide|dstail|dwfwd]
 """
 import ctypes as C
 import os
@@ -25,10 +25,11 @@ def main():
                       'last barrier'],
              'wide': [None] * 8 + ['start', 'operands requested', 'prologue items done', 'barrier 1', 'SE hidden layer + barrier 2',
                                    'coefficients + bias + barriers', 'element written', 'statistics flushed'],
+             'dwfwd': [None] * 16 + ['start', 'weights staged + barrier', 'taps done (last chunk)', 'outputs stored, statistics accumulated', 'statistics flushed'],
              'dstail': ['start', 'coefficients + weights in LDS', 'pixel loop done', 'S atomics issued', 'dW atomics issued', 'S rows folded',
                         'dW rows folded', 'barrier passed']}[which]
     buf = (C.c_ulonglong * 64)()
-    assert getattr(L, 'senas_debug_read_phases_' + ('node' if which == 'wide' else which))(buf) == 0
+    assert getattr(L, 'senas_debug_read_phases_' + {'wide': 'node', 'dwfwd': 'conv'}.get(which, which))(buf) == 0
     v = [int(x) for x in buf]
     base = min(v[i] for i, nm in enumerate(names) if nm is not None)
     for i, nm in sorted(((i, nm) for i, nm in enumerate(names) if nm is not None), key=lambda e: v[e[0]]):
